@@ -1,0 +1,508 @@
+/*
+ * gear_oracle.c -- CPU restatement of the GEAR KV-cache compress / decompress hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP kernels in
+ * gear_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product path (gear_amd/) never links, imports or falls back to it.
+ *
+ * Parity pin: every function below is checked against golden vectors produced by EXECUTING the
+ * reference's own Python (cuda_supported_gear/quant/new_pack.py and
+ * GenerationBench/.../Simulated/compress_function.py) in the build container; the vectors and the
+ * generating script live in tests/golden/ (see tests/golden/make_golden.py, tests/test_oracle_golden.py).
+ * The reference's own tests hold no golden values for this path.
+ *
+ * Citations are relative to /root/reference:
+ *   CSG = cuda_supported_gear, SIM = GenerationBench/GenerationTest/GEARLM/Simulated
+ *
+ * Arithmetic modes
+ *   mode 0 "fp16-stepwise": every elementwise op is computed in fp32 and rounded to fp16 before the
+ *          next op -- torch eager semantics on fp16 tensors (CSG/quant/new_pack.py:34-45, :237-240,
+ *          :273-278; SIM/compress_function.py:53-59 when fed fp16).  Packed payload is bit-exact.
+ *   mode 1 "fp32": the simulated path's arithmetic after .float() (SIM/compress_function.py:14-33,
+ *          :116-125, :147-151).  scale / mn are kept in fp32.
+ *
+ * Deliberate, documented divergences from the reference:
+ *   B6  zero-range group (mx == mn): reference yields NaN; here code = 0, scale = 0, dequant = mn.
+ *   B1  the _witherror variant packs ALL columns (the reference's pack grid covers only a prefix).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint16_t h16;
+
+/* ---------------------------------------------------------------- fp16 <-> fp32 (IEEE, RNE) */
+static inline float h2f(h16 h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal */
+            int e = -1;
+            do { e++; man <<= 1; } while ((man & 0x400u) == 0);
+            man &= 0x3FFu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112u) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline h16 f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) { /* inf / nan */
+        return (h16)(sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x200u : 0u));
+    }
+    if (ax >= 0x477FF000u) { /* >= 65520 rounds to inf */
+        return (h16)(sign | 0x7C00u);
+    }
+    if (ax < 0x38800000u) { /* subnormal half or zero: |f| < 2^-14 */
+        if (ax < 0x33000000u) return (h16)sign; /* < 2^-25 -> 0 (2^-25 exactly ties to even = 0) */
+        uint32_t e = ax >> 23;                  /* biased exponent, 102..112 */
+        uint32_t m = (ax & 0x7FFFFFu) | 0x800000u;
+        uint32_t shift = 126u - e;              /* 14..24 */
+        uint32_t hm = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        return (h16)(sign | hm);
+    }
+    uint32_t e = (ax >> 23) - 112u;
+    uint32_t m = ax & 0x7FFFFFu;
+    uint32_t hm = (e << 10) | (m >> 13);
+    uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (hm & 1u))) hm++; /* carry into exponent is correct */
+    return (h16)(sign | hm);
+}
+
+/* exported for tests of the conversion helpers themselves */
+float orc_h2f(h16 h) { return h2f(h); }
+h16 orc_f2h(float f) { return f2h(f); }
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---------------------------------------------------------------- group quantizer core
+ * One group of g values (strided by `st` elements).  Writes g integer codes to q[].
+ * mode 0: CSG/quant/new_pack.py:237-240 (== :34-45 quant_and_pack_vcache, :17-24 kcache)
+ * mode 1: SIM/compress_function.py:24-28 (token), :116-120 (channel cluster), :147-151 (token cluster)
+ * levels = 2^bits - 1 (== bit**2 - 1 for bits in {2,4}, compress_function.py:286,:322).
+ */
+static inline void quant_group_fp16(const h16* x, int64_t st, int g, int levels, int* q, h16* scale_o, h16* mn_o,
+                                    h16* err, int64_t est, h16* deq, int64_t dst) {
+    float mnf = h2f(x[0]), mxf = mnf;
+    for (int j = 1; j < g; j++) {
+        float v = h2f(x[j * st]);
+        if (v < mnf) mnf = v;
+        if (v > mxf) mxf = v;
+    }
+    h16 mn_h = f2h(mnf);
+    h16 range_h = f2h(mxf - mnf);                    /* (mx - mn) -> fp16 */
+    h16 scale_h = f2h(h2f(range_h) / (float)levels); /* / max_int  -> fp16 */
+    float sc = h2f(scale_h);
+    for (int j = 0; j < g; j++) {
+        float v = h2f(x[j * st]);
+        int qi = 0;
+        if (sc != 0.0f) {
+            h16 t1 = f2h(v - mnf);          /* data - mn        */
+            h16 t2 = f2h(h2f(t1) / sc);     /* data.div_(scale) */
+            float c = h2f(t2);
+            if (c < 0.0f) c = 0.0f;         /* clamp_(0, max_int) */
+            if (c > (float)levels) c = (float)levels;
+            qi = (int)nearbyintf(c);        /* round_() half-to-even, .to(int32) */
+        }
+        q[j] = qi;
+        if (err || deq) {
+            /* new_pack.py:277-278: dequant_sim = quant*scale + mn ; error = data - dequant_sim (fp16 ops) */
+            h16 p = f2h((float)qi * sc);
+            h16 d = f2h(h2f(p) + mnf);
+            if (deq) deq[j * dst] = d;
+            if (err) err[j * est] = f2h(v - h2f(d));
+        }
+    }
+    *scale_o = scale_h;
+    *mn_o = mn_h;
+}
+
+static inline void quant_group_fp32(const float* x, int64_t st, int g, int levels, int* q, float* scale_o,
+                                    float* mn_o, float* deq, int64_t dst) {
+    float mnf = x[0], mxf = mnf;
+    for (int j = 1; j < g; j++) {
+        float v = x[j * st];
+        if (v < mnf) mnf = v;
+        if (v > mxf) mxf = v;
+    }
+    float sc = (mxf - mnf) / (float)levels;
+    for (int j = 0; j < g; j++) {
+        int qi = 0;
+        if (sc != 0.0f) {
+            float c = (x[j * st] - mnf) / sc;
+            if (c < 0.0f) c = 0.0f; /* F.relu */
+            float rq = nearbyintf(c);
+            if (rq > (float)levels) rq = (float)levels; /* cannot trigger for finite data; keeps the pack well-defined */
+            qi = (int)rq;
+        }
+        q[j] = qi;
+        if (deq) {
+            float p = (float)qi * sc; /* separate mul and add: torch does not fuse */
+            deq[j * dst] = p + mnf;
+        }
+    }
+    *scale_o = sc;
+    *mn_o = mnf;
+}
+
+/* ---------------------------------------------------------------- a1 / a2 / a3(V): quantize + pack along the last dim
+ * x      : [rows, L] fp16 (mode 0) ; for mode 1 pass x32 [rows, L] float instead (x may be NULL)
+ * code   : [rows, L/fpi] int32, element j of a word-group at bits [b*(j%fpi), ...) (new_pack.py:104, :148-153)
+ * scale,mn: [rows, L/g] fp16 (mode 0) or float (mode 1)
+ * err    : optional [rows, L] fp16 (mode 0 only; new_pack.py:277-278)
+ * deq    : optional [rows, L] fp16 (mode 0) / float (mode 1) dequantized values
+ * Reference: triton_quantize_and_pack_along_last_dim (new_pack.py:217-250), _witherror (:253-288),
+ *            quant_and_pack_vcache (:30-48); fake_groupwise_token_asymmetric_quantization
+ *            (SIM/compress_function.py:7-37) and the _cluster variant (:132-160) for mode 1.
+ */
+int orc_quant_pack_lastdim(const h16* x, const float* x32, int64_t rows, int L, int g, int bits, int mode,
+                           int32_t* code, void* scale, void* mn, h16* err, void* deq) {
+    if (bits != 2 && bits != 4 && bits != 8) return -1;
+    if (g <= 0 || L % g != 0) return -2;
+    const int fpi = 32 / bits;
+    if (L % fpi != 0) return -3;
+    const int levels = (1 << bits) - 1;
+    const int ng = L / g;
+    const int nw = L / fpi;
+#pragma omp parallel
+    {
+        int* q = (int*)malloc(sizeof(int) * (size_t)L);
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < rows; r++) {
+            for (int G = 0; G < ng; G++) {
+                if (mode == 0) {
+                    quant_group_fp16(x + r * L + (int64_t)G * g, 1, g, levels, q + G * g, (h16*)scale + r * ng + G,
+                                     (h16*)mn + r * ng + G, err ? err + r * L + (int64_t)G * g : NULL, 1,
+                                     deq ? (h16*)deq + r * L + (int64_t)G * g : NULL, 1);
+                } else {
+                    quant_group_fp32(x32 + r * L + (int64_t)G * g, 1, g, levels, q + G * g, (float*)scale + r * ng + G,
+                                     (float*)mn + r * ng + G, deq ? (float*)deq + r * L + (int64_t)G * g : NULL, 1);
+                }
+            }
+            if (code) {
+                for (int w = 0; w < nw; w++) {
+                    uint32_t word = 0;
+                    for (int j = 0; j < fpi; j++) word |= (uint32_t)q[w * fpi + j] << (bits * j);
+                    code[r * nw + w] = (int32_t)word;
+                }
+            }
+        }
+        free(q);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a3(K): quantize + pack along T of a token-major tile
+ * x     : [bh, T, D] fp16 (mode 0) / x32 float (mode 1); groups of g consecutive tokens per channel
+ * code  : [bh, T/fpi, D] int32 (pack_dim = 2, new_pack.py:26) ; scale, mn : [bh, T/g, D]
+ * err/deq: optional [bh, T, D]
+ * Reference: quant_and_pack_kcache (new_pack.py:8-27); SIM fake_groupwise_channel_asymmetric_quantization_new
+ *            (compress_function.py:39-67, input-dtype arithmetic) and _cluster (:100-130, fp32 after .float()).
+ * Tokens beyond floor(T/g)*g are left unquantized only by the _cluster variant (:109-122); this
+ * function requires T % g == 0 and the Python glue handles the tail.
+ */
+int orc_quant_pack_k(const h16* x, const float* x32, int64_t bh, int T, int D, int g, int bits, int mode,
+                     int32_t* code, void* scale, void* mn, h16* err, void* deq) {
+    if (bits != 2 && bits != 4 && bits != 8) return -1;
+    if (g <= 0 || T % g != 0) return -2;
+    const int fpi = 32 / bits;
+    if (T % fpi != 0 && code) return -3;
+    const int levels = (1 << bits) - 1;
+    const int ng = T / g;
+#pragma omp parallel
+    {
+        int* q = (int*)malloc(sizeof(int) * (size_t)T);
+#pragma omp for schedule(static) collapse(2)
+        for (int64_t b = 0; b < bh; b++) {
+            for (int d = 0; d < D; d++) {
+                for (int G = 0; G < ng; G++) {
+                    int64_t off = b * (int64_t)T * D + (int64_t)G * g * D + d;
+                    int64_t soff = b * (int64_t)ng * D + (int64_t)G * D + d;
+                    if (mode == 0) {
+                        quant_group_fp16(x + off, D, g, levels, q + G * g, (h16*)scale + soff, (h16*)mn + soff,
+                                         err ? err + off : NULL, D, deq ? (h16*)deq + off : NULL, D);
+                    } else {
+                        quant_group_fp32(x32 + off, D, g, levels, q + G * g, (float*)scale + soff, (float*)mn + soff,
+                                         deq ? (float*)deq + off : NULL, D);
+                    }
+                }
+                if (code) {
+                    for (int w = 0; w < T / fpi; w++) {
+                        uint32_t word = 0;
+                        for (int j = 0; j < fpi; j++) word |= (uint32_t)q[w * fpi + j] << (bits * j);
+                        code[b * (int64_t)(T / fpi) * D + (int64_t)w * D + d] = (int32_t)word;
+                    }
+                }
+            }
+        }
+        free(q);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a3: unpack + dequant
+ * Reference: unpack_tensor (new_pack.py:110-129: arithmetic shift then mask 0xFF>>(8-b)),
+ *            unpack_and_dequant_vcache (:69-83), unpack_and_dequant_kcache (:51-66):
+ *            data.to(fp16) * scale + mn in fp16 (mode 0).  mode 1: q*scale+mn in fp32, one rounding.
+ * out: fp16 [rows, L] (lastdim) / [bh, T, D] (k).  out32 (optional, mode 1): un-rounded float.
+ */
+int orc_unpack_dequant_lastdim(const int32_t* code, const void* scale, const void* mn, int64_t rows, int L, int g,
+                               int bits, int mode, h16* out, float* out32) {
+    if (bits != 2 && bits != 4 && bits != 8) return -1;
+    const int fpi = 32 / bits;
+    const int ng = L / g, nw = L / fpi;
+    const uint32_t mask = 0xFFu >> (8 - bits);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++) {
+        for (int j = 0; j < L; j++) {
+            int32_t w = code[r * nw + j / fpi];
+            float q = (float)(((uint32_t)(w >> (bits * (j % fpi)))) & mask);
+            if (mode == 0) {
+                float sc = h2f(((const h16*)scale)[r * ng + j / g]);
+                float m = h2f(((const h16*)mn)[r * ng + j / g]);
+                out[r * L + j] = f2h(h2f(f2h(q * sc)) + m);
+            } else {
+                float sc = ((const float*)scale)[r * ng + j / g];
+                float m = ((const float*)mn)[r * ng + j / g];
+                float p = q * sc;
+                float v = p + m;
+                if (out) out[r * L + j] = f2h(v);
+                if (out32) out32[r * L + j] = v;
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_unpack_dequant_k(const int32_t* code, const void* scale, const void* mn, int64_t bh, int T, int D, int g,
+                         int bits, int mode, h16* out, float* out32) {
+    if (bits != 2 && bits != 4 && bits != 8) return -1;
+    const int fpi = 32 / bits;
+    const int ng = T / g, nw = T / fpi;
+    const uint32_t mask = 0xFFu >> (8 - bits);
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t b = 0; b < bh; b++) {
+        for (int t = 0; t < T; t++) {
+            for (int d = 0; d < D; d++) {
+                int32_t w = code[b * (int64_t)nw * D + (int64_t)(t / fpi) * D + d];
+                float q = (float)(((uint32_t)(w >> (bits * (t % fpi)))) & mask);
+                int64_t so = b * (int64_t)ng * D + (int64_t)(t / g) * D + d;
+                int64_t o = b * (int64_t)T * D + (int64_t)t * D + d;
+                if (mode == 0) {
+                    float sc = h2f(((const h16*)scale)[so]);
+                    float m = h2f(((const h16*)mn)[so]);
+                    out[o] = f2h(h2f(f2h(q * sc)) + m);
+                } else {
+                    float sc = ((const float*)scale)[so];
+                    float m = ((const float*)mn)[so];
+                    float p = q * sc;
+                    float v = p + m;
+                    if (out) out[o] = f2h(v);
+                    if (out32) out32[o] = v;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a6: decompress-into-attention GEMV
+ * out[ba, n] = sum_k a[ba, k] * (scale[bw, k, n/g] * code[bw, k, n] + zero[bw, k, n/g]),  bw = ba / n_rep
+ * a    : [BA, K] fp16            (fA [B,nh,1,K] flattened)
+ * qB   : [BW, K, N/fpi] int32    (cuda_bmm_fA_qB_outer's argument layout, CSG/quant/matmul.py:178-196)
+ * scale, zero : [BW, K, N/g] fp16 (mode 0) / float (mode 1)
+ * n_rep: query heads per KV head (1 = MHA; the reference's `mqa` flag maps batch_idx/nh, gemv_cuda.cu:276-279)
+ * Arithmetic: gemv_cuda.cu:331-335 (w = scale*code + zero in fp32; psum += w*in in fp32), :343-345 one
+ * __float2half at the end.  Summation order is unspecified by the reference; the oracle accumulates in
+ * double so that it is order-neutral, and callers compare with a tolerance.
+ */
+int orc_gemv_outer(const h16* a, const int32_t* qB, const void* scale, const void* zero, int64_t BA, int n_rep,
+                   int K, int N, int g, int bits, int mode, h16* out, float* out32) {
+    if (bits != 2 && bits != 4) return -1; /* matmul.py:217 */
+    if (n_rep < 1 || BA % n_rep != 0) return -2;
+    const int fpi = 32 / bits;
+    const int nw = N / fpi, ng = N / g;
+    const uint32_t mask = 0xFFu >> (8 - bits);
+#pragma omp parallel
+    {
+        double* acc = (double*)malloc(sizeof(double) * (size_t)N);
+#pragma omp for schedule(static)
+        for (int64_t ba = 0; ba < BA; ba++) {
+            int64_t bw = ba / n_rep;
+            for (int n = 0; n < N; n++) acc[n] = 0.0;
+            for (int k = 0; k < K; k++) {
+                float in = h2f(a[ba * K + k]);
+                const int32_t* wrow = qB + (bw * K + k) * (int64_t)nw;
+                for (int n = 0; n < N; n++) {
+                    float q = (float)(((uint32_t)(wrow[n / fpi] >> (bits * (n % fpi)))) & mask);
+                    float sc, z;
+                    if (mode == 0) {
+                        sc = h2f(((const h16*)scale)[(bw * K + k) * (int64_t)ng + n / g]);
+                        z = h2f(((const h16*)zero)[(bw * K + k) * (int64_t)ng + n / g]);
+                    } else {
+                        sc = ((const float*)scale)[(bw * K + k) * (int64_t)ng + n / g];
+                        z = ((const float*)zero)[(bw * K + k) * (int64_t)ng + n / g];
+                    }
+                    float w = sc * q + z;
+                    acc[n] += (double)w * (double)in;
+                }
+            }
+            for (int n = 0; n < N; n++) {
+                if (out) out[ba * N + n] = f2h((float)acc[n]);
+                if (out32) out32[ba * N + n] = (float)acc[n];
+            }
+        }
+        free(acc);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a4 / a10: low-rank power iteration
+ * E  : [bh, S, Dm] float   P0 : [bh, Dm, r] float (the reference draws it with torch.rand on the CPU
+ *      generator, new_pack.py:296 / compress_function.py:83; the caller supplies it)
+ * for i in range(loop): [last: P = orth(P)]  Q = E P  [last: Q = orth(Q)]  P = E^T Q
+ *      (new_pack.py:298-304, compress_function.py:86-92).  Approximation is Q P^T.
+ * orth(): the reference uses torch.linalg.qr (Householder).  Q P^T depends only on span(P) before the
+ * last E P and on span(Q) after it, so any orthonormalisation gives the same product up to rounding;
+ * here: modified Gram-Schmidt with one re-orthogonalisation pass (double accumulation).
+ * Outputs P [bh, Dm, r], Q [bh, S, r] in float (the reference casts to fp16 at new_pack.py:309-310; the
+ * Python glue does that cast).
+ */
+static void mgs2(float* A, int n, int r) { /* A: [n, r] row-major, orthonormalise columns in place */
+    for (int j = 0; j < r; j++) {
+        for (int pass = 0; pass < 2; pass++) {
+            for (int i = 0; i < j; i++) {
+                double dot = 0.0;
+                for (int t = 0; t < n; t++) dot += (double)A[t * r + i] * (double)A[t * r + j];
+                for (int t = 0; t < n; t++) A[t * r + j] = (float)((double)A[t * r + j] - dot * (double)A[t * r + i]);
+            }
+        }
+        double nrm = 0.0;
+        for (int t = 0; t < n; t++) nrm += (double)A[t * r + j] * (double)A[t * r + j];
+        nrm = sqrt(nrm);
+        double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+        for (int t = 0; t < n; t++) A[t * r + j] = (float)((double)A[t * r + j] * inv);
+    }
+}
+
+int orc_lowrank(const float* E, int64_t bh, int S, int Dm, int r, int loop, const float* P0, float* P, float* Q) {
+    if (r <= 0 || loop <= 0) return -1;
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t b = 0; b < bh; b++) {
+        const float* e = E + b * (int64_t)S * Dm;
+        float* p = P + b * (int64_t)Dm * r;
+        float* q = Q + b * (int64_t)S * r;
+        memcpy(p, P0 + b * (int64_t)Dm * r, sizeof(float) * (size_t)Dm * r);
+        for (int it = 0; it < loop; it++) {
+            if (it == loop - 1) mgs2(p, Dm, r);
+            /* Q = E P */
+            for (int s = 0; s < S; s++) {
+                for (int c = 0; c < r; c++) {
+                    float acc = 0.0f;
+                    for (int d = 0; d < Dm; d++) acc += e[(int64_t)s * Dm + d] * p[d * r + c];
+                    q[(int64_t)s * r + c] = acc;
+                }
+            }
+            if (it == loop - 1) mgs2(q, S, r);
+            /* P = E^T Q */
+            for (int d = 0; d < Dm; d++)
+                for (int c = 0; c < r; c++) p[d * r + c] = 0.0f;
+            for (int s = 0; s < S; s++) {
+                for (int d = 0; d < Dm; d++) {
+                    float ev = e[(int64_t)s * Dm + d];
+                    for (int c = 0; c < r; c++) p[d * r + c] += ev * q[(int64_t)s * r + c];
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* out[bh, S, Dm] = Q P^T (float).  compress_function.py:93 */
+int orc_lowrank_reconstruct(const float* P, const float* Q, int64_t bh, int S, int Dm, int r, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < bh; b++) {
+        for (int s = 0; s < S; s++) {
+            for (int d = 0; d < Dm; d++) {
+                float acc = 0.0f;
+                for (int c = 0; c < r; c++) acc += Q[(b * S + s) * (int64_t)r + c] * P[(b * Dm + d) * (int64_t)r + c];
+                out[(b * S + s) * (int64_t)Dm + d] = acc;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a11: per-row outlier selection
+ * x : [rows, len] float.  Selects the k smallest and k largest entries of each row
+ * (torch.topk largest=False / True, compress_function.py:273-275, :309-311) and the row mean
+ * (:276, :312 -- mean of the ORIGINAL row, outliers included).
+ * idx_small, idx_large : [rows, k] int32 column indices; ordered by value (ascending for small,
+ * descending for large), ties broken by LOWER INDEX FIRST.  torch.topk's tie order is
+ * implementation-defined, so this rule is the build's definition; golden fixtures avoid ties on the
+ * selection boundary except in the dedicated tie case, where parity is on the restored tensor.
+ */
+typedef struct { float v; int32_t i; } vi_t;
+static int cmp_asc(const void* a, const void* b) {
+    const vi_t* x = (const vi_t*)a; const vi_t* y = (const vi_t*)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+static int cmp_desc(const void* a, const void* b) {
+    const vi_t* x = (const vi_t*)a; const vi_t* y = (const vi_t*)b;
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+int orc_outlier_select(const float* x, int64_t rows, int len, int k, int32_t* idx_small, int32_t* idx_large,
+                       float* mean) {
+    if (k < 0 || k > len) return -1;
+#pragma omp parallel
+    {
+        vi_t* buf = (vi_t*)malloc(sizeof(vi_t) * (size_t)len);
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < rows; r++) {
+            const float* xr = x + r * len;
+            double s = 0.0;
+            for (int j = 0; j < len; j++) s += (double)xr[j];
+            if (mean) mean[r] = (float)(s / (double)len);
+            if (k == 0) continue;
+            for (int j = 0; j < len; j++) { buf[j].v = xr[j]; buf[j].i = j; }
+            qsort(buf, (size_t)len, sizeof(vi_t), cmp_asc);
+            for (int j = 0; j < k; j++) idx_small[r * k + j] = buf[j].i;
+            qsort(buf, (size_t)len, sizeof(vi_t), cmp_desc);
+            for (int j = 0; j < k; j++) idx_large[r * k + j] = buf[j].i;
+        }
+        free(buf);
+    }
+    return 0;
+}
