@@ -1,0 +1,86 @@
+"""ctypes binding of libgear_hip.so (C ABI: include/gear_hip.h).  Fails loudly -- no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgear_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MODE_FP16_STEPWISE = 0
+MODE_FP32 = 1
+
+_lib = None
+
+_vp, _i64, _i, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gear_hip.h one to one
+SIGNATURES = {
+    "gear_last_error": (C.c_char_p, []),
+    "gear_abi_version": (_i, []),
+    "gear_quant_pack_lastdim": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gear_quant_pack_k": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gear_unpack_dequant_lastdim": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "gear_unpack_dequant_k": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gear_gemv_outer_workspace": (_sz, [_i64, _i, _i, _i]),
+    "gear_gemv_outer": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i64, _i64, _vp, _vp, _sz, _vp]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile gear_amd/csrc/*.hip for gfx950 into gear_amd/libgear_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C gear_amd/csrc). "
+            "gear_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GearError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gear_last_error()
+        raise GearError(f"{what}: status {rc}: {msg.decode() if msg else ''}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GearError("gear_amd operators run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+        if not t.is_contiguous():
+            raise GearError("gear_amd operators need contiguous tensors")

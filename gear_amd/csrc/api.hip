@@ -1,0 +1,16 @@
+// api.hip -- error plumbing and library identification for libgear_hip.so
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void gear_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gear_last_error(void) { return g_err; }
+extern "C" int gear_abi_version(void) { return 1; }

@@ -1,0 +1,132 @@
+// common.h -- shared device/host helpers for libgear_hip.so (gfx950 only; wave64).
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
+
+#include "../../include/gear_hip.h"
+
+#define GEAR_WAVE 64
+
+// ------------------------------------------------------------------ host side error plumbing
+void gear_set_error(const char* fmt, ...);
+
+#define GEAR_CHECK_ARG(cond, ...)         \
+    do {                                  \
+        if (!(cond)) {                    \
+            gear_set_error(__VA_ARGS__);  \
+            return -1;                    \
+        }                                 \
+    } while (0)
+
+#define GEAR_CHECK_LAUNCH(name)                                                     \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            gear_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+            return -2;                                                              \
+        }                                                                           \
+    } while (0)
+
+static inline bool gear_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ------------------------------------------------------------------ device helpers
+// round a float to the nearest fp16 value (RNE) and come back: one torch-eager fp16 op boundary
+__device__ __forceinline__ float hround(float f) { return __half2float(__float2half_rn(f)); }
+
+__device__ __forceinline__ float h2f_bits(uint16_t b) {
+    __half_raw r;
+    r.x = b;
+    return __half2float(__half(r));
+}
+__device__ __forceinline__ uint16_t f2h_bits(float f) {
+    __half h = __float2half_rn(f);
+    return __half_as_ushort(h);
+}
+
+// IEEE-correct fp32 division (never the v_rcp approximation): torch semantics
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+
+// unpack 8 fp16 from a 16-byte vector
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = h2f_bits((uint16_t)(v.x & 0xFFFFu));
+    f[1] = h2f_bits((uint16_t)(v.x >> 16));
+    f[2] = h2f_bits((uint16_t)(v.y & 0xFFFFu));
+    f[3] = h2f_bits((uint16_t)(v.y >> 16));
+    f[4] = h2f_bits((uint16_t)(v.z & 0xFFFFu));
+    f[5] = h2f_bits((uint16_t)(v.z >> 16));
+    f[6] = h2f_bits((uint16_t)(v.w & 0xFFFFu));
+    f[7] = h2f_bits((uint16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = (uint32_t)f2h_bits(f[0]) | ((uint32_t)f2h_bits(f[1]) << 16);
+    v.y = (uint32_t)f2h_bits(f[2]) | ((uint32_t)f2h_bits(f[3]) << 16);
+    v.z = (uint32_t)f2h_bits(f[4]) | ((uint32_t)f2h_bits(f[5]) << 16);
+    v.w = (uint32_t)f2h_bits(f[6]) | ((uint32_t)f2h_bits(f[7]) << 16);
+    return v;
+}
+
+// scale / zero-point storage type: fp16 (mode 0) or float (mode 1)
+template <typename ST>
+__device__ __forceinline__ float ld_st(const ST* p);
+template <>
+__device__ __forceinline__ float ld_st<uint16_t>(const uint16_t* p) { return h2f_bits(*p); }
+template <>
+__device__ __forceinline__ float ld_st<float>(const float* p) { return *p; }
+
+template <typename ST>
+__device__ __forceinline__ void st_st(ST* p, float v);
+template <>
+__device__ __forceinline__ void st_st<uint16_t>(uint16_t* p, float v) { *p = f2h_bits(v); }
+template <>
+__device__ __forceinline__ void st_st<float>(float* p, float v) { *p = v; }
+
+// ------------------------------------------------------------------ the group quantizer arithmetic
+// MODE 0: fp16-stepwise (cuda_supported_gear/quant/new_pack.py:237-240, :277-278)
+// MODE 1: fp32         (GenerationBench/.../Simulated/compress_function.py:24-28)
+template <int MODE>
+struct QuantParams {
+    float mn, scale;  // as stored (exact fp16 values in MODE 0)
+    int levels;
+};
+
+template <int MODE>
+__device__ __forceinline__ QuantParams<MODE> make_qparams(float mn, float mx, int levels) {
+    QuantParams<MODE> p;
+    p.mn = mn;
+    p.levels = levels;
+    if (MODE == 0) {
+        float range = hround(mx - mn);
+        p.scale = hround(div_rn(range, (float)levels));
+    } else {
+        p.scale = div_rn(mx - mn, (float)levels);
+    }
+    return p;
+}
+
+template <int MODE>
+__device__ __forceinline__ int quant_one(float v, const QuantParams<MODE>& p) {
+    if (p.scale == 0.0f) return 0;  // zero-range group: defined as code 0 (reference: NaN, defect B6)
+    float c;
+    if (MODE == 0) {
+        float t1 = hround(v - p.mn);
+        c = hround(div_rn(t1, p.scale));
+    } else {
+        c = div_rn(v - p.mn, p.scale);
+    }
+    c = fminf(fmaxf(c, 0.0f), (float)p.levels);
+    return (int)rintf(c);  // half-to-even
+}
+
+// dequantized value as the reference computes it (MODE 0: two fp16 roundings; MODE 1: fp32 mul then add, unfused)
+template <int MODE>
+__device__ __forceinline__ float dequant_one(int q, float scale, float mn) {
+    if (MODE == 0) {
+        return hround(hround((float)q * scale) + mn);
+    } else {
+        return __fadd_rn(__fmul_rn((float)q, scale), mn);
+    }
+}
