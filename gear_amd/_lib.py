@@ -27,6 +27,11 @@ SIGNATURES = {
     "gear_unpack_dequant_lastdim": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "gear_unpack_dequant_k": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "gear_gemv_outer_workspace": (_sz, [_i64, _i, _i, _i]),
+    "gear_compress_rows": (_i, [_vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gear_lowrank_workspace": (_sz, [_i64, _i, _i, _i]),
+    "gear_lowrank": (_i, [_vp, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "gear_decompress_rows": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _i,
+                                  _vp, _vp, _i, _vp, _vp]),
     "gear_gemv_outer": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i64, _i64, _vp, _vp, _sz, _vp]),
 }
 

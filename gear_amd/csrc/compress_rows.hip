@@ -1,0 +1,303 @@
+// compress_rows.hip -- one pass per row: outlier top-k select -> mean fill -> group quantize -> bit-pack -> error.
+//
+// A "row" is the unit over which the reference selects outliers
+// (GenerationBench/.../Simulated/compress_function.py:261-333):
+//   * V / token quantization : row = one token across ALL heads  (len = H*D, H segments of D contiguous fp16)
+//   * K / channel quantization: row = one channel across all tokens (len = T, contiguous in the K^T layout
+//                               [B,H,D,T] that the attention hook passes, modeling_llamagear.py:268)
+// Quantization groups are `group` consecutive elements inside a segment.  One workgroup owns one row: each
+// lane keeps 16 consecutive elements in registers; the k smallest / k largest are found with a two-level radix
+// select on the order-preserving 16-bit key of the fp16 value (LDS histograms, wave scans), ties broken by
+// LOWER INDEX FIRST (the oracle's rule); the survivors are quantized exactly like quant_pack.hip.
+//
+// Outputs per row: packed codes, scale, mn, optional error (0 at outlier positions), and the sparse part
+// (column index within the row as uint16 + original fp16 value, sorted by index; first k = smallest side).
+#include "common.h"
+
+namespace {
+
+struct RowGeom {
+    int rows_inner;            // row r -> (r / rows_inner, r % rows_inner)
+    int64_t outer_stride;      // elements
+    int64_t inner_stride;      // elements
+    int nseg, seglen;          // row = nseg segments of seglen contiguous elements
+    int64_t seg_stride;        // elements
+};
+
+__device__ __forceinline__ uint32_t sort_key(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit)
+    return (hbits & 0x8000u) ? (~hbits & 0xFFFFu) : (hbits | 0x8000u);
+}
+
+// inclusive scan over the block of a 64-bit packed counter (fields never overflow into each other)
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* wave_tot,
+                                                              unsigned long long* total_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    __syncthreads();  // wave_tot reuse
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) {
+        unsigned long long t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    if (total_out) *total_out = tot;
+    return base + inc - v;
+}
+
+// wave 0 finds, in a 256-bin histogram, the bin where the running count from the top (FROM_TOP) or from the
+// bottom crosses `need`; returns (bin, how many to take from that bin) through LDS.
+template <bool FROM_TOP>
+__device__ __forceinline__ void find_crossing(const uint32_t* hist, int need, int* out_bin, int* out_take) {
+    // called by one full wave (64 lanes); lane l owns bins 4l .. 4l+3
+    const int lane = threadIdx.x & 63;
+    uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    uint32_t s = h0 + h1 + h2 + h3;
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    uint32_t total = __shfl(inc, 63, 64);
+    uint32_t below = inc - s;  // elements in bins < 4*lane
+    uint32_t hh[4] = {h0, h1, h2, h3};
+    if (FROM_TOP) {
+        // count of elements in bins > b
+        uint32_t above = total - below - s;  // bins > 4*lane+3
+        for (int j = 3; j >= 0; j--) {
+            if (above < (uint32_t)need && above + hh[j] >= (uint32_t)need) {
+                *out_bin = 4 * lane + j;
+                *out_take = need - (int)above;
+            }
+            above += hh[j];
+        }
+    } else {
+        uint32_t bl = below;
+        for (int j = 0; j < 4; j++) {
+            if (bl < (uint32_t)need && bl + hh[j] >= (uint32_t)need) {
+                *out_bin = 4 * lane + j;
+                *out_take = need - (int)bl;
+            }
+            bl += hh[j];
+        }
+    }
+}
+
+template <int BITS, int MODE, typename ST>
+__global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k,
+                                     uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
+                                     uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
+                                     uint16_t* __restrict__ oval, float* __restrict__ omean) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int WPL = BITS / 2;
+    constexpr int CPW = 32 / BITS;
+    __shared__ uint32_t hist[3][256];
+    __shared__ unsigned long long wave_tot[16];
+    __shared__ float wave_sum[16];
+    __shared__ int sh[8];  // 0 bin_hi, 1 need_hi, 2 bin_lo, 3 need_lo, 4 thr_hi, 5 take_hi, 6 thr_lo, 7 take_lo
+
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const int j0 = tid * 16;  // first element of this lane inside the row
+    const bool active = j0 < len;
+    const int seg = active ? j0 / gm.seglen : 0;
+    const int pos = active ? j0 % gm.seglen : 0;
+    const int64_t row_base = (r / gm.rows_inner) * gm.outer_stride + (r % gm.rows_inner) * gm.inner_stride;
+    const int64_t off = row_base + (int64_t)seg * gm.seg_stride + pos;  // element offset of this lane's 16 values
+
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
+    if (active) {
+        const uint4* p = (const uint4*)(x + off);
+        ra = p[0];
+        rb = p[1];
+    }
+    uint32_t hb[16];  // raw fp16 bits
+    hb[0] = ra.x & 0xFFFFu; hb[1] = ra.x >> 16; hb[2] = ra.y & 0xFFFFu; hb[3] = ra.y >> 16;
+    hb[4] = ra.z & 0xFFFFu; hb[5] = ra.z >> 16; hb[6] = ra.w & 0xFFFFu; hb[7] = ra.w >> 16;
+    hb[8] = rb.x & 0xFFFFu; hb[9] = rb.x >> 16; hb[10] = rb.y & 0xFFFFu; hb[11] = rb.y >> 16;
+    hb[12] = rb.z & 0xFFFFu; hb[13] = rb.z >> 16; hb[14] = rb.w & 0xFFFFu; hb[15] = rb.w >> 16;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = h2f_bits((uint16_t)hb[j]);
+
+    uint32_t flag_lo = 0, flag_hi = 0;  // bit j: element j of this lane is an outlier (small / large side)
+    if (k > 0) {
+        // ---------------- row mean (of the ORIGINAL row, compress_function.py:276 / :312)
+        float s = 0.0f;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) s += v[j];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) wave_sum[wave] = s;
+        // ---------------- level-1 histogram on the high key byte
+        for (int i = tid; i < 3 * 256; i += blockDim.x) (&hist[0][0])[i] = 0u;
+        __syncthreads();
+        uint32_t key[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) key[j] = sort_key(hb[j]);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) atomicAdd(&hist[0][key[j] >> 8], 1u);
+        }
+        __syncthreads();
+        float tot = 0.0f;
+        for (int w = 0; w < nw; w++) tot += wave_sum[w];
+        const float mean = tot / (float)len;
+        if (wave == 0) {
+            find_crossing<true>(hist[0], k, &sh[0], &sh[1]);
+            find_crossing<false>(hist[0], k, &sh[2], &sh[3]);
+        }
+        __syncthreads();
+        const uint32_t bin_hi = (uint32_t)sh[0], bin_lo = (uint32_t)sh[2];
+        const int need_hi = sh[1], need_lo = sh[3];
+        // ---------------- level-2 histograms on the low key byte inside the two boundary bins
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if ((key[j] >> 8) == bin_hi) atomicAdd(&hist[1][key[j] & 255u], 1u);
+                if ((key[j] >> 8) == bin_lo) atomicAdd(&hist[2][key[j] & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            find_crossing<true>(hist[1], need_hi, &sh[4], &sh[5]);
+            find_crossing<false>(hist[2], need_lo, &sh[6], &sh[7]);
+        }
+        __syncthreads();
+        const uint32_t thr_hi = (bin_hi << 8) | (uint32_t)sh[4];
+        const uint32_t thr_lo = (bin_lo << 8) | (uint32_t)sh[6];
+        const int take_hi = sh[5], take_lo = sh[7];
+        // ---------------- tie ranks (lower index first): exclusive scan of per-lane equal counts
+        unsigned long long eq = 0;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                eq += (key[j] == thr_hi) ? 1ull : 0ull;
+                eq += (key[j] == thr_lo) ? (1ull << 32) : 0ull;
+            }
+        }
+        unsigned long long ex = block_excl_scan(eq, wave_tot, nullptr);
+        int rank_hi = (int)(ex & 0xFFFFFFFFull), rank_lo = (int)(ex >> 32);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (key[j] < thr_lo) flag_lo |= 1u << j;
+                else if (key[j] == thr_lo) { if (rank_lo < take_lo) flag_lo |= 1u << j; rank_lo++; }
+                if (key[j] > thr_hi) flag_hi |= 1u << j;
+                else if (key[j] == thr_hi) { if (rank_hi < take_hi) flag_hi |= 1u << j; rank_hi++; }
+            }
+        }
+        // ---------------- output slots (sorted by index) and the sparse payload
+        unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
+        unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
+        int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
+        uint16_t* oi = oidx + r * (int64_t)(2 * k);
+        uint16_t* ov = oval + r * (int64_t)(2 * k);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (flag_lo & (1u << j)) {
+                if (slot_lo < k) { oi[slot_lo] = (uint16_t)(j0 + j); ov[slot_lo] = (uint16_t)hb[j]; }
+                slot_lo++;
+            }
+            if (flag_hi & (1u << j)) {
+                if (slot_hi < k) { oi[k + slot_hi] = (uint16_t)(j0 + j); ov[k + slot_hi] = (uint16_t)hb[j]; }
+                slot_hi++;
+            }
+        }
+        if (tid == 0 && omean) omean[r] = mean;
+        // ---------------- fill (compress_function.py:279-283 / :315-319)
+        const float fill = (MODE == 0) ? hround(mean) : mean;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((flag_lo | flag_hi) & (1u << j)) v[j] = fill;
+    }
+
+    // ---------------- group quantization (identical arithmetic to quant_pack.hip)
+    const int lanes_per_group = group / 16;
+    float lo = v[0], hi = v[0];
+#pragma unroll
+    for (int j = 1; j < 16; j++) {
+        lo = fminf(lo, v[j]);
+        hi = fmaxf(hi, v[j]);
+    }
+    for (int m = 1; m < lanes_per_group; m <<= 1) {
+        lo = fminf(lo, __shfl_xor(lo, m, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+    }
+    if (!active) return;
+    QuantParams<MODE> qp = make_qparams<MODE>(lo, hi, LEVELS);
+    uint32_t words[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; w++) words[w] = 0u;
+    float e[16];
+    const uint32_t outl = flag_lo | flag_hi;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        int q = quant_one<MODE>(v[j], qp);
+        words[j / CPW] |= (uint32_t)q << (BITS * (j % CPW));
+        float d = (MODE == 0) ? dequant_one<0>(q, qp.scale, qp.mn) : hround(dequant_one<1>(q, qp.scale, qp.mn));
+        e[j] = (outl & (1u << j)) ? 0.0f : (v[j] - d);
+    }
+    uint32_t* cp = code + off / CPW;
+#pragma unroll
+    for (int w = 0; w < WPL; w++) cp[w] = words[w];
+    if ((tid & (lanes_per_group - 1)) == 0) {
+        st_st<ST>(scale + off / group, qp.scale);
+        st_st<ST>(mn + off / group, qp.mn);
+    }
+    if (err) {
+        uint4* ep = (uint4*)(err + off);
+        ep[0] = pack8(e);
+        ep[1] = pack8(e + 8);
+    }
+}
+
+}  // namespace
+
+extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride,
+                                  int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int group, int bits,
+                                  int mode, int k, void* code, void* scale, void* mn, void* err, void* oidx, void* oval,
+                                  void* omean, void* stream) {
+    GEAR_CHECK_ARG(bits == 2 || bits == 4 || bits == 8, "gear_compress_rows: bits must be 2, 4 or 8 (got %d)", bits);
+    GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_compress_rows: bad mode %d", mode);
+    GEAR_CHECK_ARG(n_rows > 0 && n_rows < 0x7FFFFFFFLL && nseg > 0 && seglen > 0, "gear_compress_rows: empty input");
+    const int64_t len = (int64_t)nseg * seglen;
+    GEAR_CHECK_ARG(len <= 16384, "gear_compress_rows: row length %lld exceeds 16384", (long long)len);
+    GEAR_CHECK_ARG(group >= 16 && gear_is_pow2(group / 16) && group % 16 == 0 && group <= 1024 && seglen % group == 0,
+                   "gear_compress_rows: group %d must be a power of two in [16,1024] dividing the segment length %d", group, seglen);
+    GEAR_CHECK_ARG(k >= 0 && 2 * (int64_t)k <= len, "gear_compress_rows: k=%d out of range for row length %lld", k, (long long)len);
+    GEAR_CHECK_ARG(outer_stride % group == 0 && inner_stride % group == 0 && (nseg == 1 || seg_stride % group == 0),
+                   "gear_compress_rows: strides must be multiples of the group size");
+    GEAR_CHECK_ARG(x && code && scale && mn, "gear_compress_rows: null pointer");
+    GEAR_CHECK_ARG(k == 0 || (oidx && oval), "gear_compress_rows: outlier buffers required when k > 0");
+    RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride};
+    int threads = (int)((len / 16 + 63) / 64 * 64);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 block(threads), grid((unsigned)n_rows);
+#define GO(B, M, STT)                                                                                                  \
+    hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, 0, st, (const uint16_t*)x, gm, (int)len, group, k, \
+                       (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
+                       (float*)omean)
+    if (mode == 0) {
+        if (bits == 2) GO(2, 0, uint16_t);
+        else if (bits == 4) GO(4, 0, uint16_t);
+        else GO(8, 0, uint16_t);
+    } else {
+        if (bits == 2) GO(2, 1, float);
+        else if (bits == 4) GO(4, 1, float);
+        else GO(8, 1, float);
+    }
+#undef GO
+    GEAR_CHECK_LAUNCH("gear_compress_rows");
+    return 0;
+}

@@ -142,3 +142,22 @@ def unpack_tensor(v_code: torch.Tensor, bits: int, pack_dim: int):
     u = (c.unsqueeze(-1) >> shifts) & (0xFF >> (8 - bits))
     u = u.reshape(c.shape[:-1] + (c.shape[-1] * feat_per_int,)).to(torch.int16)
     return u.movedim(-1, pack_dim).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ a4
+def headwise_lrap(tensor: torch.Tensor, rank, loop, p_base: torch.Tensor = None):
+    """new_pack.py:291-311.  tensor [B,nh,S,Dm] -> (p_base [B,nh,Dm,rank], q_base [B,nh,S,rank]) in tensor.dtype;
+    the approximation is q_base @ p_base^T.
+
+    The initial basis is drawn exactly like the reference (torch.rand on the CPU generator, then a discarded q_base
+    draw, :296-297) unless `p_base` (float32 [B,nh,Dm,rank]) is supplied.  Bases are per (batch, head): the
+    reference's `p_base[0]` indexing (:301, :304) broadcasts batch 0's basis and is only correct for B == 1
+    (defect B3) -- identical results for B == 1."""
+    from .. import compress
+    dtype = tensor.dtype
+    batch, num_head, seq_len, head_dim = tensor.shape
+    if p_base is None:
+        p_base = compress.draw_p0(batch, num_head, seq_len, head_dim, rank, tensor.device)
+    out_dtype = torch.float16 if dtype == torch.float16 else torch.float32
+    P, Q = compress.lowrank(tensor, rank, loop, p_base, transposed=False, out_dtype=out_dtype)
+    return P.type(dtype), Q.type(dtype)

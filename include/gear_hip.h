@@ -90,6 +90,48 @@ int gear_gemv_outer(const void* a, const void* qB, const void* scale, const void
                     int N, int group, int bits, int mode, int64_t ldq, int64_t lds, void* out, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ---- a11 (+ a9): one pass per row -- outlier top-k select, mean fill, group quantize, pack, error -------------
+ * Replaces gears_channelQ / gears_tokenQ (GenerationBench/.../Simulated/compress_function.py:261-333) and, with
+ * k == 0, the fake_groupwise_*_asymmetric_quantization functions (:7-67, :100-160), producing a REAL payload.
+ * A row is the unit of outlier selection: a token across all heads (V: nseg = H segments of D) or a channel
+ * across all tokens (K in the K^T layout [B,H,D,T]: one segment of T).
+ *   row r starts at element (r / rows_inner) * outer_stride + (r % rows_inner) * inner_stride; its element j
+ *   lives at + (j / seglen) * seg_stride + j % seglen.          len = nseg * seglen <= 16384.
+ *   x fp16; code/scale/mn/err use the same geometry with the last dim divided by fpi / group / 1.
+ *   k  : outliers per side per row (compress_function.py:265-267 / :300-303); 0 disables the sparse part.
+ *   oidx uint16 [n_rows, 2k] (index within the row; first k = the k smallest, then the k largest, each sorted by
+ *   index), oval fp16 [n_rows, 2k] (original values), omean float [n_rows] (optional).  Ties across the selection
+ *   boundary: lower index first (torch.topk leaves it implementation-defined).
+ *   err: optional fp16, x - fp16(dequant) with 0 at outlier positions.
+ */
+int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride,
+                       int nseg, int seglen, int64_t seg_stride, int group, int bits, int mode, int k, void* code,
+                       void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, void* stream);
+
+/* ---- a4 / a10: low-rank power iteration ---------------------------------------------------------------------
+ * Replaces headwise_lrap (cuda_supported_gear/quant/new_pack.py:291-311) and fake_poweriteration_group
+ * (compress_function.py:69-98).  for i < loop: [last: P = orth(P)] Q = E P [last: Q = orth(Q)] P = E^T Q.
+ *   E  : [bh, S, Dm] (transposed == 0) or its transpose [bh, Dm, S] (transposed == 1); fp16 or float32
+ *   P0 : float32 [bh, Dm, r] initial basis (the reference draws it with torch.rand on the CPU generator; the
+ *        caller supplies it so that runs are reproducible);   P_out [bh, Dm, r], Q_out [bh, S, r] fp16 / float32.
+ *   1 <= r <= 16.  Per-(batch, head) bases (reference defect B3 not reproduced).
+ */
+size_t gear_lowrank_workspace(int64_t bh, int S, int Dm, int r);
+int gear_lowrank(const void* E, int e_dtype, int transposed, int64_t bh, int S, int Dm, int r, int loop,
+                 const void* P0, void* P_out, void* Q_out, int out_dtype, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* ---- decompress to fp16: dequant + low-rank + sparse restore ------------------------------------------------
+ * out = fp16(fp16(dequant) + Q P^T), outliers restored from their stored fp16 value (compress_function.py:204-220
+ * assembles the simulated result the same way).  Geometry as gear_compress_rows.
+ *   kind 0: V rows (row = (b, t), rows_inner = T, nseg = H, seglen = D)   kind 1: K^T rows (row = (bh, d),
+ *   rows_inner = D, one segment of T).  P fp16 [BH, D, r], Q fp16 [BH, T, r] (r == 0: none).
+ */
+int gear_decompress_rows(const void* code, const void* scale, const void* mn, int64_t n_rows, int rows_inner,
+                         int64_t outer_stride, int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int group,
+                         int bits, int mode, int kind, const void* P, const void* Q, int r, int T, int D,
+                         const void* oidx, const void* oval, int k, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
