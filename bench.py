@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- KV-cache compress + decompress throughput of the GEAR hot path on MI355X.
+
+One "step" = one pass of the hot path over the whole KV cache of the named model at the named context:
+    for every layer:  K, V fp16 [H, T, D]  --compress-->  packed payload (quantized backbone + rank-r factors +
+    sparse outliers)  --decompress-->  fp16 K^T / V again
+with the inputs resident in HBM.  value = fp16 KV bytes that went through compress PLUS through decompress,
+per second, whole job (all ranks).
+
+Workload (BASELINE.json): default = configs[2], the one the metric is quoted on
+    "Llama-2-7B, seq=4096, 2-bit KIVI-style per-channel K / per-token V + rank-8 + 2% outlier, 1xMI355X"
+    (--config c2 selects configs[1]: seq=2048, 4-bit, rank-4, 1%).
+Multi-GPU: KV heads are sharded across ranks (7B: 32/N heads per GPU); compress / decompress need no data-path
+collective (V outlier rows are selected per shard with k scaled by 1/N); total work is fixed ->
+"scaling": "strong".
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]      (N > 1 via torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (model, layers, kv_heads, head_dim, T, bits, group, rank, loop, sparsity)
+    "c3": ("Llama-2-7B", 32, 32, 128, 4096, 2, 64, 8, 3, 0.02),
+    "c2": ("Llama-2-7B", 32, 32, 128, 2048, 4, 64, 4, 3, 0.01),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg):
+    """The oracle (CPU restatement of the reference's simulated path, validated against the reference in the build
+    container) on a bounded sample of the same workload: ONE layer's K and V at full heads / context."""
+    import numpy as np
+    from oracle import oracle as orc
+    model, layers, H, D, T, bits, group, rank, loop, s = cfg
+    Hs, nl = H, 2  # bounded sample: 2 of the layers, all heads, full context (about 10-15 s on 8 cores)
+    rng = np.random.default_rng(0)
+    k = rng.standard_normal((nl, Hs, T, D)).astype(np.float16)
+    v = rng.standard_normal((nl, Hs, T, D)).astype(np.float16)
+    P0k = rng.random((nl, Hs, D, rank), dtype=np.float32)
+    P0v = rng.random((nl, Hs, D, rank), dtype=np.float32)
+    orc.compress_insert_function(k[:1, :1, :256], v[:1, :1, :256], "GEAR", bits, group, rank, rank, loop, s,
+                                 P0k[:1, :1], P0v[:1, :1])  # warm up / load the library
+    t0 = time.perf_counter()
+    orc.compress_insert_function(k, v, "GEAR", bits, group, rank, rank, loop, s, P0k, P0v)
+    dt = time.perf_counter() - t0
+    nbytes = 2 * (k.size + v.size) * 2  # quantize->dequantize round trip: counted like the GPU step
+    return {
+        "value": nbytes / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
+        "sample": f"oracle compress_insert_function(GEAR) on {nl} layers x {Hs} heads x T={T} (K+V), {dt:.2f} s",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gear_amd import compress as C
+    from gear_amd import _lib
+    _lib.load()
+
+    cfg = CONFIGS[args.config]
+    model, layers, H, D, T, bits, group, rnk, loop, sparsity = cfg
+    if args.layers:
+        layers = args.layers
+    assert H % world == 0, "KV heads must divide across ranks"
+    Hl = H // world
+    # k per side: reference formula on the FULL row (compress_function.py:300-303); per-shard V rows take k/N
+    k_full = C.outlier_count(1, H, T, D, sparsity)
+    k_key = k_full
+    k_val = max(1, k_full // world)
+
+    torch.manual_seed(1234 + rank)
+    K = torch.empty((layers, Hl, T, D), dtype=torch.float16, device=dev)
+    V = torch.empty_like(K)
+    for l in range(layers):  # fill in slices: no 4-byte temporaries of the whole cache
+        K[l] = torch.randn((Hl, T, D), device=dev, dtype=torch.float32).half()
+        V[l] = torch.randn((Hl, T, D), device=dev, dtype=torch.float32).half()
+    P0k = torch.rand((layers, Hl, D, rnk), device=dev, dtype=torch.float32)
+    P0v = torch.rand((layers, Hl, D, rnk), device=dev, dtype=torch.float32)
+
+    ev = {}
+
+    def stage(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.setdefault(name, []).append(e)
+
+    def step():
+        stage("t0")
+        kt = K.transpose(2, 3).contiguous()                      # what the attention hook hands over (llamagear.py:268)
+        stage("k_transpose")
+        pk = C.compress_key_t(kt, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k)
+        stage("k_compress")
+        pv = C.compress_value(V, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v)
+        stage("v_compress")
+        kr = C.decompress(pk, transposed_out=True)
+        stage("k_decompress")
+        vr = C.decompress(pv)
+        stage("v_decompress")
+        return pk, pv, kr, vr
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    ev.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    pk, pv, kr, vr = out
+    n_elem_rank = K.numel()                       # per tensor kind, this rank
+    fp16_bytes_job = 2 * n_elem_rank * 2 * world  # K + V, whole job
+    value = 2 * fp16_bytes_job * args.steps / dt / 1e9   # through compress + through decompress
+
+    # ---- per-stage GPU time (HIP events on the launch stream), averaged over the timed steps
+    names = ["k_transpose", "k_compress", "v_compress", "k_decompress", "v_decompress"]
+    prev = "t0"
+    stages = {}
+    for nme in names:
+        ms = [a.elapsed_time(b) for a, b in zip(ev[prev], ev[nme])]
+        stages[nme] = sum(ms) / len(ms)
+        prev = nme
+
+    # ---- roofline of the dominant kernel: the V row compressor (outlier select + fill + quant + pack + error)
+    # is timed as its own event interval in a dedicated loop (the compress stages above also contain the low-rank
+    # launches).  Algorithmic bytes per launch (DESIGN.md "compress_rows"): read 2n; write codes n*b/8 +
+    # scale/mn 8n/g (fp32) + error 2n + outliers rows*2k*4.
+    n = n_elem_rank
+    from gear_amd.compress import _compress_rows
+    geom = (layers * T, T, Hl * T * D, D, Hl, D, T * D)
+    for _ in range(2):
+        _compress_rows(V, geom, group, bits, 1, k_val, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        _compress_rows(V, geom, group, bits, 1, k_val, True)
+    e1.record()
+    torch.cuda.synchronize()
+    rows_ms = e0.elapsed_time(e1) / reps
+    alg_bytes = 2 * n + n * bits / 8 + 8 * n / group + 2 * n + layers * T * 2 * k_val * 4
+    achieved = alg_bytes / (rows_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "compress_rows_kernel<V>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "alg_bytes_per_launch": alg_bytes, "ms_per_launch": rows_ms}
+
+    if rank == 0:
+        res = {
+            "metric": "KV compress+decompress GB/s (fp16 KV bytes through compress + through decompress per second)",
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 arithmetic on fp16 data, int%d payload" % bits, "data": "synthetic",
+            "config": {"workload": f"{model} KV cache, {layers} layers x {H} KV heads x T={T} x D={D}, "
+                                   f"{bits}-bit g={group} per-channel K / per-token V + rank-{rnk} (loop {loop}) + "
+                                   f"{sparsity * 100:.0f}% outliers (BASELINE configs[{2 if args.config == 'c3' else 1}])",
+                       "parallelism": f"head-shard x{world}", "k_outliers_per_side": [k_key, k_val]},
+            "compress_GBps": fp16_bytes_job / ((stages["k_transpose"] + stages["k_compress"] + stages["v_compress"]) * 1e-3) / 1e9,
+            "decompress_GBps": fp16_bytes_job / ((stages["k_decompress"] + stages["v_decompress"]) * 1e-3) / 1e9,
+            "stage_ms": stages,
+            "payload_ratio": (2 * n_elem_rank * 2) / (pk.nbytes() + pv.nbytes()),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
