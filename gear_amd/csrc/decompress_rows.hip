@@ -11,7 +11,23 @@
 
 namespace {
 
-template <int BITS, int MODE, typename ST, int KIND>
+template <int N>
+__device__ __forceinline__ void load_halfs(const uint16_t* p, float* f) {
+    if (N == 8) {
+        uint4 v = *(const uint4*)p;
+        unpack8(v, f);
+    } else if (N == 16) {
+        uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
+        unpack8(a, f);
+        unpack8(b, f + 8);
+    } else if (N == 4) {
+        uint2 v = *(const uint2*)p;
+        f[0] = h2f_bits((uint16_t)(v.x & 0xFFFFu)); f[1] = h2f_bits((uint16_t)(v.x >> 16));
+        f[2] = h2f_bits((uint16_t)(v.y & 0xFFFFu)); f[3] = h2f_bits((uint16_t)(v.y >> 16));
+    }
+}
+
+template <int BITS, int MODE, typename ST, int KIND, int RV>
 __global__ void decompress_rows_kernel(const uint32_t* __restrict__ code, const ST* __restrict__ scale,
                                        const ST* __restrict__ mn, int rows_inner, int64_t outer_stride,
                                        int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int len,
@@ -71,13 +87,27 @@ __global__ void decompress_rows_kernel(const uint32_t* __restrict__ code, const 
             fvp = P + ((int64_t)ro * D + ri) * r;
             gbp = Q + ((int64_t)ro * T + j0) * r;
         }
-        float fv[16];
-        for (int c = 0; c < r; c++) fv[c] = h2f_bits(fvp[c]);
+        if (RV > 0) {   // r == RV: factor rows are RV contiguous fp16 -> vector loads, fully unrolled
+            float fv[RV > 0 ? RV : 1];
+            load_halfs<RV>(fvp, fv);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            float acc = 0.0f;
-            for (int c = 0; c < r; c++) acc = fmaf(fv[c], h2f_bits(gbp[j * r + c]), acc);
-            f[j] += acc;
+            for (int j = 0; j < 16; j++) {
+                float gv[RV > 0 ? RV : 1];
+                load_halfs<RV>(gbp + j * RV, gv);
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < RV; c++) acc = fmaf(fv[c], gv[c], acc);
+                f[j] += acc;
+            }
+        } else {
+            float fv[16];
+            for (int c = 0; c < r; c++) fv[c] = h2f_bits(fvp[c]);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                float acc = 0.0f;
+                for (int c = 0; c < r; c++) acc = fmaf(fv[c], h2f_bits(gbp[j * r + c]), acc);
+                f[j] += acc;
+            }
         }
     }
     uint4* op = (uint4*)(out + off);
@@ -108,12 +138,14 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     size_t shmem = k > 0 ? (size_t)((len + 31) / 32) * 4 + (size_t)len * 2 : 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)n_rows);
-#define GO(B, M, STT, KD)                                                                                              \
-    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD>), grid, block, shmem, st, (const uint32_t*)code,          \
+#define GO(B, M, STT, KD, RVV)                                                                                         \
+    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV>), grid, block, shmem, st, (const uint32_t*)code,          \
                        (const STT*)scale, (const STT*)mn, rows_inner, outer_stride, inner_stride, nseg, seglen,         \
                        seg_stride, (int)len, group, (const uint16_t*)P, (const uint16_t*)Q, r, T, D,                    \
                        (const uint16_t*)oidx, (const uint16_t*)oval, k, (uint16_t*)out)
-#define GOK(B, M, STT) do { if (kind == 0) GO(B, M, STT, 0); else GO(B, M, STT, 1); } while (0)
+#define GOR(B, M, STT, KD) do { if (r == 8) GO(B, M, STT, KD, 8); else if (r == 4) GO(B, M, STT, KD, 4); \
+                                else if (r == 16) GO(B, M, STT, KD, 16); else GO(B, M, STT, KD, 0); } while (0)
+#define GOK(B, M, STT) do { if (kind == 0) GOR(B, M, STT, 0); else GOR(B, M, STT, 1); } while (0)
     if (mode == 0) {
         if (bits == 2) GOK(2, 0, uint16_t);
         else if (bits == 4) GOK(4, 0, uint16_t);
@@ -124,6 +156,7 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
         else GOK(8, 1, float);
     }
 #undef GOK
+#undef GOR
 #undef GO
     GEAR_CHECK_LAUNCH("gear_decompress_rows");
     return 0;
