@@ -1,0 +1,428 @@
+"""Counterpart of cuda_supported_gear/modeling_llamagear.py: the attention hook that owns the GEAR KV cache.
+
+Same operator surface as the reference --
+    key_compression(key_full, compress_config)            modeling_llamagear.py:23-37
+    value_compression(value_full, compress_config)        :39-53
+    matmul_withlrap(group_size, a, b, scale, mn, bits, pbase, qbase, type)   :54-111
+    LlamaAttention_GEAR(layer_idx, config, compress_config).forward(...) -> (attn_output, None, 17-tuple)   :113-484
+    LlamaForCausalLM_GEARKIVI(config, compress_config)    :711
+-- on the HIP kernels of libgear_hip.so.  The module is self-contained (no `transformers` import: the reference is
+a fork of transformers 4.38 that no longer imports under the installed 5.x); `config` may be a HF LlamaConfig or
+the LlamaConfigLite below (same attribute names).
+
+Cache tuple (one per layer), identical slot layout to the reference (:458-466):
+  0 K code  int32 [B,Hkv,D,Tq/fpi]   1 K_full fp16 [B,Hkv,t<R,D] | None   2 K scale [B,Hkv,D,Tq/g]   3 K mn
+  4 V code  int32 [B,Hkv,Tq,D/fpi]   5 V_full fp16 | None                 6 V scale [B,Hkv,Tq,D/g]   7 V mn
+  8 kv_seq_len (int)                 9 K P list   10 K Q list   11, 12 None (K outliers: not stored by the
+  reference's fused path)            13 V P list  14 V Q list   15, 16 None
+  P/Q lists: [prefill factors] or [prefill factors, stacked decode-block factors [nbuf,B,Hkv,.,r]].
+  K: P is the token-side factor [.,T,r], Q the channel-side factor [.,D,r]; V: P [.,D,r], Q [.,T,r] (:227-230).
+
+Documented divergences from the reference: B1 (all code columns are packed), B2 (the K
+low-rank factors approximate the true error matrix, not a reshape-scrambled one), B3 (per-batch bases), GQA is
+supported (the reference asserts num_key_value_groups == 1, :206).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .quant.matmul import cuda_bmm_fA_qB_outer
+from .quant.new_pack import (headwise_lrap, triton_quantize_and_pack_along_last_dim,
+                             triton_quantize_and_pack_along_last_dim_witherror)
+
+
+@dataclass
+class LlamaConfigLite:
+    """The LlamaConfig attributes the GEAR attention reads (defaults: Llama-2-7B; CSG/test.py:12-17 adds the
+    k_bits / v_bits / group_size / residual_length fields)."""
+    vocab_size: int = 32000
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    max_position_embeddings: int = 4096
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    attention_bias: bool = False
+    attention_dropout: float = 0.0
+    pretraining_tp: int = 1
+    rope_scaling: Optional[dict] = None
+    k_bits: int = 2
+    v_bits: int = 2
+    group_size: int = 64
+    residual_length: int = 64
+
+
+def _uses_lowrank(compress_config) -> bool:
+    m = compress_config["compress_method"]
+    return "gearl" in m or "gearsl" in m          # substring test, modeling_llamagear.py:25 / :41
+
+
+def key_compression(key_full: torch.Tensor, compress_config: dict):
+    """modeling_llamagear.py:23-37.  key_full fp16 [B,H,D,T] (K^T, contiguous) ->
+    (code [B,H,D,T/fpi], scale [B,H,D,T/g], mn, P [B,H,T,r] | None, Q [B,H,D,r] | None)."""
+    bsz, num_head, head_dim, seq_len = key_full.shape
+    if _uses_lowrank(compress_config):
+        code, scale, mn, error = triton_quantize_and_pack_along_last_dim_witherror(
+            key_full, compress_config["group_size"], compress_config["quantize_bit"])
+        # B2: the error tensor is E^T [B,H,D,T]; the reference reshapes it as [B,H,T,D] and transposes (a scramble)
+        error = error.view(bsz, num_head, head_dim, seq_len)
+        key_states_p, key_states_q = headwise_lrap(error, compress_config["rank"], compress_config["loop"])
+    else:
+        code, scale, mn = triton_quantize_and_pack_along_last_dim(
+            key_full, compress_config["group_size"], compress_config["quantize_bit"])
+        key_states_p, key_states_q = None, None
+    return code, scale, mn, key_states_p, key_states_q
+
+
+def value_compression(value_full: torch.Tensor, compress_config: dict):
+    """modeling_llamagear.py:39-53.  value_full fp16 [B,H,T,D] ->
+    (code [B,H,T,D/fpi], scale [B,H,T,D/g], mn, P [B,H,D,r] | None, Q [B,H,T,r] | None)."""
+    bsz, num_head, seq_len, head_dim = value_full.shape
+    if _uses_lowrank(compress_config):
+        code, scale, mn, error = triton_quantize_and_pack_along_last_dim_witherror(
+            value_full, compress_config["group_size"], compress_config["quantize_bit"])
+        error = error.view(bsz, num_head, seq_len, head_dim)
+        value_states_p, value_states_q = headwise_lrap(error, compress_config["rankv"], compress_config["loop"])
+    else:
+        code, scale, mn = triton_quantize_and_pack_along_last_dim(
+            value_full, compress_config["group_size"], compress_config["quantize_bit"])
+        value_states_p, value_states_q = None, None
+    return code, scale, mn, value_states_p, value_states_q
+
+
+def _rep(t: torch.Tensor, n_rep: int) -> torch.Tensor:
+    """[.., B, Hkv, x, y] -> [.., B, Hkv*n_rep, x, y] (GQA: query heads of one KV head are adjacent)."""
+    return t if n_rep == 1 else t.repeat_interleave(n_rep, dim=-3)
+
+
+def matmul_withlrap(group_size, a, b, scale, mn, bits, pbase: list, qbase: list, type="key"):
+    """modeling_llamagear.py:54-111: fused dequant GEMV + low-rank correction.
+
+    a [B,Hq,1,K] fp16; b packed [B,Hkv,K,N/fpi]; type "key": K = head_dim, N = compressed tokens;
+    type "value": K = compressed tokens, N = head_dim.  pbase / qbase: [None] | [prefill] | [prefill, stacked]."""
+    result1 = cuda_bmm_fA_qB_outer(group_size, a, b, scale, mn, bits)
+    if pbase[0] is None:
+        return result1
+    n_rep = a.shape[1] // b.shape[1]
+    if type == "key":
+        # scores += (a Q0) P0^T over the prefill tokens, (a Q1[i]) P1[i]^T over each decode block (:71-85)
+        result3 = (a @ _rep(qbase[0], n_rep)) @ _rep(pbase[0], n_rep).transpose(2, 3)
+        prefill_length = pbase[0].shape[-2]
+        if len(pbase) == 1:
+            return result1 + result3
+        result1[:, :, :, :prefill_length] = result1[:, :, :, :prefill_length] + result3
+        result4 = a.unsqueeze(0) @ _rep(qbase[1], n_rep) @ _rep(pbase[1], n_rep).transpose(3, 4)
+        buffer_num, bsz, num_head, q_len, seq_len_buffer = result4.shape
+        result4 = result4.permute(1, 2, 3, 0, 4).reshape(bsz, num_head, q_len, buffer_num * seq_len_buffer)
+        result1[:, :, :, prefill_length:] = result1[:, :, :, prefill_length:] + result4
+        return result1
+    # value: out += (a[:, :Tp] Q0) P0^T + sum_blocks (a_blk Q1[i]) P1[i]^T (:87-108)
+    prefill_length = qbase[0].shape[-2]
+    result3 = (a[:, :, :, :prefill_length] @ _rep(qbase[0], n_rep)) @ _rep(pbase[0], n_rep).transpose(2, 3)
+    result1 = result1 + result3
+    if len(pbase) == 1:
+        return result1
+    buffer_length = qbase[1].shape[-2]
+    generated_a = a[:, :, :, prefill_length:]
+    bsz, num_head, q_len, _ = generated_a.shape
+    generated_a = generated_a.reshape(bsz, num_head, q_len, -1, buffer_length).permute(3, 0, 1, 2, 4)
+    result4 = generated_a @ _rep(qbase[1], n_rep) @ _rep(pbase[1], n_rep).transpose(3, 4)
+    return result1 + result4.sum(dim=0)
+
+
+# ------------------------------------------------------------------------------------------------- RoPE (Llama)
+class LlamaRotaryEmbedding(nn.Module):
+    def __init__(self, dim, max_position_embeddings=2048, base=10000.0):
+        super().__init__()
+        self.dim, self.base = dim, base
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+
+    @torch.no_grad()
+    def forward(self, x, position_ids):
+        freqs = position_ids[:, :, None].float() * self.inv_freq[None, None, :].to(x.device)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+
+
+def rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary_pos_emb(q, k, cos, sin):
+    cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+def _append(old, new, dim):
+    return new if old is None else torch.cat([old, new], dim=dim)
+
+
+def _append_factor(lst: list, new: torch.Tensor):
+    """Decode-block factors are stacked on a leading buffer dim in slot [1] (modeling_llamagear.py:276-286)."""
+    new = new.unsqueeze(0)
+    if len(lst) == 1:
+        lst.append(new)
+    else:
+        lst[1] = torch.cat([lst[1], new], dim=0)
+
+
+class LlamaAttention_GEAR(nn.Module):
+    """modeling_llamagear.py:113-484: attention whose cache is the packed GEAR payload plus an fp16 residual
+    window of `residual` tokens; a block is compressed whenever the window fills."""
+
+    def __init__(self, layer_idx, config, compress_config=None):
+        super().__init__()
+        self.layer_idx = layer_idx
+        self.compress_config = compress_config
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.max_position_embeddings = config.max_position_embeddings
+        self.rope_theta = config.rope_theta
+        self.k_bits = config.k_bits
+        self.v_bits = config.v_bits
+        self.group_size = config.group_size
+        self.residual_length = compress_config["residual"]
+        if (self.head_dim * self.num_heads) != self.hidden_size:
+            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
+                             f" and `num_heads`: {self.num_heads}).")
+        bias = getattr(config, "attention_bias", False)
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=bias)
+        self.rotary_emb = LlamaRotaryEmbedding(self.head_dim, self.max_position_embeddings, self.rope_theta)
+
+    # ---- cache transitions -----------------------------------------------------------------------------------
+    def _prefill_cache(self, key_states, value_states):
+        """Split the prompt: the first T - T % residual tokens are compressed, the tail stays fp16 (:386-434).
+        V is compressed only if T > residual (:416)."""
+        R = self.residual_length
+        T = key_states.shape[-2]
+        cc = self.compress_config
+        if T % R != 0:
+            if T < R:
+                k_quant, k_full = None, key_states
+            else:
+                k_quant, k_full = key_states[:, :, :-(T % R), :].contiguous(), key_states[:, :, -(T % R):, :].contiguous()
+        else:
+            k_quant, k_full = key_states, None
+        if k_quant is not None:
+            kc, ks, km, kp, kq = key_compression(k_quant.transpose(2, 3).contiguous(), cc)
+            kp, kq = [kp], [kq]
+        else:
+            kc = ks = km = kp = kq = None
+        if T <= R:
+            vc = vs = vm = vp = vq = None
+            v_full = value_states
+        else:
+            n_quant = T - T % R
+            v_full = value_states[:, :, n_quant:, :].contiguous()
+            vc, vs, vm, vp, vq = value_compression(value_states[:, :, :n_quant, :].contiguous(), cc)
+            vp, vq = [vp], [vq]
+            if v_full.shape[-2] == 0:
+                v_full = None
+        return (kc, k_full, ks, km, vc, v_full, vs, vm, T, kp, kq, None, None, vp, vq, None, None)
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.LongTensor] = None, past_key_value: Optional[Tuple] = None,
+                output_attentions: bool = False, use_cache: bool = False, **kwargs):
+        bsz, q_len, _ = hidden_states.size()
+        cc = self.compress_config
+        query_states = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim).transpose(1, 2)
+        key_states = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        value_states = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+
+        kv_seq_len = key_states.shape[-2]
+        if past_key_value is not None:
+            kv_seq_len += past_key_value[8]
+        if position_ids is None:
+            position_ids = torch.arange(kv_seq_len - q_len, kv_seq_len, device=hidden_states.device).unsqueeze(0)
+        cos, sin = self.rotary_emb(value_states, position_ids)
+        query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+        n_rep = self.num_key_value_groups
+        inv_norm = math.sqrt(self.head_dim)   # the reference divides (:261, :387)
+
+        if past_key_value is not None:
+            if q_len != 1:
+                raise ValueError("decode steps take one token at a time (the packed-cache GEMV is q_len == 1)")
+            (kc, k_full, ks, km, vc, v_full, vs, vm, _, kp, kq, _, _, vp, vq, _, _) = past_key_value
+            att_qkquant = None
+            if kc is not None:
+                att_qkquant = matmul_withlrap(cc["group_size"], query_states, kc, ks, km, cc["quantize_bit"], kp, kq,
+                                              type="key")
+            k_full = _append(k_full, key_states, 2)
+            att_qkfull = torch.matmul(query_states, _rep(k_full, n_rep).transpose(2, 3))
+            attn_weights = att_qkfull if att_qkquant is None else torch.cat([att_qkquant, att_qkfull], dim=-1)
+            attn_weights = attn_weights / inv_norm
+            if k_full.shape[-2] == self.residual_length:            # :265 -- compress the full window
+                assert self.residual_length % self.group_size == 0
+                kc_n, ks_n, km_n, kp_n, kq_n = key_compression(k_full.transpose(2, 3).contiguous(), cc)
+                k_full = None
+                if kc is not None:
+                    kc, ks, km = torch.cat([kc, kc_n], 3), torch.cat([ks, ks_n], 3), torch.cat([km, km_n], 3)
+                    if kp_n is not None:
+                        kp, kq = list(kp), list(kq)
+                        _append_factor(kp, kp_n)
+                        _append_factor(kq, kq_n)
+                else:
+                    kc, ks, km, kp, kq = kc_n, ks_n, km_n, [kp_n], [kq_n]
+            if attn_weights.size() != (bsz, self.num_heads, q_len, kv_seq_len):
+                raise ValueError(f"Attention weights should be of size {(bsz, self.num_heads, q_len, kv_seq_len)}, but is"
+                                 f" {attn_weights.size()}")
+            if attention_mask is not None:
+                if attention_mask.size() != (bsz, 1, q_len, kv_seq_len):
+                    raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is "
+                                     f"{attention_mask.size()}")
+                attn_weights = torch.max(attn_weights + attention_mask,
+                                         torch.tensor(torch.finfo(attn_weights.dtype).min, device=attn_weights.device))
+            attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)
+            v_full = _append(v_full, value_states, 2)
+            value_full_length = v_full.shape[-2]
+            if vc is None:
+                attn_output = torch.matmul(attn_weights, _rep(v_full, n_rep))
+            else:
+                attn_output = matmul_withlrap(cc["group_size"], attn_weights[:, :, :, :-value_full_length].contiguous(), vc,
+                                              vs, vm, cc["quantize_bit"], vp, vq, type="value")
+                attn_output = attn_output + torch.matmul(attn_weights[:, :, :, -value_full_length:], _rep(v_full, n_rep))
+            if value_full_length == self.residual_length:           # :335
+                vc_n, vs_n, vm_n, vp_n, vq_n = value_compression(v_full.contiguous(), cc)
+                v_full = None
+                if vc is not None:
+                    vc, vs, vm = torch.cat([vc, vc_n], 2), torch.cat([vs, vs_n], 2), torch.cat([vm, vm_n], 2)
+                    if vp_n is not None:
+                        vp, vq = list(vp), list(vq)
+                        _append_factor(vp, vp_n)
+                        _append_factor(vq, vq_n)
+                else:
+                    vc, vs, vm, vp, vq = vc_n, vs_n, vm_n, [vp_n], [vq_n]
+            new_cache = (kc, k_full, ks, km, vc, v_full, vs, vm, kv_seq_len, kp, kq, None, None, vp, vq, None, None)
+        else:
+            attn_weights = torch.matmul(query_states, _rep(key_states, n_rep).transpose(2, 3)) / inv_norm
+            if attn_weights.size() != (bsz, self.num_heads, q_len, kv_seq_len):
+                raise ValueError(f"Attention weights should be of size {(bsz, self.num_heads, q_len, kv_seq_len)}, but is"
+                                 f" {attn_weights.size()}")
+            if attention_mask is not None:
+                if attention_mask.size() != (bsz, 1, q_len, kv_seq_len):
+                    raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is "
+                                     f"{attention_mask.size()}")
+                attn_weights = torch.max(attn_weights + attention_mask,
+                                         torch.tensor(torch.finfo(attn_weights.dtype).min, device=attn_weights.device))
+            attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)
+            attn_output = torch.matmul(attn_weights, _rep(value_states, n_rep))
+            new_cache = self._prefill_cache(key_states, value_states)
+
+        if attn_output.size() != (bsz, self.num_heads, q_len, self.head_dim):
+            raise ValueError(f"`attn_output` should be of size {(bsz, self.num_heads, q_len, self.head_dim)}, but is"
+                             f" {attn_output.size()}")
+        attn_output = attn_output.transpose(1, 2).contiguous().reshape(bsz, q_len, self.hidden_size)
+        attn_output = self.o_proj(attn_output)
+        return attn_output, None, (new_cache if use_cache else None)
+
+
+# ------------------------------------------------------------------------------------------------- minimal Llama
+class LlamaRMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        dt = x.dtype
+        x = x.to(torch.float32)
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * x.to(dt)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class LlamaDecoderLayer_GEAR(nn.Module):
+    def __init__(self, config, layer_idx, compress_config):
+        super().__init__()
+        self.self_attn = LlamaAttention_GEAR(layer_idx, config, compress_config)
+        self.mlp = LlamaMLP(config)
+        self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, use_cache=False):
+        residual = hidden_states
+        hidden_states, _, present = self.self_attn(self.input_layernorm(hidden_states), attention_mask, position_ids,
+                                                   past_key_value, use_cache=use_cache)
+        hidden_states = residual + hidden_states
+        hidden_states = hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+        return hidden_states, present
+
+
+class LlamaModel_GEAR(nn.Module):
+    def __init__(self, config, compress_config):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([LlamaDecoderLayer_GEAR(config, i, compress_config)
+                                     for i in range(config.num_hidden_layers)])
+        self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids, past_key_values=None, use_cache=True):
+        bsz, q_len = input_ids.shape
+        past_len = past_key_values[0][8] if past_key_values is not None else 0     # slot 8 (:624)
+        position_ids = torch.arange(past_len, past_len + q_len, device=input_ids.device).unsqueeze(0)
+        hidden_states = self.embed_tokens(input_ids)
+        mask = None
+        if q_len > 1:
+            mask = torch.full((q_len, q_len), torch.finfo(hidden_states.dtype).min, device=input_ids.device,
+                              dtype=hidden_states.dtype).triu(1)[None, None].expand(bsz, 1, q_len, q_len)
+        presents = []
+        for i, layer in enumerate(self.layers):
+            hidden_states, present = layer(hidden_states, mask, position_ids,
+                                           past_key_values[i] if past_key_values is not None else None, use_cache)
+            presents.append(present)
+        return self.norm(hidden_states), tuple(presents)
+
+
+class LlamaForCausalLM_GEARKIVI(nn.Module):
+    """modeling_llamagear.py:711 -- causal LM over LlamaModel_GEAR with a greedy generate() for the timing harness
+    (cuda_supported_gear/test.py:95-102).  Weights are whatever the caller loads; the bench uses random init."""
+
+    def __init__(self, config, compress_config=None):
+        super().__init__()
+        self.config = config
+        self.model = LlamaModel_GEAR(config, compress_config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+
+    def forward(self, input_ids, past_key_values=None, use_cache=True):
+        hidden, presents = self.model(input_ids, past_key_values, use_cache)
+        return self.lm_head(hidden[:, -1:, :]), presents
+
+    @torch.no_grad()
+    def generate(self, input_ids, max_length: int, use_cache: bool = True):
+        logits, past = self.forward(input_ids, None, True)
+        out = [input_ids]
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        out.append(nxt)
+        while sum(t.shape[1] for t in out) < max_length:
+            logits, past = self.forward(nxt, past, True)
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+            out.append(nxt)
+        return torch.cat(out, dim=1)

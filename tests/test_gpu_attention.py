@@ -1,0 +1,176 @@
+"""GPU tests of the attention hook mirror (gear_amd/modeling_llamagear.py): the 17-slot cache state machine, the
+compress triggers, the prefill split and the fused dequant-GEMV + low-rank attention, against the numpy
+restatement in oracle/attention_oracle.py over a multi-block decode trace (SURVEY.md fixture F8)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _draw(B, H, S, Dm, r):
+    p = torch.rand(B, H, Dm, r)
+    _ = torch.rand(B, H, S, r)
+    return p.numpy()
+
+
+def _make(method, bits, n_heads, n_kv, rank=4):
+    from gear_amd.modeling_llamagear import LlamaAttention_GEAR, LlamaConfigLite
+    D = 128
+    cfg = LlamaConfigLite(hidden_size=n_heads * D, num_attention_heads=n_heads, num_key_value_heads=n_kv,
+                          num_hidden_layers=1, k_bits=bits, v_bits=bits, group_size=64, residual_length=64)
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=3)
+    torch.manual_seed(5)
+    attn = LlamaAttention_GEAR(0, cfg, cc).half().cuda()
+    return attn, cfg, cc
+
+
+def _trace(attn, cfg, prefill_len, n_decode, seed):
+    """Run the module; capture (q, k, v post-RoPE) and the tensor handed to o_proj at every step."""
+    caps = []
+    import gear_amd.modeling_llamagear as M
+    orig = M.apply_rotary_pos_emb
+
+    def spy(q, k, cos, sin):
+        qq, kk = orig(q, k, cos, sin)
+        caps.append([qq, kk])
+        return qq, kk
+
+    pre = []
+    h1 = attn.o_proj.register_forward_pre_hook(lambda m, inp: pre.append(inp[0]))
+    vcap = []
+    h2 = attn.v_proj.register_forward_hook(lambda m, i, o: vcap.append(o))
+    M.apply_rotary_pos_emb = spy
+    try:
+        g = torch.Generator().manual_seed(seed)
+        x = (torch.randn(1, prefill_len, cfg.hidden_size, generator=g) * 0.5).half().cuda()
+        mask = torch.full((prefill_len, prefill_len), torch.finfo(torch.float16).min, dtype=torch.float16,
+                          device="cuda").triu(1)[None, None]
+        torch.manual_seed(seed)
+        out, _, cache = attn(x, attention_mask=mask, use_cache=True)
+        caches = [cache]
+        for i in range(n_decode):
+            xt = (torch.randn(1, 1, cfg.hidden_size, generator=g) * 0.5).half().cuda()
+            out, _, cache = attn(xt, past_key_value=cache, use_cache=True)
+            caches.append(cache)
+    finally:
+        M.apply_rotary_pos_emb = orig
+        h1.remove()
+        h2.remove()
+    return caps, vcap, pre, mask, caches
+
+
+@pytest.mark.parametrize("method,bits,n_heads,n_kv", [("gearlKIVI", 2, 2, 2), ("gearlKIVI", 4, 2, 2), ("KIVI", 2, 2, 2),
+                                                      ("gearlKIVI", 2, 4, 2)])
+def test_decode_trace_vs_oracle(method, bits, n_heads, n_kv):
+    from oracle.attention_oracle import GearAttentionOracle
+    attn, cfg, cc = _make(method, bits, n_heads, n_kv)
+    D, Tp, steps = 128, 200, 130
+    caps, vcap, pre, mask, caches = _trace(attn, cfg, Tp, steps, seed=77)
+    assert len(caps) == steps + 1 and len(pre) == steps + 1
+
+    def heads(t, n):   # [1,T,n*D] -> [1,n,T,D]
+        return np.ascontiguousarray(host(t).reshape(1, -1, n, D).transpose(0, 2, 1, 3))
+
+    orc_attn = GearAttentionOracle(n_heads, n_kv, D, cc, _draw)
+    torch.manual_seed(77)
+    ref = orc_attn.prefill(host(caps[0][0]), host(caps[0][1]), heads(vcap[0], n_kv), host(mask))
+    got = heads(pre[0], n_heads)
+    assert rel_fro(got, ref) < 3e-3
+    worst = 0.0
+    for i in range(steps):
+        ref = orc_attn.decode(host(caps[i + 1][0]), host(caps[i + 1][1]), heads(vcap[i + 1], n_kv))
+        got = heads(pre[i + 1], n_heads)
+        worst = max(worst, rel_fro(got, ref))
+    assert worst < 5e-3, worst
+    # ---- cache tuple: slot layout, slot 8, compress triggers, prefill split (modeling_llamagear.py:390-466)
+    c0 = caches[0]
+    assert len(c0) == 17 and c0[8] == Tp
+    fpi = 32 // bits
+    assert tuple(c0[0].shape) == (1, n_kv, D, 192 // fpi) and c0[0].dtype == torch.int32
+    assert tuple(c0[1].shape) == (1, n_kv, 8, D) and tuple(c0[5].shape) == (1, n_kv, 8, D)
+    assert tuple(c0[2].shape) == (1, n_kv, D, 3) and tuple(c0[4].shape) == (1, n_kv, 192, D // fpi)
+    assert tuple(c0[6].shape) == (1, n_kv, 192, 2)
+    assert c0[11] is None and c0[12] is None and c0[15] is None and c0[16] is None
+    last = caches[-1]
+    assert last[8] == Tp + steps                                  # 330 tokens: 320 compressed + 10 in the window
+    assert last[0].shape[-1] == 320 // fpi and last[4].shape[2] == 320
+    assert last[1].shape[2] == 10 and last[5].shape[2] == 10
+    if "gearl" in method:
+        assert len(last[9]) == 2 and tuple(last[9][0].shape) == (1, n_kv, 192, 4)     # K P: token side
+        assert tuple(last[9][1].shape) == (2, 1, n_kv, 64, 4)                          # two stacked decode blocks
+        assert tuple(last[10][0].shape) == (1, n_kv, D, 4) and tuple(last[10][1].shape) == (2, 1, n_kv, D, 4)
+        assert tuple(last[13][0].shape) == (1, n_kv, D, 4) and tuple(last[14][1].shape) == (2, 1, n_kv, 64, 4)
+    else:
+        assert last[9] == [None] and last[13] == [None]
+    # the window is compressed exactly when it reaches `residual` tokens: step 56 (256) and 120 (320)
+    assert caches[56][1] is None and caches[55][1].shape[2] == 63 and caches[57][1].shape[2] == 1
+
+
+def test_short_prompt_stays_fp16_then_compresses():
+    """T < residual: nothing is quantized at prefill (:392-394, :416-421); the first block is compressed when the
+    fp16 window fills."""
+    attn, cfg, cc = _make("gearlKIVI", 2, 2, 2)
+    caps, vcap, pre, mask, caches = _trace(attn, cfg, 40, 30, seed=3)
+    assert caches[0][0] is None and caches[0][4] is None and caches[0][1].shape[2] == 40
+    assert caches[23][1].shape[2] == 63 and caches[24][1] is None and caches[24][0] is not None
+    assert caches[24][0].shape[-1] == 64 // 16 and caches[24][4].shape[2] == 64
+    assert all(torch.isfinite(p).all() for p in pre)
+
+
+def test_matmul_withlrap_matches_dense_reconstruction():
+    """a7: fused GEMV + low-rank == a @ (dequant + Q P^T) for both sides and for stacked decode-block factors."""
+    from gear_amd.modeling_llamagear import key_compression, matmul_withlrap, value_compression
+    from gear_amd.quant import new_pack
+    torch.manual_seed(9)
+    cc = dict(compress_method="gearlKIVI", group_size=64, residual=64, quantize_bit=4, rank=4, rankv=4, loop=3)
+    B, H, D = 1, 2, 128
+    k0, k1, k2 = [torch.randn(B, H, t, D).half().cuda() for t in (128, 64, 64)]
+    q = torch.randn(B, H, 1, D).half().cuda()
+    parts = [key_compression(k.transpose(2, 3).contiguous(), cc) for k in (k0, k1, k2)]
+    code = torch.cat([p[0] for p in parts], 3)
+    scale = torch.cat([p[1] for p in parts], 3)
+    mn = torch.cat([p[2] for p in parts], 3)
+    pbase = [parts[0][3], torch.stack([parts[1][3], parts[2][3]])]
+    qbase = [parts[0][4], torch.stack([parts[1][4], parts[2][4]])]
+    got = matmul_withlrap(64, q, code, scale, mn, 4, pbase, qbase, type="key").float()
+    deq = new_pack.unpack_and_dequant_vcache(code, scale.unsqueeze(-1), mn.unsqueeze(-1), 64, 4).float()  # [B,H,D,T]
+    lr = torch.cat([(p[4].float() @ p[3].float().transpose(2, 3)) for p in parts], 3)                      # Q P^T [D,T]
+    ref = q.float() @ (deq + lr)
+    assert rel_fro(host(got), host(ref)) < 3e-3
+    v0, v1, v2 = [torch.randn(B, H, t, D).half().cuda() for t in (128, 64, 64)]
+    a = torch.softmax(torch.randn(B, H, 1, 256).cuda(), -1).half()
+    vparts = [value_compression(v, cc) for v in (v0, v1, v2)]
+    vcode = torch.cat([p[0] for p in vparts], 2)
+    vscale = torch.cat([p[1] for p in vparts], 2)
+    vmn = torch.cat([p[2] for p in vparts], 2)
+    vp = [vparts[0][3], torch.stack([vparts[1][3], vparts[2][3]])]
+    vq = [vparts[0][4], torch.stack([vparts[1][4], vparts[2][4]])]
+    got = matmul_withlrap(64, a, vcode, vscale, vmn, 4, vp, vq, type="value").float()
+    vdeq = new_pack.unpack_and_dequant_vcache(vcode, vscale.unsqueeze(-1), vmn.unsqueeze(-1), 64, 4).float()
+    vlr = torch.cat([(p[4].float() @ p[3].float().transpose(2, 3)) for p in vparts], 2)                    # [T,D]
+    ref = a.float() @ (vdeq + vlr)
+    assert rel_fro(host(got), host(ref)) < 3e-3
+
+
+def test_generate_runs_and_is_deterministic():
+    """a14 counterpart: tiny random-weight model, prefill + greedy decode through the packed cache."""
+    from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
+    cfg = LlamaConfigLite(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                          num_attention_heads=2, num_key_value_heads=2)
+    cc = dict(compress_method="gearlKIVI", group_size=64, residual=64, quantize_bit=2, rank=2, rankv=2, loop=3)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM_GEARKIVI(cfg, cc).half().cuda().eval()
+    ids = torch.randint(0, 512, (2, 100)).cuda()
+    torch.manual_seed(1)
+    out1 = model.generate(ids, max_length=180)
+    torch.manual_seed(1)
+    out2 = model.generate(ids, max_length=180)
+    assert out1.shape == (2, 180) and torch.equal(out1, out2)
+    assert torch.equal(out1[:, :100], ids)
