@@ -12,6 +12,8 @@
 //     rowdot : Y[R x RP]  = M   X[C x RP]      (row-local dot products, 16 lanes per row, 8 columns per lane)
 //     coldot : Y[C x RP] += M^T X[R x RP]      (lanes own 8 columns and stream rows; LDS + atomics at the end)
 // E stored as [S x Dm] ("normal", V and the build's K error) or as its transpose [Dm x S] (the K^T layout).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -304,6 +306,9 @@ inline int pad_rank(int r) { return r <= 4 ? 4 : (r <= 8 ? 8 : 16); }
 
 }  // namespace
 
+int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
+                      void* Q_out, int out_dtype, void* workspace, hipStream_t st);
+
 extern "C" size_t gear_lowrank_workspace(int64_t bh, int S, int Dm, int r) {
     if (r < 1 || r > 16) return 0;
     size_t RP = (size_t)pad_rank(r);
@@ -323,6 +328,9 @@ extern "C" int gear_lowrank(const void* E, int e_dtype, int transposed, int64_t 
     GEAR_CHECK_ARG(C % 8 == 0, "gear_lowrank: contiguous dim %d must be a multiple of 8", C);
     GEAR_CHECK_ARG(E && P0 && P_out && Q_out && workspace, "gear_lowrank: null pointer");
     GEAR_CHECK_ARG(workspace_bytes >= gear_lowrank_workspace(bh, S, Dm, r), "gear_lowrank: workspace too small");
+    // fast path: fp16 error, head_dim 128 -> Gram-matrix formulation on the matrix cores (lowrank_gram.hip)
+    if (e_dtype == GEAR_DTYPE_F16 && Dm == 128 && (!transposed || S % 8 == 0) && !getenv("GEAR_LOWRANK_GENERIC"))
+        return gear_lowrank_gram(E, transposed, bh, S, r, loop, P0, P_out, Q_out, out_dtype, workspace, (hipStream_t)stream);
     const int RP = pad_rank(r);
     LrWs ws;
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

@@ -1,0 +1,350 @@
+// lowrank_gram.hip -- the power iteration of lowrank.hip restructured around the Gram matrix, for head_dim 128.
+//
+//   for i < loop: [last: P = orth(P)]  Q = E P  [last: Q = orth(Q)]  P = E^T Q          (reference order)
+// With G = E^T E (128 x 128, per head) every P-update is P <- G P, so
+//   P_a = G^(loop-1) P0 ; P' = orth(P_a) ; Q = E P' ; Q^T Q = P'^T G P' = R^T R ; Q' = E (P' R^-1) ;  P_out = G (P' R^-1)
+// i.e. the whole iteration needs ONE pass over E on the matrix cores (the Gram matrix, fp16 inputs are exact, fp32
+// accumulate), a tiny per-head solve that never leaves LDS, and ONE more pass Q' = E W with W = P' R^-1.
+// The reference makes 2*loop passes over E (new_pack.py:298-304); same mathematics, fp32-level differences.
+//
+// Kernel 1 (one workgroup per head): stream E through LDS, v_mfma_f32_32x32x16_f16 on the 10 upper-triangular
+//   32x32 blocks of G (contraction over tokens), then the solve (CholeskyQR2 in fp64 for orth(P), one Cholesky for Q).
+// Kernel 2: Q' = E W -- lanes own 8 tokens and stream the 128 channels (K^T layout) or 16 lanes share a token row
+//   (token-major layout); plain fp32 FMAs, HBM-bound.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+constexpr int GD = 128;          // head_dim (the Gram trick is built for 128)
+constexpr int KT_PITCH = 72;     // halfs per LDS row of the K^T staging tile [128][64 (+8 pad)]
+constexpr int TM_PITCH = 136;    // halfs per LDS row of the token-major staging tile [64][128 (+8 pad)]
+
+__host__ __device__ constexpr int blk_index(int I, int J) {  // upper-triangular block (I <= J) -> 0..9
+    return I * 4 - (I * (I - 1)) / 2 + (J - I);
+}
+
+// LDS layout (bytes): [0, 65536) G fp32 (its head doubles as the staging tile while the Gram matrix is
+// still in registers), then Pa, Pb fp32 [128][RP], then small fp64 scratch.
+template <int RP, bool TOKEN_MAJOR>
+__global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* __restrict__ E, int S, int loop,
+                                                               const float* __restrict__ P0, int r,
+                                                               float* __restrict__ Wout, void* __restrict__ P_out,
+                                                               int out_f16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* G = (float*)smem;                                  // [128][128]
+    uint16_t* tile = (uint16_t*)smem;                         // staging (aliases G during phase 1)
+    float* Pa = (float*)(smem + GD * GD * 4);                 // [128][RP]
+    float* Pb = Pa + GD * RP;                                 // [128][RP]
+    double* Md = (double*)(Pb + GD * RP);                     // [RP][RP]
+    double* Rinv = Md + RP * RP;                              // [RP][RP]
+
+    const int64_t bh = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 31, kg = lane >> 5;
+    const uint16_t* Eb = E + bh * (int64_t)S * GD;
+
+    float16_t acc[10];
+#pragma unroll
+    for (int b = 0; b < 10; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
+
+    // ------------------------------------------------------------------ phase 1: G = E^T E on the matrix cores
+    for (int t0 = 0; t0 < S; t0 += 64) {
+        __syncthreads();
+        if (TOKEN_MAJOR) {
+            // tile [64 tokens][128 channels]: 16 lanes per token row, 16 rows per pass
+            const int l16 = tid & 15, rr = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int t = t0 + rr + 16 * p;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (t < S) v = *(const uint4*)(Eb + (int64_t)t * GD + l16 * 8);
+                *(uint4*)(tile + (rr + 16 * p) * TM_PITCH + l16 * 8) = v;
+            }
+        } else {
+            // K^T: E^T [128 channels][S tokens]; tile [128][64]: 8 lanes per channel row, 32 rows per pass
+            const int l8 = tid & 7, rr = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                int d = rr + 32 * p;
+                int t = t0 + l8 * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (t < S) v = *(const uint4*)(Eb + (int64_t)d * S + t);
+                *(uint4*)(tile + d * KT_PITCH + l8 * 8) = v;
+            }
+        }
+        __syncthreads();
+        // wave w owns tokens [16w, 16w+16) of the tile; lane (x, kg) holds channel x of each 32-block, tokens 8kg..8kg+7
+        half8_t f[4];
+#pragma unroll
+        for (int I = 0; I < 4; I++) {
+            if (TOKEN_MAJOR) {
+                union { half8_t h; uint16_t u[8]; } cv;
+#pragma unroll
+                for (int j = 0; j < 8; j++) cv.u[j] = tile[(16 * wave + 8 * kg + j) * TM_PITCH + 32 * I + x];
+                f[I] = cv.h;
+            } else {
+                union { half8_t h; uint4 u; } cv;
+                cv.u = *(const uint4*)(tile + (32 * I + x) * KT_PITCH + 16 * wave + 8 * kg);
+                f[I] = cv.h;
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I++)
+#pragma unroll
+            for (int J = I; J < 4; J++)
+                acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
+    }
+    __syncthreads();
+    for (int i = tid; i < GD * GD; i += 256) G[i] = 0.0f;
+    __syncthreads();
+    // C layout of the 32x32 MFMA: lane l, reg q -> row (q&3) + 8*(q>>2) + 4*(l>>5), col l&31
+#pragma unroll
+    for (int I = 0; I < 4; I++)
+#pragma unroll
+        for (int J = I; J < 4; J++) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                int row = 32 * I + (q & 3) + 8 * (q >> 2) + 4 * kg, col = 32 * J + x;
+                float v = acc[blk_index(I, J)][q];
+                atomicAdd(&G[row * GD + col], v);
+                if (I != J) atomicAdd(&G[col * GD + row], v);
+            }
+        }
+    // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS
+    for (int i = tid; i < GD * RP; i += 256) {
+        int d = i / RP, c = i % RP;
+        Pa[i] = (c < r) ? P0[(bh * GD + d) * r + c] : 0.0f;
+    }
+    __syncthreads();
+    auto matmulG = [&](const float* X, float* Y) {  // Y = G X   ([128][RP])
+        for (int i = tid; i < GD * RP; i += 256) {
+            int d = i / RP, c = i % RP;
+            float s = 0.0f;
+            for (int e = 0; e < GD; e++) s = fmaf(G[d * GD + e], X[e * RP + c], s);
+            Y[i] = s;
+        }
+        __syncthreads();
+    };
+    auto chol_inverse = [&]() {  // Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0
+        if (tid == 0) {
+            double Rm[RP][RP];
+            bool dead[RP];
+            for (int j = 0; j < RP; j++)
+                for (int i = 0; i < RP; i++) Rm[i][j] = 0.0;
+            for (int j = 0; j < RP; j++) {
+                double dg = Md[j * RP + j];
+                double d = dg;
+                for (int kk = 0; kk < j; kk++) d -= Rm[kk][j] * Rm[kk][j];
+                dead[j] = !(d > 1e-12 * dg) || !(dg > 0.0);
+                if (dead[j]) { Rm[j][j] = 1.0; continue; }
+                double rjj = sqrt(d);
+                Rm[j][j] = rjj;
+                for (int m = j + 1; m < RP; m++) {
+                    double s = Md[j * RP + m];
+                    for (int kk = 0; kk < j; kk++) s -= Rm[kk][j] * Rm[kk][m];
+                    Rm[j][m] = s / rjj;
+                }
+            }
+            for (int j = 0; j < RP; j++) {
+                for (int i = 0; i < RP; i++) Rinv[i * RP + j] = 0.0;
+                if (dead[j]) continue;
+                Rinv[j * RP + j] = 1.0 / Rm[j][j];
+                for (int i = j - 1; i >= 0; i--) {
+                    double s = 0.0;
+                    for (int kk = i + 1; kk <= j; kk++) s += Rm[i][kk] * Rinv[kk * RP + j];
+                    Rinv[i * RP + j] = dead[i] ? 0.0 : -s / Rm[i][i];
+                }
+            }
+        }
+        __syncthreads();
+    };
+    auto gram_small = [&](const float* A, const float* B) {  // Md = A^T B  (fp64 accumulate)
+        for (int i = tid; i < RP * RP; i += 256) {
+            int a = i / RP, b = i % RP;
+            double s = 0.0;
+            for (int d = 0; d < GD; d++) s += (double)A[d * RP + a] * (double)B[d * RP + b];
+            Md[i] = s;
+        }
+        __syncthreads();
+    };
+    auto apply_rinv = [&](const float* X, float* Y) {  // Y = X Rinv
+        for (int i = tid; i < GD * RP; i += 256) {
+            int d = i / RP, c = i % RP;
+            double s = 0.0;
+            for (int a = 0; a <= c; a++) s += (double)X[d * RP + a] * Rinv[a * RP + c];
+            Y[i] = (float)s;
+        }
+        __syncthreads();
+    };
+    float* cur = Pa;
+    float* oth = Pb;
+    for (int it = 0; it + 1 < loop; it++) {  // P <- G P, loop-1 times
+        matmulG(cur, oth);
+        float* t = cur; cur = oth; oth = t;
+    }
+    // P' = orth(P): CholeskyQR twice (fp64 Gram) -- stable for the column scaling power iteration produces
+    for (int rep = 0; rep < 2; rep++) {
+        gram_small(cur, cur);
+        chol_inverse();
+        apply_rinv(cur, oth);
+        float* t = cur; cur = oth; oth = t;
+    }
+    // T1 = G P' ; Q^T Q = P'^T T1 ; W = P' R^-1 ; P_out = T1 R^-1
+    matmulG(cur, oth);            // oth = T1
+    gram_small(cur, oth);
+    chol_inverse();
+    // write W (fp32, padded) and P_out
+    for (int i = tid; i < GD * RP; i += 256) {
+        int d = i / RP, c = i % RP;
+        double sw = 0.0, sp = 0.0;
+        for (int a = 0; a <= c; a++) {
+            sw += (double)cur[d * RP + a] * Rinv[a * RP + c];
+            sp += (double)oth[d * RP + a] * Rinv[a * RP + c];
+        }
+        Wout[(bh * GD + d) * RP + c] = (float)sw;
+        if (c < r) {
+            if (out_f16) ((uint16_t*)P_out)[(bh * GD + d) * r + c] = f2h_bits((float)sp);
+            else ((float*)P_out)[(bh * GD + d) * r + c] = (float)sp;
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void store_halfs(uint16_t* p, const float* f) {  // N in {4, 8, 16}, p aligned to 2N bytes
+    if (N == 4) {
+        uint2 v;
+        v.x = (uint32_t)f2h_bits(f[0]) | ((uint32_t)f2h_bits(f[1]) << 16);
+        v.y = (uint32_t)f2h_bits(f[2]) | ((uint32_t)f2h_bits(f[3]) << 16);
+        *(uint2*)p = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N / 8; i++) ((uint4*)p)[i] = pack8(f + 8 * i);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Q' = E W
+// K^T layout: E^T [bh][128][S].  Lane owns 8 consecutive tokens and walks the 128 channel rows.
+template <int RP>
+__global__ __launch_bounds__(256) void lr_qpass_kt_kernel(const uint16_t* __restrict__ Et, const float* __restrict__ W,
+                                                          int S, int r, void* __restrict__ Q_out, int out_f16) {
+    __shared__ float Ws[GD * RP];
+    const int64_t bh = blockIdx.y;
+    for (int i = threadIdx.x; i < GD * RP; i += 256) Ws[i] = W[bh * GD * RP + i];
+    __syncthreads();
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (t0 >= S) return;
+    const uint16_t* p = Et + bh * (int64_t)GD * S + t0;
+    float acc[8][RP];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int c = 0; c < RP; c++) acc[j][c] = 0.0f;
+#pragma unroll 4
+    for (int d = 0; d < GD; d++) {
+        float m[8];
+        unpack8(*(const uint4*)(p + (int64_t)d * S), m);
+#pragma unroll
+        for (int c = 0; c < RP; c++) {
+            float w = Ws[d * RP + c];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j][c] = fmaf(m[j], w, acc[j][c]);
+        }
+    }
+    if (out_f16 && r == RP && t0 + 8 <= S) {   // 8 tokens x RP halfs = one contiguous run per lane
+        uint16_t* qo = (uint16_t*)Q_out + (bh * S + t0) * (int64_t)RP;
+#pragma unroll
+        for (int j = 0; j < 8; j++) store_halfs<RP>(qo + j * RP, acc[j]);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (t0 + j >= S) break;
+        for (int c = 0; c < r; c++) {
+            int64_t o = (bh * S + t0 + j) * r + c;
+            if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[j][c]);
+            else ((float*)Q_out)[o] = acc[j][c];
+        }
+    }
+}
+
+// token-major layout: E [bh][S][128].  16 lanes share a token row (8 channels per lane), W in registers.
+template <int RP>
+__global__ __launch_bounds__(256) void lr_qpass_tm_kernel(const uint16_t* __restrict__ E, const float* __restrict__ W,
+                                                          int S, int r, void* __restrict__ Q_out, int out_f16) {
+    const int64_t bh = blockIdx.y;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const float* Wb = W + bh * GD * RP;
+    float wr[8][RP];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int c = 0; c < RP; c++) wr[i][c] = Wb[(l16 * 8 + i) * RP + c];
+    for (int i = 0; i < 8; i++) {
+        const int row = blockIdx.x * 128 + grp + 16 * i;
+        float acc[RP];
+#pragma unroll
+        for (int c = 0; c < RP; c++) acc[c] = 0.0f;
+        if (row < S) {
+            float m[8];
+            unpack8(*(const uint4*)(E + (bh * S + row) * (int64_t)GD + l16 * 8), m);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int c = 0; c < RP; c++) acc[c] = fmaf(m[j], wr[j][c], acc[c]);
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+            for (int c = 0; c < RP; c++) acc[c] += __shfl_xor(acc[c], d, 64);
+        if (l16 == 0 && row < S) {
+            if (out_f16 && r == RP) {
+                store_halfs<RP>((uint16_t*)Q_out + (bh * S + row) * (int64_t)RP, acc);
+                continue;
+            }
+            for (int c = 0; c < r; c++) {
+                int64_t o = (bh * S + row) * r + c;
+                if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[c]);
+                else ((float*)Q_out)[o] = acc[c];
+            }
+        }
+    }
+}
+
+template <int RP>
+int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int loop, const float* P0, void* P_out,
+             void* Q_out, int out_dtype, float* Wws, hipStream_t st) {
+    const int of16 = out_dtype == GEAR_DTYPE_F16;
+    size_t shmem = (size_t)GD * GD * 4 + 2 * (size_t)GD * RP * 4 + 2 * (size_t)RP * RP * 8;
+    if (transposed) {
+        auto kfn = lr_gram_solve_kernel<RP, false>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16);
+        hipLaunchKernelGGL((lr_qpass_kt_kernel<RP>), dim3((S + 2047) / 2048, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
+                           Q_out, of16);
+    } else {
+        auto kfn = lr_gram_solve_kernel<RP, true>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16);
+        hipLaunchKernelGGL((lr_qpass_tm_kernel<RP>), dim3((S + 127) / 128, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
+                           Q_out, of16);
+    }
+    GEAR_CHECK_LAUNCH("gear_lowrank(gram)");
+    return 0;
+}
+
+}  // namespace
+
+// Called by gear_lowrank() when the fast path applies: fp16 error, Dm == 128, S % 8 == 0 (K^T layout).
+int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
+                      void* Q_out, int out_dtype, void* workspace, hipStream_t st) {
+    const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
+    float* Wws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (RP == 4) return run_gram<4>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
+    if (RP == 8) return run_gram<8>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
+    return run_gram<16>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
+}

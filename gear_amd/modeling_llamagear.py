@@ -180,15 +180,23 @@ class LlamaAttention_GEAR(nn.Module):
     """modeling_llamagear.py:113-484: attention whose cache is the packed GEAR payload plus an fp16 residual
     window of `residual` tokens; a block is compressed whenever the window fills."""
 
-    def __init__(self, layer_idx, config, compress_config=None):
+    def __init__(self, layer_idx, config, compress_config=None, tp_rank: int = 0, tp_world: int = 1, tp_group=None):
+        """tp_world > 1: head-sharded attention (new design -- the reference has no
+        distributed code): this rank owns num_attention_heads / tp_world query heads and the matching KV heads, its
+        own slice of the packed cache, and all-gathers the per-head attention output before the (replicated) o_proj."""
         super().__init__()
         self.layer_idx = layer_idx
         self.compress_config = compress_config
         self.config = config
+        self.tp_rank, self.tp_world, self.tp_group = tp_rank, tp_world, tp_group
         self.hidden_size = config.hidden_size
-        self.num_heads = config.num_attention_heads
-        self.head_dim = self.hidden_size // self.num_heads
-        self.num_key_value_heads = config.num_key_value_heads
+        self.total_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.total_heads
+        if config.num_attention_heads % tp_world or config.num_key_value_heads % tp_world:
+            raise ValueError(f"heads ({config.num_attention_heads} q / {config.num_key_value_heads} kv) must divide "
+                             f"across {tp_world} ranks")
+        self.num_heads = config.num_attention_heads // tp_world              # local query heads
+        self.num_key_value_heads = config.num_key_value_heads // tp_world    # local KV heads
         self.num_key_value_groups = self.num_heads // self.num_key_value_heads
         self.max_position_embeddings = config.max_position_embeddings
         self.rope_theta = config.rope_theta
@@ -196,14 +204,14 @@ class LlamaAttention_GEAR(nn.Module):
         self.v_bits = config.v_bits
         self.group_size = config.group_size
         self.residual_length = compress_config["residual"]
-        if (self.head_dim * self.num_heads) != self.hidden_size:
+        if (self.head_dim * self.total_heads) != self.hidden_size:
             raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
-                             f" and `num_heads`: {self.num_heads}).")
+                             f" and `num_heads`: {self.total_heads}).")
         bias = getattr(config, "attention_bias", False)
         self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
         self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
         self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
-        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=bias)
+        self.o_proj = nn.Linear(self.total_heads * self.head_dim, self.hidden_size, bias=bias)
         self.rotary_emb = LlamaRotaryEmbedding(self.head_dim, self.max_position_embeddings, self.rope_theta)
 
     # ---- cache transitions -----------------------------------------------------------------------------------
@@ -323,12 +331,15 @@ class LlamaAttention_GEAR(nn.Module):
                                          torch.tensor(torch.finfo(attn_weights.dtype).min, device=attn_weights.device))
             attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)
             attn_output = torch.matmul(attn_weights, _rep(value_states, n_rep))
-            new_cache = self._prefill_cache(key_states, value_states)
+            new_cache = self._prefill_cache(key_states, value_states) if use_cache else None
 
         if attn_output.size() != (bsz, self.num_heads, q_len, self.head_dim):
             raise ValueError(f"`attn_output` should be of size {(bsz, self.num_heads, q_len, self.head_dim)}, but is"
                              f" {attn_output.size()}")
-        attn_output = attn_output.transpose(1, 2).contiguous().reshape(bsz, q_len, self.hidden_size)
+        attn_output = attn_output.transpose(1, 2).contiguous().reshape(bsz, q_len, self.num_heads * self.head_dim)
+        if self.tp_world > 1:
+            from .parallel import all_gather_heads
+            attn_output = all_gather_heads(attn_output, self.tp_world, self.tp_group)
         attn_output = self.o_proj(attn_output)
         return attn_output, None, (new_cache if use_cache else None)
 
