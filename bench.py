@@ -118,7 +118,7 @@ def main():
 
     def step():
         stage("t0")
-        kt = K.transpose(2, 3).contiguous()                      # what the attention hook hands over (llamagear.py:268)
+        kt = C.transpose_last2(K)                                # K^T, what the attention hook hands over (llamagear.py:268)
         stage("k_transpose")
         pk = C.compress_key_t(kt, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k)
         stage("k_compress")

@@ -32,6 +32,7 @@ SIGNATURES = {
     "gear_lowrank": (_i, [_vp, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "gear_decompress_rows": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _i,
                                   _vp, _vp, _i, _vp, _vp]),
+    "gear_transpose_f16": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "gear_gemv_outer": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i64, _i64, _vp, _vp, _sz, _vp]),
 }
 

@@ -152,10 +152,22 @@ def compress_key_t(kt: torch.Tensor, bits: int, group: int, k_out: int = 0, rank
     return Payload("k", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
 
 
+def transpose_last2(x: torch.Tensor) -> torch.Tensor:
+    """fp16 [B,H,R,C] -> contiguous [B,H,C,R] with the LDS-tiled HIP kernel (the reference's caller does
+    key_states.transpose(2, 3).contiguous(), modeling_llamagear.py:268, :403)."""
+    assert x.dim() == 4 and x.dtype == torch.float16
+    x = x.contiguous()
+    L.require_gpu(x)
+    B, H, R, Cc = x.shape
+    y = torch.empty((B, H, Cc, R), dtype=torch.float16, device=x.device)
+    rc = L.load().gear_transpose_f16(L.ptr(x), B * H, R, Cc, L.ptr(y), L.stream_ptr())
+    L.check(rc, "gear_transpose_f16")
+    return y
+
+
 def compress_key(k: torch.Tensor, *args, **kw) -> Payload:
-    """K [B,H,T,D] fp16 (token-major) -> Payload.  The transpose is the same one the reference's caller performs
-    (key_states.transpose(2, 3).contiguous(), modeling_llamagear.py:268, :403)."""
-    return compress_key_t(k.transpose(2, 3).contiguous(), *args, **kw)
+    """K [B,H,T,D] fp16 (token-major) -> Payload (the K^T re-layout runs on the HIP transpose kernel)."""
+    return compress_key_t(transpose_last2(k), *args, **kw)
 
 
 def decompress(p: Payload, transposed_out: bool = False) -> torch.Tensor:
@@ -176,4 +188,4 @@ def decompress(p: Payload, transposed_out: bool = False) -> torch.Tensor:
                                   p.bits, p.mode, 1, L.ptr(p.P), L.ptr(p.Q), r, T, D, L.ptr(p.oidx), L.ptr(p.oval), k,
                                   L.ptr(out), L.stream_ptr())
     L.check(rc, "gear_decompress_rows")
-    return out if transposed_out else out.transpose(2, 3).contiguous()
+    return out if transposed_out else transpose_last2(out)

@@ -90,6 +90,32 @@ __device__ __forceinline__ void find_crossing(const uint32_t* hist, int need, in
     }
 }
 
+
+// ---- candidate-based exact top-k (fast path) ------------------------------------------------------------------
+// Every one of the k largest elements of a row is >= tau_hi whenever at least k elements are >= tau_hi.  Take, in each
+// wave, the ceil(k/nw)-th largest of the 64 per-lane maxima (bitonic sort in registers); tau_hi = the minimum of those
+// over the waves: at least k distinct elements (lane maxima) are >= tau_hi.  Typically only ~1-2 % of the row passes
+// the threshold; the survivors are ranked exactly (value, then lower index first) in LDS.  Same for the small side.
+constexpr int CAND_CAP = 640;
+
+template <bool DESC>
+__device__ __forceinline__ uint32_t wave_bitonic_sort(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            uint32_t o = __shfl_xor(v, j, 64);
+            bool up = ((lane & k2) == 0);
+            bool lower = ((lane & j) == 0);
+            uint32_t mx = max(v, o), mn = min(v, o);
+            bool take_first = (lower == up);            // "first" = max for a descending sort, min for ascending
+            v = DESC ? (take_first ? mx : mn) : (take_first ? mn : mx);
+        }
+    }
+    return v;  // lane i holds the i-th element of the sorted order
+}
+
 template <int BITS, int MODE, typename ST>
 __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k,
                                      uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
@@ -102,6 +128,10 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     __shared__ unsigned long long wave_tot[16];
     __shared__ float wave_sum[16];
     __shared__ int sh[8];  // 0 bin_hi, 1 need_hi, 2 bin_lo, 3 need_lo, 4 thr_hi, 5 take_hi, 6 thr_lo, 7 take_lo
+    __shared__ uint32_t cand[2][CAND_CAP];   // composite (key, index) of the hi / lo candidates
+    __shared__ uint32_t omask[2][512];       // per-element outlier bitmaps (hi / lo), row length <= 16384
+    __shared__ uint32_t wave_thr[2][16];
+    __shared__ uint32_t ncand[2];
 
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -139,64 +169,123 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
         if (lane == 0) wave_sum[wave] = s;
-        // ---------------- level-1 histogram on the high key byte
-        for (int i = tid; i < 3 * 256; i += blockDim.x) (&hist[0][0])[i] = 0u;
-        __syncthreads();
         uint32_t key[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) key[j] = sort_key(hb[j]);
-        if (active) {
+        // ---------------- fast path: thresholds from the sorted per-lane extrema
+        const int kk = (k + nw - 1) / nw;
+        bool use_hist = kk > 64;
+        if (!use_hist) {
+            uint32_t lmax = 0u, lmin = 0xFFFFu;
+            if (active) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) atomicAdd(&hist[0][key[j] >> 8], 1u);
+                for (int j = 0; j < 16; j++) { lmax = max(lmax, key[j]); lmin = min(lmin, key[j]); }
+            }
+            // inactive lanes carry (0, 0xFFFF): they sort to the end of both lists
+            uint32_t smax = wave_bitonic_sort<true>(lmax);
+            uint32_t smin = wave_bitonic_sort<false>(lmin);
+            uint32_t thi = __shfl(smax, kk - 1, 64), tlo = __shfl(smin, kk - 1, 64);
+            if (lane == 0) { wave_thr[0][wave] = thi; wave_thr[1][wave] = tlo; }
+            if (tid < 2) ncand[tid] = 0u;
+            for (int i = tid; i < 2 * 512; i += blockDim.x) (&omask[0][0])[i] = 0u;
+            __syncthreads();
+            uint32_t tau_hi = 0xFFFFu, tau_lo = 0u;
+            for (int w = 0; w < nw; w++) { tau_hi = min(tau_hi, wave_thr[0][w]); tau_lo = max(tau_lo, wave_thr[1][w]); }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (key[j] >= tau_hi) {
+                        uint32_t sl = atomicAdd(&ncand[0], 1u);
+                        if (sl < CAND_CAP) cand[0][sl] = (key[j] << 16) | (0xFFFFu - (uint32_t)(j0 + j));
+                    }
+                    if (key[j] <= tau_lo) {
+                        uint32_t sl = atomicAdd(&ncand[1], 1u);
+                        if (sl < CAND_CAP) cand[1][sl] = (key[j] << 16) | (uint32_t)(j0 + j);
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nh = ncand[0], nl = ncand[1];
+            use_hist = (nh > CAND_CAP) || (nl > CAND_CAP);   // block-uniform
+            if (!use_hist) {
+                // exact rank among the candidates: hi -- larger composite first; lo -- smaller composite first
+                for (uint32_t c = tid; c < nh; c += blockDim.x) {
+                    uint32_t me = cand[0][c];
+                    int rk = 0;
+                    for (uint32_t o = 0; o < nh; o++) rk += (cand[0][o] > me) ? 1 : 0;
+                    if (rk < k) { uint32_t idx = 0xFFFFu - (me & 0xFFFFu); atomicOr(&omask[0][idx >> 5], 1u << (idx & 31)); }
+                }
+                for (uint32_t c = tid; c < nl; c += blockDim.x) {
+                    uint32_t me = cand[1][c];
+                    int rk = 0;
+                    for (uint32_t o = 0; o < nl; o++) rk += (cand[1][o] < me) ? 1 : 0;
+                    if (rk < k) { uint32_t idx = me & 0xFFFFu; atomicOr(&omask[1][idx >> 5], 1u << (idx & 31)); }
+                }
+                __syncthreads();
+                if (active) {
+                    flag_hi = (omask[0][j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
+                    flag_lo = (omask[1][j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
+                }
+            }
         }
-        __syncthreads();
+        if (use_hist) {
+            // ---------------- level-1 histogram on the high key byte
+            for (int i = tid; i < 3 * 256; i += blockDim.x) (&hist[0][0])[i] = 0u;
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) atomicAdd(&hist[0][key[j] >> 8], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                find_crossing<true>(hist[0], k, &sh[0], &sh[1]);
+                find_crossing<false>(hist[0], k, &sh[2], &sh[3]);
+            }
+            __syncthreads();
+            const uint32_t bin_hi = (uint32_t)sh[0], bin_lo = (uint32_t)sh[2];
+            const int need_hi = sh[1], need_lo = sh[3];
+            // ---------------- level-2 histograms on the low key byte inside the two boundary bins
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((key[j] >> 8) == bin_hi) atomicAdd(&hist[1][key[j] & 255u], 1u);
+                    if ((key[j] >> 8) == bin_lo) atomicAdd(&hist[2][key[j] & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                find_crossing<true>(hist[1], need_hi, &sh[4], &sh[5]);
+                find_crossing<false>(hist[2], need_lo, &sh[6], &sh[7]);
+            }
+            __syncthreads();
+            const uint32_t thr_hi = (bin_hi << 8) | (uint32_t)sh[4];
+            const uint32_t thr_lo = (bin_lo << 8) | (uint32_t)sh[6];
+            const int take_hi = sh[5], take_lo = sh[7];
+            // ---------------- tie ranks (lower index first): exclusive scan of per-lane equal counts
+            unsigned long long eq = 0;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    eq += (key[j] == thr_hi) ? 1ull : 0ull;
+                    eq += (key[j] == thr_lo) ? (1ull << 32) : 0ull;
+                }
+            }
+            unsigned long long ex = block_excl_scan(eq, wave_tot, nullptr);
+            int rank_hi = (int)(ex & 0xFFFFFFFFull), rank_lo = (int)(ex >> 32);
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (key[j] < thr_lo) flag_lo |= 1u << j;
+                    else if (key[j] == thr_lo) { if (rank_lo < take_lo) flag_lo |= 1u << j; rank_lo++; }
+                    if (key[j] > thr_hi) flag_hi |= 1u << j;
+                    else if (key[j] == thr_hi) { if (rank_hi < take_hi) flag_hi |= 1u << j; rank_hi++; }
+                }
+            }
+        }
+        // every path has crossed a barrier since wave_sum was written
         float tot = 0.0f;
         for (int w = 0; w < nw; w++) tot += wave_sum[w];
         const float mean = tot / (float)len;
-        if (wave == 0) {
-            find_crossing<true>(hist[0], k, &sh[0], &sh[1]);
-            find_crossing<false>(hist[0], k, &sh[2], &sh[3]);
-        }
-        __syncthreads();
-        const uint32_t bin_hi = (uint32_t)sh[0], bin_lo = (uint32_t)sh[2];
-        const int need_hi = sh[1], need_lo = sh[3];
-        // ---------------- level-2 histograms on the low key byte inside the two boundary bins
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                if ((key[j] >> 8) == bin_hi) atomicAdd(&hist[1][key[j] & 255u], 1u);
-                if ((key[j] >> 8) == bin_lo) atomicAdd(&hist[2][key[j] & 255u], 1u);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            find_crossing<true>(hist[1], need_hi, &sh[4], &sh[5]);
-            find_crossing<false>(hist[2], need_lo, &sh[6], &sh[7]);
-        }
-        __syncthreads();
-        const uint32_t thr_hi = (bin_hi << 8) | (uint32_t)sh[4];
-        const uint32_t thr_lo = (bin_lo << 8) | (uint32_t)sh[6];
-        const int take_hi = sh[5], take_lo = sh[7];
-        // ---------------- tie ranks (lower index first): exclusive scan of per-lane equal counts
-        unsigned long long eq = 0;
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                eq += (key[j] == thr_hi) ? 1ull : 0ull;
-                eq += (key[j] == thr_lo) ? (1ull << 32) : 0ull;
-            }
-        }
-        unsigned long long ex = block_excl_scan(eq, wave_tot, nullptr);
-        int rank_hi = (int)(ex & 0xFFFFFFFFull), rank_lo = (int)(ex >> 32);
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                if (key[j] < thr_lo) flag_lo |= 1u << j;
-                else if (key[j] == thr_lo) { if (rank_lo < take_lo) flag_lo |= 1u << j; rank_lo++; }
-                if (key[j] > thr_hi) flag_hi |= 1u << j;
-                else if (key[j] == thr_hi) { if (rank_hi < take_hi) flag_hi |= 1u << j; rank_hi++; }
-            }
-        }
         // ---------------- output slots (sorted by index) and the sparse payload
         unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
         unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);

@@ -7,6 +7,12 @@
 // Rows and segments are described exactly as in compress_rows.hip.
 //   kind 0 (V):   row = (b, t), element j -> head j / seglen, channel j % seglen
 //   kind 1 (K^T): row = (bh, d), element j -> token j
+//
+// A workgroup owns RPB consecutive rows.  A lane keeps the same 16 columns for every row, so the 16 x r block of
+// the factor that varies along the row (P rows for V, Q rows for K^T) is loaded ONCE into registers and reused;
+// only the r-vector of the other factor changes per row.  Dense phase: one 32-byte store per lane per row.
+// Sparse phase (after a barrier): the few outlier positions of the block's rows are overwritten with
+// fp16(value + low-rank term).
 #include "common.h"
 
 namespace {
@@ -27,92 +33,118 @@ __device__ __forceinline__ void load_halfs(const uint16_t* p, float* f) {
     }
 }
 
-template <int BITS, int MODE, typename ST, int KIND, int RV>
-__global__ void decompress_rows_kernel(const uint32_t* __restrict__ code, const ST* __restrict__ scale,
-                                       const ST* __restrict__ mn, int rows_inner, int64_t outer_stride,
-                                       int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int len,
-                                       int group, const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, int r,
-                                       int T, int D, const uint16_t* __restrict__ oidx,
-                                       const uint16_t* __restrict__ oval, int k, uint16_t* __restrict__ out) {
+struct DGeom {
+    int rows_inner;
+    int64_t outer_stride, inner_stride;
+    int nseg, seglen;
+    int64_t seg_stride;
+    int len, group, T, D, r, k, rpb;
+    int64_t n_rows;
+};
+
+// RV: compile-time rank (4 / 8 / 16) or 0 for the generic runtime-rank path.
+// TB: launch bound bucket (256 / 512 / 1024 threads) -- the register budget for the 16 x r factor block.
+template <int BITS, int MODE, typename ST, int KIND, int RV, int TB>
+__global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __restrict__ code, const ST* __restrict__ scale,
+                                       const ST* __restrict__ mn, DGeom g, const uint16_t* __restrict__ P,
+                                       const uint16_t* __restrict__ Q, const uint16_t* __restrict__ oidx,
+                                       const uint16_t* __restrict__ oval, uint16_t* __restrict__ out) {
     constexpr int WPL = BITS / 2;
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
-    extern __shared__ uint32_t lds[];  // [len/32] mask words, then len uint16 values
-    uint32_t* lmask = lds;
-    uint16_t* lval = (uint16_t*)(lds + (len + 31) / 32);
-    const int64_t row = blockIdx.x;
+    constexpr int RVS = RV > 0 ? RV : 1;
     const int tid = threadIdx.x;
     const int j0 = tid * 16;
-    const bool active = j0 < len;
-    if (k > 0) {
-        for (int i = tid; i < (len + 31) / 32; i += blockDim.x) lmask[i] = 0u;
-        __syncthreads();
-        for (int i = tid; i < 2 * k; i += blockDim.x) {
-            uint32_t idx = oidx[row * (int64_t)(2 * k) + i];
-            atomicOr(&lmask[idx >> 5], 1u << (idx & 31));
-            lval[idx] = oval[row * (int64_t)(2 * k) + i];
-        }
-        __syncthreads();
-    }
-    if (!active) return;
-    const int seg = j0 / seglen, pos = j0 % seglen;
-    const int ro = (int)(row / rows_inner), ri = (int)(row % rows_inner);
-    const int64_t off = (int64_t)ro * outer_stride + (int64_t)ri * inner_stride + (int64_t)seg * seg_stride + pos;
-    const int64_t g = off / group;
-    const float s = ld_st<ST>(scale + g), m = ld_st<ST>(mn + g);
-    float f[16];
+    const bool active = j0 < g.len;
+    const int64_t row0 = (int64_t)blockIdx.x * g.rpb;
+    const int r = g.r;
+    // all rows of the block share the outer index (rpb divides rows_inner)
+    const int ro = (int)(row0 / g.rows_inner);
+    const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
+
+    // ---- the 16 x r factor block of this lane's columns (row-independent)
+    float gb[16][RVS];
+    const uint16_t* gbp = nullptr;
+    if (active && r > 0) {
+        if (KIND == 0) gbp = P + (((int64_t)ro * g.nseg + seg) * g.D + pos) * r;   // P[bh, pos.., :]
+        else gbp = Q + ((int64_t)ro * g.T + j0) * r;                                // Q[bh, j0.., :]
+        if (RV > 0) {
 #pragma unroll
-    for (int w = 0; w < WPL; w++) {
-        uint32_t word = code[off / CPW + w];
-#pragma unroll
-        for (int j = 0; j < CPW; j++) {
-            float d = dequant_one<MODE>((int)((word >> (BITS * j)) & MASK), s, m);
-            f[w * CPW + j] = (MODE == 0) ? d : hround(d);
+            for (int j = 0; j < 16; j++) load_halfs<RVS>(gbp + j * RVS, gb[j]);
         }
     }
-    if (k > 0) {
-        uint32_t mbits = (lmask[j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
+
+#pragma unroll 2
+    for (int ri = 0; ri < g.rpb; ri++) {
+        const int64_t row = row0 + ri;
+        if (row >= g.n_rows || !active) break;
+        const int rin = (int)(row % g.rows_inner);
+        const int64_t off = (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)seg * g.seg_stride + pos;
+        const int64_t gi = off / g.group;
+        const float s = ld_st<ST>(scale + gi), m = ld_st<ST>(mn + gi);
+        float f[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (mbits & (1u << j)) f[j] = h2f_bits(lval[j0 + j]);
-    }
-    if (r > 0) {
-        // fixed vector fv[r] and a contiguous 16 x r block gb
-        const uint16_t *fvp, *gbp;
-        if (KIND == 0) {  // row = (b, t): bh = b * nseg + seg; fixed = Q[bh, t, :], block = P[bh, pos.., :]
-            const int64_t bh = (int64_t)ro * nseg + seg;
-            fvp = Q + (bh * T + ri) * r;
-            gbp = P + (bh * D + pos) * r;
-        } else {          // row = (bh, d): fixed = P[bh, d, :], block = Q[bh, j0.., :]
-            fvp = P + ((int64_t)ro * D + ri) * r;
-            gbp = Q + ((int64_t)ro * T + j0) * r;
-        }
-        if (RV > 0) {   // r == RV: factor rows are RV contiguous fp16 -> vector loads, fully unrolled
-            float fv[RV > 0 ? RV : 1];
-            load_halfs<RV>(fvp, fv);
+        for (int w = 0; w < WPL; w++) {
+            uint32_t word = code[off / CPW + w];
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                float gv[RV > 0 ? RV : 1];
-                load_halfs<RV>(gbp + j * RV, gv);
-                float acc = 0.0f;
-#pragma unroll
-                for (int c = 0; c < RV; c++) acc = fmaf(fv[c], gv[c], acc);
-                f[j] += acc;
-            }
-        } else {
-            float fv[16];
-            for (int c = 0; c < r; c++) fv[c] = h2f_bits(fvp[c]);
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                float acc = 0.0f;
-                for (int c = 0; c < r; c++) acc = fmaf(fv[c], h2f_bits(gbp[j * r + c]), acc);
-                f[j] += acc;
+            for (int j = 0; j < CPW; j++) {
+                float d = dequant_one<MODE>((int)((word >> (BITS * j)) & MASK), s, m);
+                f[w * CPW + j] = (MODE == 0) ? d : hround(d);
             }
         }
+        if (r > 0) {
+            const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r      // Q[bh, t, :]
+                                              : P + ((int64_t)ro * g.D + rin) * r;                       // P[bh, d, :]
+            if (RV > 0) {
+                float fv[RVS];
+                load_halfs<RVS>(fvp, fv);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < RVS; c++) acc = fmaf(fv[c], gb[j][c], acc);
+                    f[j] += acc;
+                }
+            } else {
+                float fv[16];
+                for (int c = 0; c < r; c++) fv[c] = h2f_bits(fvp[c]);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    float acc = 0.0f;
+                    for (int c = 0; c < r; c++) acc = fmaf(fv[c], h2f_bits(gbp[j * r + c]), acc);
+                    f[j] += acc;
+                }
+            }
+        }
+        uint4* op = (uint4*)(out + off);
+        op[0] = pack8(f);
+        op[1] = pack8(f + 8);
     }
-    uint4* op = (uint4*)(out + off);
-    op[0] = pack8(f);
-    op[1] = pack8(f + 8);
+    if (g.k == 0) return;
+    // ---- sparse phase: overwrite the outlier positions of this block's rows
+    __syncthreads();
+    const int per_row = 2 * g.k;
+    const int n_ent = g.rpb * per_row;
+    for (int e = tid; e < n_ent; e += blockDim.x) {
+        const int64_t row = row0 + e / per_row;
+        if (row >= g.n_rows) break;
+        const int rin = (int)(row % g.rows_inner);
+        const uint32_t idx = oidx[row * per_row + e % per_row];
+        float v = h2f_bits(oval[row * per_row + e % per_row]);
+        const int sg = (int)idx / g.seglen, ps = (int)idx % g.seglen;
+        if (r > 0) {
+            int64_t bh, t, d;
+            if (KIND == 0) { bh = (int64_t)ro * g.nseg + sg; t = rin; d = ps; }
+            else { bh = ro; t = idx; d = rin; }
+            const uint16_t* qp = Q + (bh * g.T + t) * r;
+            const uint16_t* pp = P + (bh * g.D + d) * r;
+            float acc = 0.0f;
+            for (int c = 0; c < r; c++) acc = fmaf(h2f_bits(qp[c]), h2f_bits(pp[c]), acc);
+            v += acc;
+        }
+        const int64_t off = (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)sg * g.seg_stride + ps;
+        out[off] = f2h_bits(v);
+    }
 }
 
 }  // namespace
@@ -132,17 +164,21 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(r == 0 || (P && Q), "gear_decompress_rows: low-rank factors missing");
     GEAR_CHECK_ARG(k >= 0 && (k == 0 || (oidx && oval)), "gear_decompress_rows: outlier buffers missing");
     GEAR_CHECK_ARG(code && scale && mn && out, "gear_decompress_rows: null pointer");
+    GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
+    int rpb = 8;
+    while (rpb > 1 && rows_inner % rpb != 0) rpb >>= 1;
+    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
-    size_t shmem = k > 0 ? (size_t)((len + 31) / 32) * 4 + (size_t)len * 2 : 0;
     hipStream_t st = (hipStream_t)stream;
-    dim3 block(threads), grid((unsigned)n_rows);
-#define GO(B, M, STT, KD, RVV)                                                                                         \
-    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV>), grid, block, shmem, st, (const uint32_t*)code,          \
-                       (const STT*)scale, (const STT*)mn, rows_inner, outer_stride, inner_stride, nseg, seglen,         \
-                       seg_stride, (int)len, group, (const uint16_t*)P, (const uint16_t*)Q, r, T, D,                    \
-                       (const uint16_t*)oidx, (const uint16_t*)oval, k, (uint16_t*)out)
+    dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));
+#define GOT(B, M, STT, KD, RVV, TBB)                                                                                    \
+    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV, TBB>), grid, block, 0, st, (const uint32_t*)code,    \
+                       (const STT*)scale, (const STT*)mn, g, (const uint16_t*)P, (const uint16_t*)Q,                    \
+                       (const uint16_t*)oidx, (const uint16_t*)oval, (uint16_t*)out)
+#define GO(B, M, STT, KD, RVV) do { if (threads <= 256) GOT(B, M, STT, KD, RVV, 256); else if (threads <= 512) GOT(B, M, STT, KD, RVV, 512); \
+                                    else GOT(B, M, STT, KD, RVV, 1024); } while (0)
 #define GOR(B, M, STT, KD) do { if (r == 8) GO(B, M, STT, KD, 8); else if (r == 4) GO(B, M, STT, KD, 4); \
                                 else if (r == 16) GO(B, M, STT, KD, 16); else GO(B, M, STT, KD, 0); } while (0)
 #define GOK(B, M, STT) do { if (kind == 0) GOR(B, M, STT, 0); else GOR(B, M, STT, 1); } while (0)
@@ -158,6 +194,7 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
 #undef GOK
 #undef GOR
 #undef GO
+#undef GOT
     GEAR_CHECK_LAUNCH("gear_decompress_rows");
     return 0;
 }

@@ -132,6 +132,12 @@ int gear_decompress_rows(const void* code, const void* scale, const void* mn, in
                          int bits, int mode, int kind, const void* P, const void* Q, int r, int T, int D,
                          const void* oidx, const void* oval, int k, void* out, void* stream);
 
+/* ---- batched fp16 transpose [bh, R, C] -> [bh, C, R] ------------------------------------------------------------
+ * Replaces the caller-side key_states.transpose(2, 3).contiguous() of the attention hook
+ * (cuda_supported_gear/modeling_llamagear.py:268, :403).  R, C multiples of 8.
+ */
+int gear_transpose_f16(const void* x, int64_t bh, int R, int C, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
