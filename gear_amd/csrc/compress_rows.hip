@@ -12,6 +12,9 @@
 //
 // Outputs per row: packed codes, scale, mn, optional error (0 at outlier positions), and the sparse part
 // (column index within the row as uint16 + original fp16 value, sorted by index; first k = smallest side).
+#include <math.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -25,7 +28,11 @@ struct RowGeom {
 };
 
 __device__ __forceinline__ uint32_t sort_key(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit)
+    if (hbits == 0x8000u) hbits = 0u;  // -0 == +0 (the oracle / torch.topk compare values)
     return (hbits & 0x8000u) ? (~hbits & 0xFFFFu) : (hbits | 0x8000u);
+}
+__device__ __forceinline__ uint32_t key_to_bits(uint32_t key) {  // inverse of sort_key
+    return (key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu);
 }
 
 // inclusive scan over the block of a 64-bit packed counter (fields never overflow into each other)
@@ -351,6 +358,309 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     }
 }
 
+
+// =====================================================================================================
+// Wave-per-row variant (the fast path): ONE wave owns the whole row.  Lane l holds CPL chunks of 16 consecutive
+// elements (chunk c = elements [1024 c + 16 l, +16)), so global accesses stay fully coalesced, every reduction is a
+// DPP / shuffle butterfly, and there is no workgroup barrier on the critical path (the block IS the wave): far more
+// rows are in flight per CU than with the 4-wave workgroup kernel, whose chain of barriers made it latency-bound.
+// Selection: tau_hi = k-th largest of the 64 per-lane maxima (one bitonic sort in registers) -- at least k elements
+// are >= tau_hi; the few elements passing the threshold are ranked exactly in LDS ((value desc, index asc) for the
+// large side, (value asc, index asc) for the small side) and written out sorted by index.
+// =====================================================================================================
+template <int BITS, int MODE>
+__device__ __forceinline__ int quant_fast(float v, float mn, float scale, float inv, int levels) {
+    if (scale == 0.0f) return 0;
+    if (MODE == 0) {
+        float t1 = hround(v - mn);
+        float c = hround(div_rn(t1, scale));
+        c = fminf(fmaxf(c, 0.0f), (float)levels);
+        return (int)rintf(c);
+    } else {
+        // (v - mn) / scale with an IEEE-exact result: multiply by the reciprocal, and redo the division only when the
+        // approximate quotient is within 1e-5 of a rounding tie (x.5) -- the only place the two can round differently.
+        float t = v - mn;
+        float c = t * inv;
+        float r = rintf(c);
+        if (fabsf(fabsf(c - r) - 0.5f) < 1e-5f) {
+            c = div_rn(t, scale);
+            r = rintf(c);
+        }
+        r = fminf(fmaxf(r, 0.0f), (float)levels);
+        return (int)r;
+    }
+}
+
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t x, uint32_t* total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    *total = __shfl(inc, 63, 64);
+    return inc - x;
+}
+
+// Exact selection without the survivor buffer (rows where more than CAND_CAP elements tie with / exceed the
+// threshold, e.g. constant rows): bisection on the 16-bit key for the k-th largest (LARGE) / smallest value, then
+// ties in index order.  Returns per-chunk 16-bit flags and writes the (index-sorted) payload.  Slow, rare, exact.
+template <int CPL, bool LARGE>
+__device__ __forceinline__ void select_bisect(const float (&v)[CPL][16], const bool (&act)[CPL], int k, uint32_t* flags,
+                                               uint16_t* oi, uint16_t* ov) {
+    const int lane = threadIdx.x & 63;
+    auto count = [&](uint32_t thr, bool strict) {
+        uint32_t n = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+            if (act[c]) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    uint32_t key = sort_key(f2h_bits(v[c][j]));
+                    bool hit = LARGE ? (strict ? key > thr : key >= thr) : (strict ? key < thr : key <= thr);
+                    n += hit ? 1u : 0u;
+                }
+            }
+        return wave_sum_u32(n);
+    };
+    uint32_t lo_b = 0u, hi_b = 0xFFFFu;
+    for (int it = 0; it < 16; it++) {
+        if (LARGE) {   // largest thr with count(key >= thr) >= k
+            uint32_t mid = (lo_b + hi_b + 1u) >> 1;
+            if (count(mid, false) >= (uint32_t)k) lo_b = mid; else hi_b = mid - 1u;
+        } else {       // smallest thr with count(key <= thr) >= k
+            uint32_t mid = (lo_b + hi_b) >> 1;
+            if (count(mid, false) >= (uint32_t)k) hi_b = mid; else lo_b = mid + 1u;
+        }
+    }
+    const uint32_t thr = LARGE ? lo_b : hi_b;
+    const int take = k - (int)count(thr, true);
+    uint32_t eq_base = 0u, slot_base = 0u;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        uint32_t key[16], neq = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            key[j] = sort_key(f2h_bits(v[c][j]));
+            neq += (act[c] && key[j] == thr) ? 1u : 0u;
+        }
+        uint32_t tot_eq;
+        int rank = (int)(eq_base + wave_excl_scan_u32(neq, &tot_eq));
+        eq_base += tot_eq;
+        uint32_t f = 0u;
+        if (act[c]) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                bool beyond = LARGE ? key[j] > thr : key[j] < thr;
+                if (beyond) f |= 1u << j;
+                else if (key[j] == thr) { if (rank < take) f |= 1u << j; rank++; }
+            }
+        }
+        flags[c] = f;
+        uint32_t tot_f;
+        int slot = (int)(slot_base + wave_excl_scan_u32((uint32_t)__popc(f), &tot_f));
+        slot_base += tot_f;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (f & (1u << j)) {
+                if (slot < k) { oi[slot] = (uint16_t)(c * 1024 + lane * 16 + j); ov[slot] = f2h_bits(v[c][j]); }
+                slot++;
+            }
+    }
+}
+
+template <int BITS, int MODE, typename ST, int CPL>
+__global__ __launch_bounds__(64) void compress_rows_wave_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len,
+                                                                 int group, int k, uint32_t* __restrict__ code,
+                                                                 ST* __restrict__ scale, ST* __restrict__ mn,
+                                                                 uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
+                                                                 uint16_t* __restrict__ oval, float* __restrict__ omean) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int WPL = BITS / 2;
+    constexpr int CPW = 32 / BITS;
+    __shared__ uint32_t cand[2][CAND_CAP];
+    __shared__ uint32_t sel[2][CAND_CAP];
+    __shared__ uint32_t omask[2][32 * CPL];   // 1024 * CPL bits per side
+    __shared__ uint32_t ncand[2];
+
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t row_base = (r / gm.rows_inner) * gm.outer_stride + (r % gm.rows_inner) * gm.inner_stride;
+    float v[CPL][16];
+    int64_t off[CPL];
+    bool act[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int j0 = c * 1024 + lane * 16;
+        act[c] = j0 < len;
+        const int jj = act[c] ? j0 : 0;
+        off[c] = row_base + (int64_t)(jj / gm.seglen) * gm.seg_stride + jj % gm.seglen;
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        if (act[c]) {
+            const uint4* p = (const uint4*)(x + off[c]);
+            a = p[0];
+            b = p[1];
+        }
+        unpack8(a, v[c]);
+        unpack8(b, v[c] + 8);
+    }
+    uint32_t fl[CPL];   // bits 0-15: large-side outlier flags of chunk c, bits 16-31: small side
+#pragma unroll
+    for (int c = 0; c < CPL; c++) fl[c] = 0u;
+
+    if (k > 0) {
+        float s = 0.0f, lmax = -INFINITY, lmin = INFINITY;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            if (act[c]) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    s += v[c][j];
+                    lmax = fmaxf(lmax, v[c][j]);
+                    lmin = fminf(lmin, v[c][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float mean = s / (float)len;
+        const uint32_t kmax = act[0] ? sort_key(f2h_bits(lmax)) : 0u;
+        const uint32_t kmin = act[0] ? sort_key(f2h_bits(lmin)) : 0xFFFFu;
+        const uint32_t smax = wave_bitonic_sort<true>(kmax);
+        const uint32_t smin = wave_bitonic_sort<false>(kmin);
+        const uint32_t tau_hi = __shfl(smax, k - 1, 64), tau_lo = __shfl(smin, k - 1, 64);
+        const float thi = h2f_bits((uint16_t)key_to_bits(tau_hi)), tlo = h2f_bits((uint16_t)key_to_bits(tau_lo));
+        if (lane < 2) ncand[lane] = 0u;
+        for (int i = lane; i < 2 * 32 * CPL; i += 64) (&omask[0][0])[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            if (act[c]) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float vv = v[c][j];
+                    if (vv >= thi) {
+                        uint32_t sl = atomicAdd(&ncand[0], 1u);
+                        if (sl < CAND_CAP) cand[0][sl] = (sort_key(f2h_bits(vv)) << 16) | (0xFFFFu - (uint32_t)(c * 1024 + lane * 16 + j));
+                    }
+                    if (vv <= tlo) {
+                        uint32_t sl = atomicAdd(&ncand[1], 1u);
+                        if (sl < CAND_CAP) cand[1][sl] = (sort_key(f2h_bits(vv)) << 16) | (uint32_t)(c * 1024 + lane * 16 + j);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nh = min(ncand[0], (uint32_t)CAND_CAP), nl = min(ncand[1], (uint32_t)CAND_CAP);
+        const bool overflow = (ncand[0] > CAND_CAP) || (ncand[1] > CAND_CAP);
+        uint16_t* oi = oidx + r * (int64_t)(2 * k);
+        uint16_t* ov = oval + r * (int64_t)(2 * k);
+        uint32_t fhi[CPL], flo[CPL];
+        if (overflow) {
+            // more than CAND_CAP elements reach the threshold (massive duplicates): exact bisection path
+            select_bisect<CPL, true>(v, act, k, fhi, oi + k, ov + k);
+            select_bisect<CPL, false>(v, act, k, flo, oi, ov);
+        } else {
+            // pass 1: exact rank inside the survivor set
+            for (uint32_t ci = lane; ci < nh; ci += 64) {
+                const uint32_t me = cand[0][ci];
+                int rk = 0;
+                for (uint32_t o = 0; o < nh; o++) rk += (cand[0][o] > me) ? 1 : 0;
+                sel[0][ci] = (rk < k) ? 1u : 0u;
+                if (rk < k) { uint32_t idx = 0xFFFFu - (me & 0xFFFFu); atomicOr(&omask[0][idx >> 5], 1u << (idx & 31)); }
+            }
+            for (uint32_t ci = lane; ci < nl; ci += 64) {
+                const uint32_t me = cand[1][ci];
+                int rk = 0;
+                for (uint32_t o = 0; o < nl; o++) rk += (cand[1][o] < me) ? 1 : 0;
+                sel[1][ci] = (rk < k) ? 1u : 0u;
+                if (rk < k) { uint32_t idx = me & 0xFFFFu; atomicOr(&omask[1][idx >> 5], 1u << (idx & 31)); }
+            }
+            __syncthreads();
+            // pass 2: output slot = number of selected survivors with a smaller index; payload sorted by index
+            for (uint32_t ci = lane; ci < nh; ci += 64) {
+                if (!sel[0][ci]) continue;
+                const uint32_t me = cand[0][ci], idx = 0xFFFFu - (me & 0xFFFFu);
+                int sl = 0;
+                for (uint32_t o = 0; o < nh; o++) sl += (sel[0][o] && (0xFFFFu - (cand[0][o] & 0xFFFFu)) < idx) ? 1 : 0;
+                if (sl < k) { oi[k + sl] = (uint16_t)idx; ov[k + sl] = (uint16_t)key_to_bits(me >> 16); }
+            }
+            for (uint32_t ci = lane; ci < nl; ci += 64) {
+                if (!sel[1][ci]) continue;
+                const uint32_t me = cand[1][ci], idx = me & 0xFFFFu;
+                int sl = 0;
+                for (uint32_t o = 0; o < nl; o++) sl += (sel[1][o] && (cand[1][o] & 0xFFFFu) < idx) ? 1 : 0;
+                if (sl < k) { oi[sl] = (uint16_t)idx; ov[sl] = (uint16_t)key_to_bits(me >> 16); }
+            }
+        }
+        if (lane == 0 && omean) omean[r] = mean;
+        const float fill = (MODE == 0) ? hround(mean) : mean;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int j0 = c * 1024 + lane * 16;
+            const uint32_t fh = overflow ? fhi[c] : ((omask[0][j0 >> 5] >> (j0 & 31)) & 0xFFFFu);
+            const uint32_t fw = overflow ? flo[c] : ((omask[1][j0 >> 5] >> (j0 & 31)) & 0xFFFFu);
+            fl[c] = act[c] ? (fh | (fw << 16)) : 0u;
+            const uint32_t any = (fl[c] | (fl[c] >> 16)) & 0xFFFFu;
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (any & (1u << j)) v[c][j] = fill;
+        }
+    }
+
+    const int lanes_per_group = group / 16;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        float lo = v[c][0], hi = v[c][0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) {
+            lo = fminf(lo, v[c][j]);
+            hi = fmaxf(hi, v[c][j]);
+        }
+        for (int m = 1; m < lanes_per_group; m <<= 1) {
+            lo = fminf(lo, __shfl_xor(lo, m, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+        }
+        if (!act[c]) continue;
+        QuantParams<MODE> qp = make_qparams<MODE>(lo, hi, LEVELS);
+        const float inv = (qp.scale != 0.0f) ? div_rn(1.0f, qp.scale) : 0.0f;
+        uint32_t words[WPL];
+#pragma unroll
+        for (int w = 0; w < WPL; w++) words[w] = 0u;
+        float e[16];
+        const uint32_t outl = (fl[c] | (fl[c] >> 16)) & 0xFFFFu;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            int q = quant_fast<BITS, MODE>(v[c][j], qp.mn, qp.scale, inv, LEVELS);
+            words[j / CPW] |= (uint32_t)q << (BITS * (j % CPW));
+            float d = (MODE == 0) ? dequant_one<0>(q, qp.scale, qp.mn) : hround(dequant_one<1>(q, qp.scale, qp.mn));
+            e[j] = (outl & (1u << j)) ? 0.0f : (v[c][j] - d);
+        }
+        uint32_t* cp = code + off[c] / CPW;
+#pragma unroll
+        for (int w = 0; w < WPL; w++) cp[w] = words[w];
+        if ((lane & (lanes_per_group - 1)) == 0) {
+            st_st<ST>(scale + off[c] / group, qp.scale);
+            st_st<ST>(mn + off[c] / group, qp.mn);
+        }
+        if (err) {
+            uint4* ep = (uint4*)(err + off[c]);
+            ep[0] = pack8(e);
+            ep[1] = pack8(e + 8);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride,
@@ -372,6 +682,30 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
+    if (k <= 64 && len <= 8192 && len >= 16 * (int64_t)k && !getenv("GEAR_ROWS_WG_KERNEL")) {
+        // fast path: one wave per row
+        const int cpl = len <= 1024 ? 1 : (len <= 2048 ? 2 : (len <= 4096 ? 4 : 8));
+        dim3 wb(64), wg((unsigned)n_rows);
+#define GOW(B, M, STT, CP)                                                                                                \
+    hipLaunchKernelGGL((compress_rows_wave_kernel<B, M, STT, CP>), wg, wb, 0, st, (const uint16_t*)x, gm, (int)len, group, \
+                       k, (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
+                       (float*)omean)
+#define GOC(B, M, STT) do { if (cpl == 1) GOW(B, M, STT, 1); else if (cpl == 2) GOW(B, M, STT, 2); \
+                            else if (cpl == 4) GOW(B, M, STT, 4); else GOW(B, M, STT, 8); } while (0)
+        if (mode == 0) {
+            if (bits == 2) GOC(2, 0, uint16_t);
+            else if (bits == 4) GOC(4, 0, uint16_t);
+            else GOC(8, 0, uint16_t);
+        } else {
+            if (bits == 2) GOC(2, 1, float);
+            else if (bits == 4) GOC(4, 1, float);
+            else GOC(8, 1, float);
+        }
+#undef GOC
+#undef GOW
+        GEAR_CHECK_LAUNCH("gear_compress_rows(wave)");
+        return 0;
+    }
     dim3 block(threads), grid((unsigned)n_rows);
 #define GO(B, M, STT)                                                                                                  \
     hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, 0, st, (const uint16_t*)x, gm, (int)len, group, k, \
