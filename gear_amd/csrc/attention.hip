@@ -1,0 +1,409 @@
+// attention.hip -- single-token decode attention straight over the compressed GEAR cache (gfx950, head_dim 128).
+//
+//   scores[t] = q . Khat[t,:] / sqrt(D)          Khat = dequant(K codes) + Qk Pk^T, outlier entries = stored value + Qk Pk^T
+//   out[d]    = softmax(scores) . Vhat[:,d]      Vhat likewise; an fp16 window of recent tokens (the reference's residual
+//                                                buffer, modeling_llamagear.py:256-261, :329-333) joins the same softmax.
+//
+// Replaces, in ONE pass over the packed bytes: cuda_bmm_fA_qB_outer for K and V (cuda_supported_gear/quant/matmul.py:178),
+// the low-rank bmm chains of matmul_withlrap (modeling_llamagear.py:64-108), the fp32 softmax (:313) and the
+// [B,H,1,T] score round trip between them -- plus the sparse outlier term the reference's fused path never stores.
+//
+// Flash-decoding split: grid (splits, B*Hq).  A workgroup owns a chunk of TC compressed tokens of one query head:
+//   1. K side, lanes along tokens (one packed word = 32/bits tokens of one channel), 4 row-subsets over channels,
+//      partial sums merged in LDS;  + Qk[t,:] . (Pk^T q);  + sum over K outliers in the chunk q[d] (val - dequant)
+//   2. chunk-local softmax statistics (m, l), p = exp(s - m)
+//   3. V side, lanes along (token-subset, packed word = 32/bits channels);  w = Qv^T p for the low-rank term;
+//      + V outliers of the chunk's tokens that fall into this head
+// A second kernel merges the splits and the fp16 window and applies Pv w.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int AD = 128;       // head_dim
+constexpr int TC_MAX = 2048;  // chunk of compressed tokens per workgroup
+
+struct AttnArgs {
+    const uint16_t* q;       // [B*Hq, 128]
+    // K payload (channel-major)
+    const uint32_t* kcode;   // [B*Hkv, 128, ldk] words
+    const void* kscale;      // [B*Hkv, 128, lsk]
+    const void* kmn;
+    const uint16_t* kP;      // [B*Hkv, 128, rk]  channel-side factor
+    const uint16_t* kQ;      // [B*Hkv, Tf, rk]   token-side factor (Tf = token capacity of the factor tensor)
+    const uint16_t* koidx;   // [B*Hkv, 128, 2*kk] token indices (each half sorted ascending)
+    const uint16_t* koval;
+    // V payload (token-major)
+    const uint32_t* vcode;   // [B*Hkv, Tcap, 128/CPW]
+    const void* vscale;      // [B*Hkv, Tcap, 128/g]
+    const void* vmn;
+    const uint16_t* vP;      // [B*Hkv, 128, rv]
+    const uint16_t* vQ;      // [B*Hkv, Tf, rv]
+    const uint16_t* voidx;   // [B, Tcap, 2*kv] column index hkv*128 + d (each half sorted ascending)
+    const uint16_t* voval;
+    int B, Hq, Hkv, T;       // T = number of compressed tokens
+    int ldk, lsk;            // K code / scale row pitch
+    int tcap_v, tf_k, tf_v;  // token capacity (row count) of V tensors / factor tensors
+    int group, rk, rv, kk, kv;
+    int tc, splits;
+    float qscale;
+    float* part_o;           // [B*Hq, splits, 128]
+    float* part_w;           // [B*Hq, splits, 16]
+    float* part_ml;          // [B*Hq, splits, 2]
+};
+
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// first index i in [0, n) with a[i] >= key (a ascending)
+__device__ __forceinline__ int lower_bound_u16(const uint16_t* a, int n, int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((int)a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int BITS, typename ST>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    constexpr int NWV = AD / CPW;  // packed words per V token row
+    __shared__ float qs[AD];
+    __shared__ float u[16];
+    __shared__ float s[TC_MAX];
+    __shared__ float oacc[AD];
+    __shared__ float wacc[16];
+    __shared__ float red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int split = blockIdx.x;
+    const int64_t bhq = blockIdx.y;
+    const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
+    const int n_rep = a.Hq / a.Hkv;
+    const int hkv = hq / n_rep;
+    const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    const int t0 = split * a.tc;
+    const int tn = min(a.tc, a.T - t0);  // tokens in this chunk (> 0 by construction)
+    const ST* kscale = (const ST*)a.kscale;
+    const ST* kmn = (const ST*)a.kmn;
+    const ST* vscale = (const ST*)a.vscale;
+    const ST* vmn = (const ST*)a.vmn;
+
+    if (tid < AD) {
+        qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
+        oacc[tid] = 0.0f;
+    }
+    if (tid < 16) wacc[tid] = 0.0f;
+    for (int i = tid; i < a.tc; i += 256) s[i] = 0.0f;
+    __syncthreads();
+    if (tid < a.rk) {  // u = Pk^T q
+        float acc = 0.0f;
+        for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(a.kP[(bhk * AD + d) * a.rk + tid]), acc);
+        u[tid] = acc;
+    }
+    // ------------------------------------------------------------------ 1. K side
+    {
+        const int nw = (tn + CPW - 1) / CPW;        // words in the chunk
+        const int w0 = t0 / CPW;                    // t0 is a multiple of CPW
+        const int NT = 64;                          // token-word lanes per row-subset
+        const int tl = tid & (NT - 1), dsub = tid >> 6;  // 4 row-subsets (one per wave)
+        for (int wb = 0; wb < nw; wb += NT) {
+            const int w = wb + tl;
+            float acc[CPW];
+#pragma unroll
+            for (int j = 0; j < CPW; j++) acc[j] = 0.0f;
+            float zacc = 0.0f;
+            if (w < nw) {
+                const int g = ((w0 + w) * CPW) / a.group;
+                for (int d = dsub; d < AD; d += 4) {
+                    const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + w0 + w];
+                    const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
+                    const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
+                    const float qd = qs[d];
+                    const float sa = sc * qd;
+                    zacc = fmaf(mnv, qd, zacc);
+#pragma unroll
+                    for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((word >> (BITS * j)) & MASK), acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < CPW; j++) {
+                    int t = w * CPW + j;
+                    if (t < tn) atomicAdd(&s[t], acc[j] + zacc);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // low-rank: s[t] += Qk[t,:] . u
+    if (a.rk > 0) {
+        for (int t = tid; t < tn; t += 256) {
+            const uint16_t* qp = a.kQ + (bhk * a.tf_k + t0 + t) * (int64_t)a.rk;
+            float acc = 0.0f;
+            for (int c = 0; c < a.rk; c++) acc = fmaf(h2f_bits(qp[c]), u[c], acc);
+            s[t] += acc;
+        }
+    }
+    __syncthreads();
+    // K outliers inside the chunk: s[t] += q[d] (val - dequant(t, d))
+    if (a.kk > 0 && tid < AD) {
+        const int d = tid;
+        const float qd = qs[d];
+        for (int side = 0; side < 2; side++) {
+            const uint16_t* oi = a.koidx + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
+            const uint16_t* ov = a.koval + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
+            for (int i = lower_bound_u16(oi, a.kk, t0); i < a.kk; i++) {
+                const int t = oi[i];
+                if (t >= t0 + tn) break;
+                const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + t / CPW];
+                const int g = t / a.group;
+                const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
+                const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
+                const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & MASK), mnv);
+                atomicAdd(&s[t - t0], qd * (h2f_bits(ov[i]) - deq));
+            }
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ 2. chunk softmax statistics
+    float lm = -INFINITY;
+    for (int t = tid; t < tn; t += 256) lm = fmaxf(lm, s[t]);
+    const float m = block_reduce_max(lm, red);
+    float ls = 0.0f;
+    for (int t = tid; t < tn; t += 256) {
+        float p = __expf(s[t] - m);
+        s[t] = p;
+        ls += p;
+    }
+    const float l = block_reduce_sum(ls, red);  // (contains the barrier that publishes s[])
+    // ------------------------------------------------------------------ 3. V side
+    {
+        const int wv = tid % NWV, rsub = tid / NWV;
+        constexpr int NRS = 256 / NWV;  // row-subsets
+        float acc[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; j++) acc[j] = 0.0f;
+        float zacc = 0.0f;
+        const int gv = (wv * CPW) / a.group;
+        const int ngv = AD / a.group;
+        for (int t = rsub; t < tn; t += NRS) {
+            const int64_t row = bhk * a.tcap_v + t0 + t;
+            const uint32_t word = a.vcode[row * NWV + wv];
+            const float sc = ld_st<ST>(vscale + row * ngv + gv);
+            const float mnv = ld_st<ST>(vmn + row * ngv + gv);
+            const float p = s[t];
+            const float sa = sc * p;
+            zacc = fmaf(mnv, p, zacc);
+#pragma unroll
+            for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((word >> (BITS * j)) & MASK), acc[j]);
+        }
+        // lanes with equal wv inside a wave differ in the bits above log2(NWV)
+#pragma unroll
+        for (int j = 0; j < CPW; j++) {
+            float v = acc[j] + zacc;
+            for (int msk = NWV; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
+            if (lane < NWV) atomicAdd(&oacc[wv * CPW + j], v);
+        }
+    }
+    // w = Qv^T p (low-rank term of V, applied after the merge)
+    if (a.rv > 0) {
+        float wl[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) wl[c] = 0.0f;
+        for (int t = tid; t < tn; t += 256) {
+            const uint16_t* qp = a.vQ + (bhk * a.tf_v + t0 + t) * (int64_t)a.rv;
+            const float p = s[t];
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                if (c < a.rv) wl[c] = fmaf(p, h2f_bits(qp[c]), wl[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (c < a.rv) {
+                float v = wl[c];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                if (lane == 0) atomicAdd(&wacc[c], v);
+            }
+        }
+    }
+    // V outliers of the chunk's tokens that fall into this head's 128 columns
+    if (a.kv > 0) {
+        const int c_lo = hkv * AD, c_hi = c_lo + AD;
+        const int ngv = AD / a.group;
+        for (int t = tid; t < tn; t += 256) {
+            const float p = s[t];
+            const int64_t orow = (int64_t)b * a.tcap_v + t0 + t;
+            const int64_t row = bhk * a.tcap_v + t0 + t;
+            for (int side = 0; side < 2; side++) {
+                const uint16_t* oi = a.voidx + (orow * 2 + side) * a.kv;
+                const uint16_t* ov = a.voval + (orow * 2 + side) * a.kv;
+                for (int i = lower_bound_u16(oi, a.kv, c_lo); i < a.kv; i++) {
+                    const int col = oi[i];
+                    if (col >= c_hi) break;
+                    const int d = col - c_lo;
+                    const uint32_t word = a.vcode[row * NWV + d / CPW];
+                    const float sc = ld_st<ST>(vscale + row * ngv + d / a.group);
+                    const float mnv = ld_st<ST>(vmn + row * ngv + d / a.group);
+                    const float deq = fmaf(sc, (float)((word >> (BITS * (d % CPW))) & MASK), mnv);
+                    atomicAdd(&oacc[d], p * (h2f_bits(ov[i]) - deq));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t po = bhq * a.splits + split;
+    if (tid < AD) a.part_o[po * AD + tid] = oacc[tid];
+    if (tid < 16) a.part_w[po * 16 + tid] = wacc[tid];
+    if (tid == 0) {
+        a.part_ml[po * 2] = m;
+        a.part_ml[po * 2 + 1] = l;
+    }
+}
+
+// merge the splits + the fp16 window, apply the V low-rank factor, normalise.  grid (B*Hq), block 128.
+__global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
+                                                                 const uint16_t* __restrict__ vwin, int W,
+                                                                 uint16_t* __restrict__ out, float* __restrict__ lse) {
+    __shared__ float qs[AD];
+    __shared__ float sw[64];
+    __shared__ float wsum[16];
+    __shared__ float coef[64 + 64];  // per split, then per window token
+    __shared__ float stat[2];
+    const int tid = threadIdx.x;
+    const int64_t bhq = blockIdx.x;
+    const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    const int ns = a.T > 0 ? a.splits : 0;
+    qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
+    __syncthreads();
+    if (tid < W) {
+        const uint16_t* kr = kwin + (bhk * W + tid) * (int64_t)AD;
+        float acc = 0.0f;
+        for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(kr[d]), acc);
+        sw[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float M = -INFINITY;
+        for (int i = 0; i < ns; i++) M = fmaxf(M, a.part_ml[(bhq * a.splits + i) * 2]);
+        for (int j = 0; j < W; j++) M = fmaxf(M, sw[j]);
+        float Lsum = 0.0f;
+        for (int i = 0; i < ns; i++) {
+            float c = __expf(a.part_ml[(bhq * a.splits + i) * 2] - M);
+            coef[i] = c;
+            Lsum += c * a.part_ml[(bhq * a.splits + i) * 2 + 1];
+        }
+        for (int j = 0; j < W; j++) {
+            float c = __expf(sw[j] - M);
+            coef[64 + j] = c;
+            Lsum += c;
+        }
+        stat[0] = M;
+        stat[1] = Lsum;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float acc = 0.0f;
+        for (int i = 0; i < ns; i++) acc = fmaf(coef[i], a.part_w[(bhq * a.splits + i) * 16 + tid], acc);
+        wsum[tid] = acc;
+    }
+    __syncthreads();
+    float o = 0.0f;
+    for (int i = 0; i < ns; i++) o = fmaf(coef[i], a.part_o[(bhq * a.splits + i) * AD + tid], o);
+    for (int c = 0; c < a.rv && ns > 0; c++) o = fmaf(h2f_bits(a.vP[(bhk * AD + tid) * a.rv + c]), wsum[c], o);
+    for (int j = 0; j < W; j++) o = fmaf(coef[64 + j], h2f_bits(vwin[(bhk * W + j) * (int64_t)AD + tid]), o);
+    out[bhq * AD + tid] = f2h_bits(o / stat[1]);
+    if (lse && tid == 0) lse[bhq] = stat[0] + logf(stat[1]);
+}
+
+int plan_splits(int T, int bits, int64_t bhq, int* tc_out) {
+    if (T <= 0) { *tc_out = 64; return 1; }
+    // enough workgroups to cover the chip a few times over, chunks a multiple of 64 tokens
+    int splits = 1;
+    while (splits < 64 && (int64_t)splits * bhq < 1024 && T / (splits * 2) >= 128) splits *= 2;
+    int tc = ((T + splits - 1) / splits + 63) / 64 * 64;
+    if (tc > TC_MAX) tc = TC_MAX;
+    splits = (T + tc - 1) / tc;
+    *tc_out = tc;
+    (void)bits;
+    return splits;
+}
+
+}  // namespace
+
+extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
+    int tc;
+    int splits = plan_splits(T, bits, (int64_t)B * Hq, &tc);
+    return (size_t)B * Hq * splits * (AD + 16 + 2) * sizeof(float) + 256;
+}
+
+extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                                const void* kQ, const void* koidx, const void* koval, const void* vcode,
+                                const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
+                                const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T,
+                                int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
+                                int rk, int rv, int kk, int kv, float qscale, void* out, void* lse, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    GEAR_CHECK_ARG(D == AD, "gear_attn_decode: head_dim must be 128 (got %d)", D);
+    GEAR_CHECK_ARG(bits == 2 || bits == 4, "gear_attn_decode: bits must be 2 or 4 (got %d)", bits);
+    GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_attn_decode: bad mode %d", mode);
+    GEAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "gear_attn_decode: bad head counts %d / %d", Hq, Hkv);
+    GEAR_CHECK_ARG(T >= 0 && W >= 0 && W <= 64 && T + W > 0, "gear_attn_decode: need 0 <= W <= 64 and T + W > 0");
+    GEAR_CHECK_ARG(T <= 64 * TC_MAX, "gear_attn_decode: at most %d compressed tokens", 64 * TC_MAX);
+    GEAR_CHECK_ARG((int64_t)B * Hq <= 65535, "gear_attn_decode: too many (batch, head) pairs");
+    const int cpw = 32 / bits;
+    GEAR_CHECK_ARG(group % cpw == 0 && AD % group == 0 && (T == 0 || T % cpw == 0),
+                   "gear_attn_decode: group %d / T %d incompatible with %d-bit packing", group, T, bits);
+    GEAR_CHECK_ARG(rk >= 0 && rk <= 16 && rv >= 0 && rv <= 16, "gear_attn_decode: ranks must be <= 16");
+    GEAR_CHECK_ARG(q && out && workspace, "gear_attn_decode: null pointer");
+    GEAR_CHECK_ARG(T == 0 || (kcode && kscale && kmn && vcode && vscale && vmn), "gear_attn_decode: payload missing");
+    GEAR_CHECK_ARG(W == 0 || (kwin && vwin), "gear_attn_decode: window missing");
+    GEAR_CHECK_ARG(workspace_bytes >= gear_attn_decode_workspace(B, Hq, T, bits), "gear_attn_decode: workspace too small");
+    AttnArgs a;
+    a.q = (const uint16_t*)q;
+    a.kcode = (const uint32_t*)kcode; a.kscale = kscale; a.kmn = kmn;
+    a.kP = (const uint16_t*)kP; a.kQ = (const uint16_t*)kQ; a.koidx = (const uint16_t*)koidx; a.koval = (const uint16_t*)koval;
+    a.vcode = (const uint32_t*)vcode; a.vscale = vscale; a.vmn = vmn;
+    a.vP = (const uint16_t*)vP; a.vQ = (const uint16_t*)vQ; a.voidx = (const uint16_t*)voidx; a.voval = (const uint16_t*)voval;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.T = T;
+    a.ldk = ldk; a.lsk = lsk; a.tcap_v = tcap_v; a.tf_k = tf_k; a.tf_v = tf_v;
+    a.group = group; a.rk = (kP && kQ) ? rk : 0; a.rv = (vP && vQ) ? rv : 0;
+    a.kk = (koidx && koval) ? kk : 0; a.kv = (voidx && voval) ? kv : 0;
+    a.qscale = qscale;
+    a.splits = plan_splits(T, bits, (int64_t)B * Hq, &a.tc);
+    float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    a.part_o = ws;
+    a.part_w = a.part_o + (size_t)B * Hq * a.splits * AD;
+    a.part_ml = a.part_w + (size_t)B * Hq * a.splits * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (T > 0) {
+        dim3 grid(a.splits, (unsigned)(B * Hq));
+#define GO(BI, STT) hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a)
+        if (mode == 0) { if (bits == 2) GO(2, uint16_t); else GO(4, uint16_t); }
+        else           { if (bits == 2) GO(2, float); else GO(4, float); }
+#undef GO
+        GEAR_CHECK_LAUNCH("gear_attn_decode(partial)");
+    }
+    hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(128), 0, st, a, (const uint16_t*)kwin,
+                       (const uint16_t*)vwin, W, (uint16_t*)out, (float*)lse);
+    GEAR_CHECK_LAUNCH("gear_attn_decode(reduce)");
+    return 0;
+}

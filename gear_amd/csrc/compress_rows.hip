@@ -682,8 +682,9 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (k <= 64 && len <= 8192 && len >= 16 * (int64_t)k && !getenv("GEAR_ROWS_WG_KERNEL")) {
-        // fast path: one wave per row
+    if (k <= 64 && len <= 8192 && len >= 16 * (int64_t)k && getenv("GEAR_ROWS_WAVE_KERNEL")) {
+        // experimental: one wave per row (fewer instructions per element, but 3 waves/SIMD; measured slower than the
+        // workgroup kernel on MI355X -- both are VALU-issue-bound)
         const int cpl = len <= 1024 ? 1 : (len <= 2048 ? 2 : (len <= 4096 ? 4 : 8));
         dim3 wb(64), wg((unsigned)n_rows);
 #define GOW(B, M, STT, CP)                                                                                                \

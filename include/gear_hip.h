@@ -138,6 +138,29 @@ int gear_decompress_rows(const void* code, const void* scale, const void* mn, in
  */
 int gear_transpose_f16(const void* x, int64_t bh, int R, int C, void* y, void* stream);
 
+/* ---- a6 + a7 (+ outliers): single-token decode attention over the compressed cache ---------------------------
+ * One pass over the packed bytes replaces cuda_bmm_fA_qB_outer for K and V (cuda_supported_gear/quant/matmul.py:178),
+ * the low-rank bmm chains of matmul_withlrap (modeling_llamagear.py:64-108), the fp32 softmax (:313) and the merge with
+ * the fp16 residual window (:256-261, :329-333); also applies the sparse outlier term (not stored by the reference's
+ * fused path).  head_dim must be 128.
+ *   q      fp16 [B, Hq, 128]
+ *   K payload (channel-major, as gear_compress_rows produces for K^T): kcode int32 [B*Hkv, 128, ldk], kscale / kmn
+ *     [B*Hkv, 128, lsk], kP fp16 [B*Hkv, 128, rk] (channel side), kQ fp16 [B*Hkv, tf_k, rk] (token side),
+ *     koidx / koval uint16 / fp16 [B*Hkv, 128, 2*kk] (token index, each half ascending) -- factors / outliers may be NULL
+ *   V payload (token-major): vcode int32 [B*Hkv, tcap_v, 128/fpi], vscale / vmn [B*Hkv, tcap_v, 128/group], vP fp16
+ *     [B*Hkv, 128, rv], vQ fp16 [B*Hkv, tf_v, rv], voidx / voval [B, tcap_v, 2*kv] (column Hkv-head*128 + d)
+ *   kwin / vwin fp16 [B*Hkv, W, 128]: the W <= 64 most recent, still uncompressed tokens (NULL when W == 0)
+ *   T compressed tokens (multiple of fpi); scores are scaled by qscale (1/sqrt(128)); softmax in fp32.
+ *   out fp16 [B, Hq, 128]; lse optional float [B, Hq] (log-sum-exp of the scaled scores).
+ */
+size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits);
+int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP, const void* kQ,
+                     const void* koidx, const void* koval, const void* vcode, const void* vscale, const void* vmn,
+                     const void* vP, const void* vQ, const void* voidx, const void* voval, const void* kwin,
+                     const void* vwin, int B, int Hq, int Hkv, int D, int T, int W, int ldk, int lsk, int tcap_v, int tf_k,
+                     int tf_v, int group, int bits, int mode, int rk, int rv, int kk, int kv, float qscale, void* out,
+                     void* lse, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
