@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the full-model decode tokens/s leg")
     return ap.parse_args()
 
 
@@ -69,6 +70,47 @@ def cpu_baseline(cfg):
         "value": nbytes / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
         "sample": f"oracle compress_insert_function(GEAR) on {nl} layers x {Hs} heads x T={T} (K+V), {dt:.2f} s",
     }
+
+
+def decode_tokens_per_s(cfg, dev, new_tokens=64):
+    """a14 counterpart (cuda_supported_gear/test.py:95-102): random-weight Llama-2-7B through the GEAR attention hook
+    (packed cache, fused dequant GEMV, block compression every `residual` tokens), greedy decode, one synchronize
+    before the clock stops.  Prefill = context - new_tokens so that decoding happens AT the named context."""
+    import torch
+    from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
+    model_name, layers, H, D, T, bits, group, rank, loop, s = cfg
+    mcfg = LlamaConfigLite(num_hidden_layers=layers, num_attention_heads=H, num_key_value_heads=H, hidden_size=H * D,
+                           max_position_embeddings=max(4096, T), k_bits=bits, v_bits=bits, group_size=group, residual_length=64)
+    cc = dict(compress_method="gearlKIVI", group_size=group, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=loop)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float16)
+    try:
+        with torch.device(dev):
+            model = LlamaForCausalLM_GEARKIVI(mcfg, cc).eval()
+    finally:
+        torch.set_default_dtype(old)
+    prompt = T - new_tokens
+    ids = torch.randint(0, mcfg.vocab_size, (1, prompt), device=dev)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        logits, past = model(ids, None, True)            # prefill (dense attention + one-shot compression)
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(2):                               # warm-up decode steps
+            logits, past = model(nxt, past, True)
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(new_tokens - 2):
+            logits, past = model(nxt, past, True)
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    peak = torch.cuda.max_memory_allocated(dev) / 2 ** 20
+    del model, past
+    torch.cuda.empty_cache()
+    return {"tokens_per_s": (new_tokens - 2) / dt, "ms_per_token": dt / (new_tokens - 2) * 1e3, "context": T,
+            "batch": 1, "peak_mem_MiB": peak, "weights": "random init, Llama-2-7B shapes",
+            "method": "gearlKIVI %d-bit rank %d, residual 64 (CSG fused path)" % (bits, rank)}
 
 
 def main():
@@ -187,6 +229,34 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": rows_ms}
 
+    # ---- decompress-into-attention: one decode token's attention over the compressed cache of ALL layers
+    from gear_amd.attention import decode_attention
+    from gear_amd import parallel
+    qv = torch.randn((layers, Hl, 1, D), device=dev, dtype=torch.float16)
+
+    def attn_step():
+        o = decode_attention(qv, pk, pv)
+        if dist is not None:       # head shards -> full [layers, 1, H*D] on every rank (latency-bound, a few KiB / layer)
+            o = parallel.all_gather_heads(o.transpose(1, 2).reshape(layers, 1, Hl * D), world)
+        return o
+
+    for _ in range(3):
+        attn_step()
+    sync()
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    areps = 20
+    a0.record()
+    for _ in range(areps):
+        attn_step()
+    a1.record()
+    sync()
+    attn_ms = a0.elapsed_time(a1) / areps
+    if dist is not None:
+        t = torch.tensor([attn_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        attn_ms = float(t.item())
+    payload_bytes_job = (pk.nbytes() + pv.nbytes()) * world
+
     if rank == 0:
         res = {
             "metric": "KV compress+decompress GB/s (fp16 KV bytes through compress + through decompress per second)",
@@ -201,10 +271,17 @@ def main():
             "decompress_GBps": fp16_bytes_job / ((stages["k_decompress"] + stages["v_decompress"]) * 1e-3) / 1e9,
             "stage_ms": stages,
             "payload_ratio": (2 * n_elem_rank * 2) / (pk.nbytes() + pv.nbytes()),
+            "attn_decode": {"ms_per_token_all_layers": attn_ms, "compressed_GBps": payload_bytes_job / (attn_ms * 1e-3) / 1e9,
+                            "fp16_equiv_GBps": fp16_bytes_job / (attn_ms * 1e-3) / 1e9,
+                            "collective": "all_gather of per-rank attention output" if world > 1 else None},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_decode and not args.layers:
+            del K, V, kr, vr, pk, pv, out
+            torch.cuda.empty_cache()
+            res["decode"] = decode_tokens_per_s(cfg, dev)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
