@@ -123,8 +123,32 @@ __device__ __forceinline__ uint32_t wave_bitonic_sort(uint32_t v) {
     return v;  // lane i holds the i-th element of the sorted order
 }
 
+template <int BITS, int MODE>
+__device__ __forceinline__ int quant_fast(float v, float mn, float scale, float inv, int levels) {
+    if (scale == 0.0f) return 0;
+    if (MODE == 0) {
+        float t1 = hround(v - mn);
+        float c = hround(div_rn(t1, scale));
+        c = fminf(fmaxf(c, 0.0f), (float)levels);
+        return (int)rintf(c);
+    } else {
+        // (v - mn) / scale with an IEEE-exact result: multiply by the reciprocal, and redo the division only when the
+        // approximate quotient is within 1e-5 of a rounding tie (x.5) -- the only place the two can round differently.
+        float t = v - mn;
+        float c = t * inv;
+        float r = rintf(c);
+        if (fabsf(fabsf(c - r) - 0.5f) < 1e-5f) {
+            c = div_rn(t, scale);
+            r = rintf(c);
+        }
+        r = fminf(fmaxf(r, 0.0f), (float)levels);
+        return (int)r;
+    }
+}
+
+
 template <int BITS, int MODE, typename ST>
-__global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k,
+__global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
                                      uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
                                      uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
                                      uint16_t* __restrict__ oval, float* __restrict__ omean) {
@@ -179,60 +203,94 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
         uint32_t key[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) key[j] = sort_key(hb[j]);
-        // ---------------- fast path: thresholds from the sorted per-lane extrema
-        const int kk = (k + nw - 1) / nw;
-        bool use_hist = kk > 64;
+        // ---------------- fast path (tier 0): Gaussian-guess thresholds, validated by the survivor counts
+        // tau = mean +- z*sigma of THIS row (z from the host: about 2.2 k / len of a normal row passes).  Any threshold
+        // is valid as long as at least k elements pass it on each side; if not (or if more than 128 pass) the row falls
+        // back to the histogram radix select below.  Survivors: exact k-th composite by ballot bisection on ONE wave per
+        // side (popcounts run on the scalar unit), then one bitonic sort of the <= 64 selected by index.
+        bool use_hist = (k > 64) || (zthr <= 0.0f);
+        bool payload_done = false;
         if (!use_hist) {
-            uint32_t lmax = 0u, lmin = 0xFFFFu;
+            float s2 = 0.0f;
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) { lmax = max(lmax, key[j]); lmin = min(lmin, key[j]); }
+                for (int j = 0; j < 16; j++) s2 = fmaf(v[j], v[j], s2);
             }
-            // inactive lanes carry (0, 0xFFFF): they sort to the end of both lists
-            uint32_t smax = wave_bitonic_sort<true>(lmax);
-            uint32_t smin = wave_bitonic_sort<false>(lmin);
-            uint32_t thi = __shfl(smax, kk - 1, 64), tlo = __shfl(smin, kk - 1, 64);
-            if (lane == 0) { wave_thr[0][wave] = thi; wave_thr[1][wave] = tlo; }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) s2 += __shfl_xor(s2, d, 64);
+            if (lane == 0) wave_thr[0][wave] = __float_as_uint(s2);
             if (tid < 2) ncand[tid] = 0u;
             for (int i = tid; i < 2 * 512; i += blockDim.x) (&omask[0][0])[i] = 0u;
             __syncthreads();
-            uint32_t tau_hi = 0xFFFFu, tau_lo = 0u;
-            for (int w = 0; w < nw; w++) { tau_hi = min(tau_hi, wave_thr[0][w]); tau_lo = max(tau_lo, wave_thr[1][w]); }
+            float tot1 = 0.0f, tot2 = 0.0f;
+            for (int w = 0; w < nw; w++) { tot1 += wave_sum[w]; tot2 += __uint_as_float(wave_thr[0][w]); }
+            const float mu = tot1 / (float)len;
+            const float sd = sqrtf(fmaxf(tot2 / (float)len - mu * mu, 0.0f));
+            const float thi = mu + zthr * sd, tlo = mu - zthr * sd;
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    if (key[j] >= tau_hi) {
+                for (int j = 0; j < 16; j++) {      // survivors keep (raw fp16 bits << 16) | index; ~2 % of the elements
+                    if (v[j] >= thi) {
                         uint32_t sl = atomicAdd(&ncand[0], 1u);
-                        if (sl < CAND_CAP) cand[0][sl] = (key[j] << 16) | (0xFFFFu - (uint32_t)(j0 + j));
+                        if (sl < 128u) cand[0][sl] = (hb[j] << 16) | (uint32_t)(j0 + j);
                     }
-                    if (key[j] <= tau_lo) {
+                    if (v[j] <= tlo) {
                         uint32_t sl = atomicAdd(&ncand[1], 1u);
-                        if (sl < CAND_CAP) cand[1][sl] = (key[j] << 16) | (uint32_t)(j0 + j);
+                        if (sl < 128u) cand[1][sl] = (hb[j] << 16) | (uint32_t)(j0 + j);
                     }
                 }
             }
             __syncthreads();
             const uint32_t nh = ncand[0], nl = ncand[1];
-            use_hist = (nh > CAND_CAP) || (nl > CAND_CAP);   // block-uniform
+            use_hist = (nh < (uint32_t)k) || (nl < (uint32_t)k) || (nh > 128u) || (nl > 128u);   // block-uniform
             if (!use_hist) {
-                // exact rank among the candidates: hi -- larger composite first; lo -- smaller composite first
-                for (uint32_t c = tid; c < nh; c += blockDim.x) {
-                    uint32_t me = cand[0][c];
-                    int rk = 0;
-                    for (uint32_t o = 0; o < nh; o++) rk += (cand[0][o] > me) ? 1 : 0;
-                    if (rk < k) { uint32_t idx = 0xFFFFu - (me & 0xFFFFu); atomicOr(&omask[0][idx >> 5], 1u << (idx & 31)); }
-                }
-                for (uint32_t c = tid; c < nl; c += blockDim.x) {
-                    uint32_t me = cand[1][c];
-                    int rk = 0;
-                    for (uint32_t o = 0; o < nl; o++) rk += (cand[1][o] < me) ? 1 : 0;
-                    if (rk < k) { uint32_t idx = me & 0xFFFFu; atomicOr(&omask[1][idx >> 5], 1u << (idx & 31)); }
+                // wave 0 finishes the large side, wave 1 (or wave 0 again) the small side
+                for (int side = 0; side < 2; side++) {
+                    if (wave != ((nw > 1) ? side : 0)) continue;
+                    const uint32_t n = side == 0 ? nh : nl;
+                    // large side: select the k LARGEST composites; small side: the k SMALLEST -> flip to "largest of ~c"
+                    const bool v0 = (uint32_t)lane < n, v1 = (uint32_t)(lane + 64) < n;
+                    const uint32_t c0 = v0 ? cand[side][lane] : 0u, c1 = v1 ? cand[side][lane + 64] : 0u;
+                    const uint32_t k0 = sort_key(c0 >> 16), k1 = sort_key(c1 >> 16), i0 = c0 & 0xFFFFu, i1 = c1 & 0xFFFFu;
+                    // order value, larger = selected first: large side (key desc, index asc); small side (key asc, index asc)
+                    uint32_t o0 = side == 0 ? ((k0 << 16) | (0xFFFFu - i0)) : ~((k0 << 16) | i0);
+                    uint32_t o1 = side == 0 ? ((k1 << 16) | (0xFFFFu - i1)) : ~((k1 << 16) | i1);
+                    if (!v0) o0 = 0u;
+                    if (!v1) o1 = 0u;
+                    uint32_t lo_b = 0u, hi_b = 0xFFFFFFFFu;   // largest T with count(o >= T) >= k
+                    for (int it = 0; it < 32; it++) {
+                        const uint32_t mid = lo_b + ((hi_b - lo_b) >> 1) + ((hi_b - lo_b) & 1u);
+                        const int cnt = __popcll(__ballot(o0 >= mid)) + __popcll(__ballot(o1 >= mid));
+                        if (cnt >= k) lo_b = mid; else hi_b = mid - 1u;
+                    }
+                    const bool s0 = v0 && o0 >= lo_b, s1 = v1 && o1 >= lo_b;
+                    const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+                    const int p0 = __popcll(b0 & ((1ull << lane) - 1ull));
+                    const int p1 = __popcll(b0) + __popcll(b1 & ((1ull << lane) - 1ull));
+                    uint32_t* selb = &cand[side][128];     // scratch behind the candidates (CAND_CAP >= 192)
+                    // sort value: (index << 16) | raw fp16 bits  -> ascending by index
+                    if (s0) selb[p0] = (i0 << 16) | (c0 >> 16);
+                    if (s1) selb[p1] = (i1 << 16) | (c1 >> 16);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    uint32_t sv = lane < k ? selb[lane] : 0xFFFFFFFFu;
+                    sv = wave_bitonic_sort<false>(sv);
+                    if (lane < k) {
+                        const uint32_t idx = sv >> 16;
+                        uint16_t* oi = oidx + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                        uint16_t* ov = oval + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                        oi[lane] = (uint16_t)idx;
+                        ov[lane] = (uint16_t)(sv & 0xFFFFu);
+                        atomicOr(&omask[side][idx >> 5], 1u << (idx & 31));
+                    }
                 }
                 __syncthreads();
                 if (active) {
                     flag_hi = (omask[0][j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
                     flag_lo = (omask[1][j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
                 }
+                payload_done = true;
             }
         }
         if (use_hist) {
@@ -294,20 +352,22 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
         for (int w = 0; w < nw; w++) tot += wave_sum[w];
         const float mean = tot / (float)len;
         // ---------------- output slots (sorted by index) and the sparse payload
-        unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
-        unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
-        int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
-        uint16_t* oi = oidx + r * (int64_t)(2 * k);
-        uint16_t* ov = oval + r * (int64_t)(2 * k);
+        if (!payload_done) {
+            unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
+            unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
+            int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
+            uint16_t* oi = oidx + r * (int64_t)(2 * k);
+            uint16_t* ov = oval + r * (int64_t)(2 * k);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (flag_lo & (1u << j)) {
-                if (slot_lo < k) { oi[slot_lo] = (uint16_t)(j0 + j); ov[slot_lo] = (uint16_t)hb[j]; }
-                slot_lo++;
-            }
-            if (flag_hi & (1u << j)) {
-                if (slot_hi < k) { oi[k + slot_hi] = (uint16_t)(j0 + j); ov[k + slot_hi] = (uint16_t)hb[j]; }
-                slot_hi++;
+            for (int j = 0; j < 16; j++) {
+                if (flag_lo & (1u << j)) {
+                    if (slot_lo < k) { oi[slot_lo] = (uint16_t)(j0 + j); ov[slot_lo] = (uint16_t)hb[j]; }
+                    slot_lo++;
+                }
+                if (flag_hi & (1u << j)) {
+                    if (slot_hi < k) { oi[k + slot_hi] = (uint16_t)(j0 + j); ov[k + slot_hi] = (uint16_t)hb[j]; }
+                    slot_hi++;
+                }
             }
         }
         if (tid == 0 && omean) omean[r] = mean;
@@ -332,6 +392,7 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     }
     if (!active) return;
     QuantParams<MODE> qp = make_qparams<MODE>(lo, hi, LEVELS);
+    const float inv = (qp.scale != 0.0f) ? div_rn(1.0f, qp.scale) : 0.0f;
     uint32_t words[WPL];
 #pragma unroll
     for (int w = 0; w < WPL; w++) words[w] = 0u;
@@ -339,7 +400,7 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     const uint32_t outl = flag_lo | flag_hi;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        int q = quant_one<MODE>(v[j], qp);
+        int q = quant_fast<BITS, MODE>(v[j], qp.mn, qp.scale, inv, LEVELS);
         words[j / CPW] |= (uint32_t)q << (BITS * (j % CPW));
         float d = (MODE == 0) ? dequant_one<0>(q, qp.scale, qp.mn) : hround(dequant_one<1>(q, qp.scale, qp.mn));
         e[j] = (outl & (1u << j)) ? 0.0f : (v[j] - d);
@@ -368,30 +429,6 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
 // are >= tau_hi; the few elements passing the threshold are ranked exactly in LDS ((value desc, index asc) for the
 // large side, (value asc, index asc) for the small side) and written out sorted by index.
 // =====================================================================================================
-template <int BITS, int MODE>
-__device__ __forceinline__ int quant_fast(float v, float mn, float scale, float inv, int levels) {
-    if (scale == 0.0f) return 0;
-    if (MODE == 0) {
-        float t1 = hround(v - mn);
-        float c = hround(div_rn(t1, scale));
-        c = fminf(fmaxf(c, 0.0f), (float)levels);
-        return (int)rintf(c);
-    } else {
-        // (v - mn) / scale with an IEEE-exact result: multiply by the reciprocal, and redo the division only when the
-        // approximate quotient is within 1e-5 of a rounding tie (x.5) -- the only place the two can round differently.
-        float t = v - mn;
-        float c = t * inv;
-        float r = rintf(c);
-        if (fabsf(fabsf(c - r) - 0.5f) < 1e-5f) {
-            c = div_rn(t, scale);
-            r = rintf(c);
-        }
-        r = fminf(fmaxf(r, 0.0f), (float)levels);
-        return (int)r;
-    }
-}
-
-
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
@@ -663,6 +700,25 @@ __global__ __launch_bounds__(64) void compress_rows_wave_kernel(const uint16_t* 
 
 }  // namespace
 
+// inverse of the standard normal CDF (Acklam's rational approximation, |error| < 1.2e-9) -- host side only
+static double inv_norm_cdf(double p) {
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                               1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                               6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                               -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (p < 0.02425) {
+        double q = sqrt(-2 * log(p));
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    if (p > 1 - 0.02425) return -inv_norm_cdf(1 - p);
+    double q = p - 0.5, rr = q * q;
+    return (((((a[0] * rr + a[1]) * rr + a[2]) * rr + a[3]) * rr + a[4]) * rr + a[5]) * q /
+           (((((b[0] * rr + b[1]) * rr + b[2]) * rr + b[3]) * rr + b[4]) * rr + 1);
+}
+
 extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride,
                                   int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int group, int bits,
                                   int mode, int k, void* code, void* scale, void* mn, void* err, void* oidx, void* oval,
@@ -681,6 +737,12 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     GEAR_CHECK_ARG(k == 0 || (oidx && oval), "gear_compress_rows: outlier buffers required when k > 0");
     RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride};
     int threads = (int)((len / 16 + 63) / 64 * 64);
+    // tier-0 threshold: let about 2.2 k of a normal row's elements pass on each side (at most 128 may)
+    float zthr = 0.0f;
+    if (k > 0 && k <= 58 && !getenv("GEAR_ROWS_HIST_ONLY")) {
+        double frac = 2.2 * (double)k / (double)len;
+        if (frac < 0.45) zthr = (float)(-inv_norm_cdf(frac));
+    }
     hipStream_t st = (hipStream_t)stream;
     if (k <= 64 && len <= 8192 && len >= 16 * (int64_t)k && getenv("GEAR_ROWS_WAVE_KERNEL")) {
         // experimental: one wave per row (fewer instructions per element, but 3 waves/SIMD; measured slower than the
@@ -709,7 +771,7 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     }
     dim3 block(threads), grid((unsigned)n_rows);
 #define GO(B, M, STT)                                                                                                  \
-    hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, 0, st, (const uint16_t*)x, gm, (int)len, group, k, \
+    hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, 0, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
                        (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
                        (float*)omean)
     if (mode == 0) {
