@@ -54,7 +54,7 @@ def cpu_baseline(cfg):
     import numpy as np
     from oracle import oracle as orc
     model, layers, H, D, T, bits, group, rank, loop, s = cfg
-    Hs, nl = H, 2  # bounded sample: 2 of the layers, all heads, full context (about 10-15 s on 8 cores)
+    Hs, nl = H, 8  # bounded sample: 8 of the 32 layers, all heads, full context (about 10 s on the GPU box's host cores)
     rng = np.random.default_rng(0)
     k = rng.standard_normal((nl, Hs, T, D)).astype(np.float16)
     v = rng.standard_normal((nl, Hs, T, D)).astype(np.float16)
