@@ -225,8 +225,11 @@ def main():
     rows_ms = e0.elapsed_time(e1) / reps
     alg_bytes = 2 * n + n * bits / 8 + 8 * n / group + 2 * n + layers * T * 2 * k_val * 4
     achieved = alg_bytes / (rows_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed in profiles/r1_pmc_traffic_compress_rows.md (FETCH_SIZE x2 per
+    # the gfx950 correction + WRITE_SIZE); measured for exactly this launch (C3, 1 GPU, all layers), null otherwise
+    traffic = 2.592e9 if (args.config == "c3" and world == 1 and not args.layers) else None
     roofline = {"bound": "hbm", "kernel": "compress_rows_kernel<V>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": rows_ms}
 
     # ---- decompress-into-attention: one decode token's attention over the compressed cache of ALL layers
