@@ -163,6 +163,7 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     __shared__ uint32_t omask[2][512];       // per-element outlier bitmaps (hi / lo), row length <= 16384
     __shared__ uint32_t wave_thr[2][16];
     __shared__ uint32_t ncand[2];
+    extern __shared__ uint32_t rawlds[];     // [blockDim.x][8]: the lane's 16 raw fp16 values (tier-0 path only)
 
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -227,18 +228,40 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
             const float mu = tot1 / (float)len;
             const float sd = sqrtf(fmaxf(tot2 / (float)len - mu * mu, 0.0f));
             const float thi = mu + zthr * sd, tlo = mu - zthr * sd;
-            if (active) {
+            // survivors: packed fp16 subtract against the threshold, sign bits gathered into one mask per side
+            // (3 VALU per two elements), then each lane emits its own few hits ((raw bits << 16) | index) -- about
+            // 2 % of the elements survive, so the emission loop runs ~3 times per wave
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            const uint32_t th = f2h_bits(thi), tl = f2h_bits(tlo);
+            const half2_t thi2 = __builtin_bit_cast(half2_t, th | (th << 16)), tlo2 = __builtin_bit_cast(half2_t, tl | (tl << 16));
+            uint32_t sg_hi = 0u, sg_lo = 0u;   // sign(x - thi): set where x < thi ; sign(tlo - x): set where x > tlo
 #pragma unroll
-                for (int j = 0; j < 16; j++) {      // survivors keep (raw fp16 bits << 16) | index; ~2 % of the elements
-                    if (v[j] >= thi) {
-                        uint32_t sl = atomicAdd(&ncand[0], 1u);
-                        if (sl < 128u) cand[0][sl] = (hb[j] << 16) | (uint32_t)(j0 + j);
-                    }
-                    if (v[j] <= tlo) {
-                        uint32_t sl = atomicAdd(&ncand[1], 1u);
-                        if (sl < 128u) cand[1][sl] = (hb[j] << 16) | (uint32_t)(j0 + j);
-                    }
-                }
+            for (int w = 0; w < 8; w++) {
+                const half2_t xv = __builtin_bit_cast(half2_t, rw[w]);
+                const uint32_t dh = __builtin_bit_cast(uint32_t, (half2_t)(xv - thi2));
+                const uint32_t dl = __builtin_bit_cast(uint32_t, (half2_t)(tlo2 - xv));
+                sg_hi |= (dh & 0x80008000u) >> w;
+                sg_lo |= (dl & 0x80008000u) >> w;
+                rawlds[tid * 8 + w] = rw[w];
+            }
+            uint32_t mh = active ? (~sg_hi & 0xFF00FF00u) : 0u, ml = active ? (~sg_lo & 0xFF00FF00u) : 0u;
+            // bit 15-w <-> element 2w, bit 31-w <-> element 2w+1
+            while (mh) {
+                const int b = 31 - __clz(mh);
+                mh &= ~(1u << b);
+                const int j = b >= 24 ? 2 * (31 - b) + 1 : 2 * (15 - b);
+                const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                uint32_t sl = atomicAdd(&ncand[0], 1u);
+                if (sl < 128u) cand[0][sl] = (bits << 16) | (uint32_t)(j0 + j);
+            }
+            while (ml) {
+                const int b = 31 - __clz(ml);
+                ml &= ~(1u << b);
+                const int j = b >= 24 ? 2 * (31 - b) + 1 : 2 * (15 - b);
+                const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                uint32_t sl = atomicAdd(&ncand[1], 1u);
+                if (sl < 128u) cand[1][sl] = (bits << 16) | (uint32_t)(j0 + j);
             }
             __syncthreads();
             const uint32_t nh = ncand[0], nl = ncand[1];
@@ -771,7 +794,7 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     }
     dim3 block(threads), grid((unsigned)n_rows);
 #define GO(B, M, STT)                                                                                                  \
-    hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, 0, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
+    hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
                        (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
                        (float*)omean)
     if (mode == 0) {
