@@ -84,6 +84,18 @@ __device__ __forceinline__ void st_st<uint16_t>(uint16_t* p, float v) { *p = f2h
 template <>
 __device__ __forceinline__ void st_st<float>(float* p, float v) { *p = v; }
 
+// ------------------------------------------------------------------ DPP reductions (no LDS crossbar)
+// sum over the 16 lanes of a DPP row (lanes 16i .. 16i+15); every lane of the row gets the total.
+// quad_perm xor 1 (0xB1), xor 2 (0x4E), row_half_mirror (0x141), row_mirror (0x140).
+#define GEAR_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+__device__ __forceinline__ float row16_sum(float v) {
+    v = GEAR_DPP_ADD(v, 0xB1);
+    v = GEAR_DPP_ADD(v, 0x4E);
+    v = GEAR_DPP_ADD(v, 0x141);
+    v = GEAR_DPP_ADD(v, 0x140);
+    return v;
+}
+
 // ------------------------------------------------------------------ the group quantizer arithmetic
 // MODE 0: fp16-stepwise (cuda_supported_gear/quant/new_pack.py:237-240, :277-278)
 // MODE 1: fp32         (GenerationBench/.../Simulated/compress_function.py:24-28)

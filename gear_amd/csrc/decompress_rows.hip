@@ -74,30 +74,48 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         }
     }
 
-#pragma unroll 2
-    for (int ri = 0; ri < g.rpb; ri++) {
-        const int64_t row = row0 + ri;
-        if (row >= g.n_rows || !active) break;
-        const int rin = (int)(row % g.rows_inner);
-        const int64_t off = (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)seg * g.seg_stride + pos;
-        const int64_t gi = off / g.group;
-        const float s = ld_st<ST>(scale + gi), m = ld_st<ST>(mn + gi);
+    // software pipeline over the block's rows: the loads of row i+1 are issued before row i is computed and stored
+    struct RowIn { uint32_t words[WPL]; float s, m; uint4 fv0, fv1; int64_t off; };
+    auto row_offset = [&](int ri) -> int64_t {
+        const int rin = (int)((row0 + ri) % g.rows_inner);
+        return (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)seg * g.seg_stride + pos;
+    };
+    auto fetch = [&](int ri, RowIn& in) {
+        const int rin = (int)((row0 + ri) % g.rows_inner);
+        in.off = row_offset(ri);
+        const int64_t gi = in.off / g.group;
+        in.s = ld_st<ST>(scale + gi);
+        in.m = ld_st<ST>(mn + gi);
+#pragma unroll
+        for (int w = 0; w < WPL; w++) in.words[w] = code[in.off / CPW + w];
+        if (RV > 0 && r > 0) {
+            const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r
+                                              : P + ((int64_t)ro * g.D + rin) * r;
+            if (RV == 4) { uint2 t = *(const uint2*)fvp; in.fv0 = make_uint4(t.x, t.y, 0, 0); }
+            else in.fv0 = *(const uint4*)fvp;
+            if (RV == 16) in.fv1 = ((const uint4*)fvp)[1];
+        }
+    };
+    const int nrows = active ? (int)((g.n_rows - row0) < g.rpb ? (g.n_rows - row0) : g.rpb) : 0;
+    RowIn cur, nxt;
+    if (nrows > 0) fetch(0, cur);
+    for (int ri = 0; ri < nrows; ri++) {
+        if (ri + 1 < nrows) fetch(ri + 1, nxt);
         float f[16];
 #pragma unroll
         for (int w = 0; w < WPL; w++) {
-            uint32_t word = code[off / CPW + w];
 #pragma unroll
             for (int j = 0; j < CPW; j++) {
-                float d = dequant_one<MODE>((int)((word >> (BITS * j)) & MASK), s, m);
+                float d = dequant_one<MODE>((int)((cur.words[w] >> (BITS * j)) & MASK), cur.s, cur.m);
                 f[w * CPW + j] = (MODE == 0) ? d : hround(d);
             }
         }
         if (r > 0) {
-            const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r      // Q[bh, t, :]
-                                              : P + ((int64_t)ro * g.D + rin) * r;                       // P[bh, d, :]
             if (RV > 0) {
                 float fv[RVS];
-                load_halfs<RVS>(fvp, fv);
+                if (RV == 4) { fv[0] = h2f_bits((uint16_t)(cur.fv0.x & 0xFFFFu)); fv[1 % RVS] = h2f_bits((uint16_t)(cur.fv0.x >> 16));
+                               fv[2 % RVS] = h2f_bits((uint16_t)(cur.fv0.y & 0xFFFFu)); fv[3 % RVS] = h2f_bits((uint16_t)(cur.fv0.y >> 16)); }
+                else { unpack8(cur.fv0, fv); if (RV == 16) unpack8(cur.fv1, fv + (RVS > 8 ? 8 : 0)); }
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     float acc = 0.0f;
@@ -106,6 +124,9 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                     f[j] += acc;
                 }
             } else {
+                const int rin = (int)((row0 + ri) % g.rows_inner);
+                const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r
+                                                  : P + ((int64_t)ro * g.D + rin) * r;
                 float fv[16];
                 for (int c = 0; c < r; c++) fv[c] = h2f_bits(fvp[c]);
 #pragma unroll
@@ -116,9 +137,10 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                 }
             }
         }
-        uint4* op = (uint4*)(out + off);
+        uint4* op = (uint4*)(out + cur.off);
         op[0] = pack8(f);
         op[1] = pack8(f + 8);
+        cur = nxt;
     }
     if (g.k == 0) return;
     // ---- sparse phase: overwrite the outlier positions of this block's rows

@@ -53,31 +53,44 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
         for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
 
     // ------------------------------------------------------------------ phase 1: G = E^T E on the matrix cores
-    for (int t0 = 0; t0 < S; t0 += 64) {
-        __syncthreads();
-        if (TOKEN_MAJOR) {
-            // tile [64 tokens][128 channels]: 16 lanes per token row, 16 rows per pass
+    // staging: global -> registers (issued one tile ahead) -> LDS; the loads of tile t+1 fly during the MFMAs of tile t
+    uint4 stg[4];
+    auto stage_load = [&](int t0) {
+        if (TOKEN_MAJOR) {   // tile [64 tokens][128 channels]: 16 lanes per token row, 16 rows per pass
             const int l16 = tid & 15, rr = tid >> 4;
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 int t = t0 + rr + 16 * p;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (t < S) v = *(const uint4*)(Eb + (int64_t)t * GD + l16 * 8);
-                *(uint4*)(tile + (rr + 16 * p) * TM_PITCH + l16 * 8) = v;
+                stg[p] = make_uint4(0, 0, 0, 0);
+                if (t < S) stg[p] = *(const uint4*)(Eb + (int64_t)t * GD + l16 * 8);
             }
-        } else {
-            // K^T: E^T [128 channels][S tokens]; tile [128][64]: 8 lanes per channel row, 32 rows per pass
+        } else {             // K^T: E^T [128 channels][S tokens]; tile [128][64]: 8 lanes per channel row, 32 rows per pass
             const int l8 = tid & 7, rr = tid >> 3;
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                int d = rr + 32 * p;
-                int t = t0 + l8 * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (t < S) v = *(const uint4*)(Eb + (int64_t)d * S + t);
-                *(uint4*)(tile + d * KT_PITCH + l8 * 8) = v;
+                int d = rr + 32 * p, t = t0 + l8 * 8;
+                stg[p] = make_uint4(0, 0, 0, 0);
+                if (t < S) stg[p] = *(const uint4*)(Eb + (int64_t)d * S + t);
             }
         }
+    };
+    auto stage_store = [&]() {
+        if (TOKEN_MAJOR) {
+            const int l16 = tid & 15, rr = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < 4; p++) *(uint4*)(tile + (rr + 16 * p) * TM_PITCH + l16 * 8) = stg[p];
+        } else {
+            const int l8 = tid & 7, rr = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < 4; p++) *(uint4*)(tile + (rr + 32 * p) * KT_PITCH + l8 * 8) = stg[p];
+        }
+    };
+    stage_load(0);
+    for (int t0 = 0; t0 < S; t0 += 64) {
         __syncthreads();
+        stage_store();
+        __syncthreads();
+        if (t0 + 64 < S) stage_load(t0 + 64);
         // wave w owns tokens [16w, 16w+16) of the tile; lane (x, kg) holds channel x of each 32-block, tokens 8kg..8kg+7
         half8_t f[4];
 #pragma unroll
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256) void lr_qpass_kt_kernel(const uint16_t* __rest
     for (int j = 0; j < 8; j++)
 #pragma unroll
         for (int c = 0; c < RP; c++) acc[j][c] = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
     for (int d = 0; d < GD; d++) {
         float m[8];
         unpack8(*(const uint4*)(p + (int64_t)d * S), m);
@@ -284,23 +297,27 @@ __global__ __launch_bounds__(256) void lr_qpass_tm_kernel(const uint16_t* __rest
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int c = 0; c < RP; c++) wr[i][c] = Wb[(l16 * 8 + i) * RP + c];
+    // all 8 row loads are issued up front; the 16-lane reductions run on DPP (no LDS crossbar)
+    uint4 raw[8];
+#pragma unroll
     for (int i = 0; i < 8; i++) {
         const int row = blockIdx.x * 128 + grp + 16 * i;
-        float acc[RP];
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (row < S) raw[i] = *(const uint4*)(E + (bh * S + row) * (int64_t)GD + l16 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = blockIdx.x * 128 + grp + 16 * i;
+        float acc[RP], m[8];
 #pragma unroll
         for (int c = 0; c < RP; c++) acc[c] = 0.0f;
-        if (row < S) {
-            float m[8];
-            unpack8(*(const uint4*)(E + (bh * S + row) * (int64_t)GD + l16 * 8), m);
+        unpack8(raw[i], m);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
+        for (int j = 0; j < 8; j++)
 #pragma unroll
-                for (int c = 0; c < RP; c++) acc[c] = fmaf(m[j], wr[j][c], acc[c]);
-        }
+            for (int c = 0; c < RP; c++) acc[c] = fmaf(m[j], wr[j][c], acc[c]);
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1)
-#pragma unroll
-            for (int c = 0; c < RP; c++) acc[c] += __shfl_xor(acc[c], d, 64);
+        for (int c = 0; c < RP; c++) acc[c] = row16_sum(acc[c]);
         if (l16 == 0 && row < S) {
             if (out_f16 && r == RP) {
                 store_halfs<RP>((uint16_t*)Q_out + (bh * S + row) * (int64_t)RP, acc);
