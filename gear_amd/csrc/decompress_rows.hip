@@ -142,31 +142,46 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         op[1] = pack8(f + 8);
         cur = nxt;
     }
-    if (g.k == 0) return;
-    // ---- sparse phase: overwrite the outlier positions of this block's rows
-    __syncthreads();
+}
+
+// Sparse restore, one thread per outlier entry (launched after the dense kernel on the same stream): plenty of
+// independent threads hide the dependent index -> factor -> store chain that stalled the dense workgroups.
+template <int KIND, int RV>
+__global__ __launch_bounds__(256) void decompress_sparse_kernel(DGeom g, const uint16_t* __restrict__ P,
+                                                                const uint16_t* __restrict__ Q,
+                                                                const uint16_t* __restrict__ oidx,
+                                                                const uint16_t* __restrict__ oval,
+                                                                uint16_t* __restrict__ out) {
+    constexpr int RVS = RV > 0 ? RV : 1;
     const int per_row = 2 * g.k;
-    const int n_ent = g.rpb * per_row;
-    for (int e = tid; e < n_ent; e += blockDim.x) {
-        const int64_t row = row0 + e / per_row;
-        if (row >= g.n_rows) break;
-        const int rin = (int)(row % g.rows_inner);
-        const uint32_t idx = oidx[row * per_row + e % per_row];
-        float v = h2f_bits(oval[row * per_row + e % per_row]);
-        const int sg = (int)idx / g.seglen, ps = (int)idx % g.seglen;
-        if (r > 0) {
-            int64_t bh, t, d;
-            if (KIND == 0) { bh = (int64_t)ro * g.nseg + sg; t = rin; d = ps; }
-            else { bh = ro; t = idx; d = rin; }
-            const uint16_t* qp = Q + (bh * g.T + t) * r;
-            const uint16_t* pp = P + (bh * g.D + d) * r;
-            float acc = 0.0f;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.n_rows * per_row) return;
+    const int64_t row = e / per_row;
+    const int ro = (int)(row / g.rows_inner), rin = (int)(row % g.rows_inner);
+    const uint32_t idx = oidx[e];
+    float v = h2f_bits(oval[e]);
+    const int sg = (int)idx / g.seglen, ps = (int)idx % g.seglen;
+    const int r = g.r;
+    if (r > 0) {
+        int64_t bh, t, d;
+        if (KIND == 0) { bh = (int64_t)ro * g.nseg + sg; t = rin; d = ps; }
+        else { bh = ro; t = idx; d = rin; }
+        const uint16_t* qp = Q + (bh * g.T + t) * r;
+        const uint16_t* pp = P + (bh * g.D + d) * r;
+        float acc = 0.0f;
+        if (RV > 0) {
+            float a[RVS], b[RVS];
+            load_halfs<RVS>(qp, a);
+            load_halfs<RVS>(pp, b);
+#pragma unroll
+            for (int c = 0; c < RVS; c++) acc = fmaf(a[c], b[c], acc);
+        } else {
             for (int c = 0; c < r; c++) acc = fmaf(h2f_bits(qp[c]), h2f_bits(pp[c]), acc);
-            v += acc;
         }
-        const int64_t off = (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)sg * g.seg_stride + ps;
-        out[off] = f2h_bits(v);
+        v += acc;
     }
+    const int64_t off = (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)sg * g.seg_stride + ps;
+    out[off] = f2h_bits(v);
 }
 
 }  // namespace
@@ -218,5 +233,16 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
 #undef GO
 #undef GOT
     GEAR_CHECK_LAUNCH("gear_decompress_rows");
+    if (k > 0) {
+        const int64_t n_ent = n_rows * 2 * (int64_t)k;
+        dim3 sg((unsigned)((n_ent + 255) / 256));
+#define GS(KD, RVV) hipLaunchKernelGGL((decompress_sparse_kernel<KD, RVV>), sg, dim3(256), 0, st, g, (const uint16_t*)P, \
+                                       (const uint16_t*)Q, (const uint16_t*)oidx, (const uint16_t*)oval, (uint16_t*)out)
+#define GSR(KD) do { if (r == 8) GS(KD, 8); else if (r == 4) GS(KD, 4); else if (r == 16) GS(KD, 16); else GS(KD, 0); } while (0)
+        if (kind == 0) GSR(0); else GSR(1);
+#undef GSR
+#undef GS
+        GEAR_CHECK_LAUNCH("gear_decompress_rows(sparse)");
+    }
     return 0;
 }

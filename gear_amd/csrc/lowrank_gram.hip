@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
 
     // ------------------------------------------------------------------ phase 1: G = E^T E on the matrix cores
     // staging: global -> registers (issued one tile ahead) -> LDS; the loads of tile t+1 fly during the MFMAs of tile t
-    uint4 stg[4];
-    auto stage_load = [&](int t0) {
+    uint4 stgA[4], stgB[4];
+    auto stage_load = [&](int t0, uint4 (&stg)[4]) {
         if (TOKEN_MAJOR) {   // tile [64 tokens][128 channels]: 16 lanes per token row, 16 rows per pass
             const int l16 = tid & 15, rr = tid >> 4;
 #pragma unroll
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
             }
         }
     };
-    auto stage_store = [&]() {
+    auto stage_store = [&](const uint4 (&stg)[4]) {
         if (TOKEN_MAJOR) {
             const int l16 = tid & 15, rr = tid >> 4;
 #pragma unroll
@@ -85,12 +85,7 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
             for (int p = 0; p < 4; p++) *(uint4*)(tile + (rr + 32 * p) * KT_PITCH + l8 * 8) = stg[p];
         }
     };
-    stage_load(0);
-    for (int t0 = 0; t0 < S; t0 += 64) {
-        __syncthreads();
-        stage_store();
-        __syncthreads();
-        if (t0 + 64 < S) stage_load(t0 + 64);
+    auto tile_mfma = [&]() {
         // wave w owns tokens [16w, 16w+16) of the tile; lane (x, kg) holds channel x of each 32-block, tokens 8kg..8kg+7
         half8_t f[4];
 #pragma unroll
@@ -111,6 +106,22 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
 #pragma unroll
             for (int J = I; J < 4; J++)
                 acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
+    };
+    stage_load(0, stgA);
+    if (64 < S) stage_load(64, stgB);
+    for (int t0 = 0; t0 < S; t0 += 128) {       // two tiles per trip, two tiles of loads in flight
+        __syncthreads();
+        stage_store(stgA);
+        __syncthreads();
+        if (t0 + 128 < S) stage_load(t0 + 128, stgA);
+        tile_mfma();
+        if (t0 + 64 < S) {
+            __syncthreads();
+            stage_store(stgB);
+            __syncthreads();
+            if (t0 + 192 < S) stage_load(t0 + 192, stgB);
+            tile_mfma();
+        }
     }
     __syncthreads();
     for (int i = tid; i < GD * GD; i += 256) G[i] = 0.0f;
