@@ -1,0 +1,152 @@
+"""Pre-allocated, kernel-native GEAR KV cache for one attention layer (the build's own
+design: the reference rebuilds every payload tensor with torch.cat on each block boundary,
+cuda_supported_gear/modeling_llamagear.py:273-286, :365-378, and re-lays the whole packed K out on every token,
+quant/matmul.py:205, :215-216).
+
+State machine = the attention hook's (modeling_llamagear.py:177-484): an fp16 window of the most recent < `residual`
+tokens; when it fills, the block is compressed (quantize + pack + per-block rank-r factors) in place behind the already
+compressed tokens.  Layout = what gear_attn_decode_seg streams: K channel-major with a fixed row pitch (so a block append
+is 128 short row segments, never a re-layout), V token-major, token-side factors per token, channel-side factors per
+segment (segment 0 = the prompt, then one per block).
+
+Differences from the hook, on purpose: K and V are compressed in lockstep (the hook compresses V only when T > residual,
+:416, which strands V in fp16 when the prompt is exactly `residual` long), and the block factors start from a
+channel-side random basis (the simulated path's orientation, compress_function.py:83) so that the Gram-matrix kernel
+applies; both are rank-r power-iteration approximations of the same error matrix.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+from . import compress as C
+
+
+class GearKVCache:
+    def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device, head_dim: int = 128,
+                 seed: int = 0):
+        assert head_dim == 128
+        cc = compress_config
+        self.B, self.H, self.D = batch, n_kv_heads, head_dim
+        self.bits, self.group, self.R = cc["quantize_bit"], cc["group_size"], cc["residual"]
+        m = cc["compress_method"]
+        self.lowrank = ("gearl" in m) or ("gearsl" in m)
+        self.rk = int(cc["rank"]) if self.lowrank else 0
+        self.rv = int(cc["rankv"]) if self.lowrank else 0
+        self.loop = int(cc.get("loop", 3))
+        assert self.R % 64 == 0 and self.R % self.group == 0
+        fpi = 32 // self.bits
+        self.fpi = fpi
+        self.Tmax = (max_tokens + self.R - 1) // self.R * self.R
+        nseg = 1 + self.Tmax // self.R
+        B, H, D, T = batch, n_kv_heads, head_dim, self.Tmax
+        dev, h16 = device, torch.float16
+        self.kcode = torch.zeros((B, H, D, T // fpi), dtype=torch.int32, device=dev)
+        self.kscale = torch.zeros((B, H, D, T // self.group), dtype=h16, device=dev)
+        self.kmn = torch.zeros_like(self.kscale)
+        self.vcode = torch.zeros((B, H, T, D // fpi), dtype=torch.int32, device=dev)
+        self.vscale = torch.zeros((B, H, T, D // self.group), dtype=h16, device=dev)
+        self.vmn = torch.zeros_like(self.vscale)
+        if self.lowrank:
+            self.kPseg = torch.zeros((nseg, B, H, D, self.rk), dtype=h16, device=dev)   # channel side, per segment
+            self.kQtok = torch.zeros((B, H, T, self.rk), dtype=h16, device=dev)         # token side
+            self.vPseg = torch.zeros((nseg, B, H, D, self.rv), dtype=h16, device=dev)
+            self.vQtok = torch.zeros((B, H, T, self.rv), dtype=h16, device=dev)
+        else:
+            self.kPseg = self.kQtok = self.vPseg = self.vQtok = None
+        self.kwin = torch.zeros((B, H, self.R, D), dtype=h16, device=dev)
+        self.vwin = torch.zeros_like(self.kwin)
+        self.n_comp = 0      # compressed tokens
+        self.n_win = 0       # tokens in the fp16 window
+        self.seg0 = 0        # tokens of segment 0 (the compressed part of the prompt)
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self._ws = None
+
+    # ------------------------------------------------------------------------------------------------ state
+    @property
+    def seq_len(self) -> int:
+        return self.n_comp + self.n_win
+
+    def _segment_of(self, t0: int) -> int:
+        return 0 if t0 < self.seg0 else 1 + (t0 - self.seg0) // self.R
+
+    def _store_block(self, k_blk: torch.Tensor, v_blk: torch.Tensor, seg: int):
+        """Compress [B,H,n,128] K and V and write them behind the compressed tokens."""
+        n, t0, g, fpi = k_blk.shape[2], self.n_comp, self.group, self.fpi
+        assert t0 + n <= self.Tmax, "cache capacity exceeded"
+        P0k = P0v = None
+        if self.lowrank:
+            P0k = torch.rand((self.B, self.H, self.D, self.rk), device=k_blk.device, generator=self.gen)
+            P0v = torch.rand((self.B, self.H, self.D, self.rv), device=k_blk.device, generator=self.gen)
+        pk = C.compress_key(k_blk, self.bits, g, rank=self.rk, loop=self.loop, mode="fp16", P0=P0k)
+        pv = C.compress_value(v_blk, self.bits, g, rank=self.rv, loop=self.loop, mode="fp16", P0=P0v)
+        self.kcode[:, :, :, t0 // fpi:(t0 + n) // fpi] = pk.code
+        self.kscale[:, :, :, t0 // g:(t0 + n) // g] = pk.scale
+        self.kmn[:, :, :, t0 // g:(t0 + n) // g] = pk.mn
+        self.vcode[:, :, t0:t0 + n] = pv.code
+        self.vscale[:, :, t0:t0 + n] = pv.scale
+        self.vmn[:, :, t0:t0 + n] = pv.mn
+        if self.lowrank:
+            self.kPseg[seg] = pk.P
+            self.kQtok[:, :, t0:t0 + n] = pk.Q
+            self.vPseg[seg] = pv.P
+            self.vQtok[:, :, t0:t0 + n] = pv.Q
+        self.n_comp += n
+
+    def prefill(self, k: torch.Tensor, v: torch.Tensor):
+        """k, v fp16 [B,Hkv,T,128] (post-RoPE): the first T - T % residual tokens are compressed as segment 0, the tail
+        stays in the fp16 window (modeling_llamagear.py:390-434)."""
+        assert self.seq_len == 0
+        T = k.shape[2]
+        nq = T - T % self.R
+        if nq:
+            self.seg0 = nq
+            self._store_block(k[:, :, :nq].contiguous(), v[:, :, :nq].contiguous(), 0)
+        self.n_win = T - nq
+        if self.n_win:
+            self.kwin[:, :, :self.n_win] = k[:, :, nq:]
+            self.vwin[:, :, :self.n_win] = v[:, :, nq:]
+
+    def append_rope(self, qkv: torch.Tensor, n_q_heads: int, pos: int, theta: float) -> torch.Tensor:
+        """qkv fp16 [B, (Hq + 2 Hkv) * 128] of the new token -> RoPE, k / v into the window; returns q [B,Hq,1,128]."""
+        q = torch.empty((self.B, n_q_heads, 1, self.D), dtype=torch.float16, device=qkv.device)
+        rc = L.load().gear_rope_append(L.ptr(qkv), self.B, n_q_heads, self.H, self.D, pos, theta, L.ptr(q), L.ptr(self.kwin),
+                                       L.ptr(self.vwin), self.n_win, self.R, L.stream_ptr())
+        L.check(rc, "gear_rope_append")
+        self.n_win += 1
+        return q
+
+    def append(self, k_new: torch.Tensor, v_new: torch.Tensor):
+        """k_new, v_new fp16 [B,Hkv,1,128] (already rotated) into the window."""
+        self.kwin[:, :, self.n_win] = k_new[:, :, 0]
+        self.vwin[:, :, self.n_win] = v_new[:, :, 0]
+        self.n_win += 1
+
+    def attend(self, q: torch.Tensor) -> torch.Tensor:
+        """q fp16 [B,Hq,1,128] -> softmax(q Khat^T / sqrt(128)) Vhat over compressed + window tokens, fp16 [B,Hq,1,128]."""
+        B, Hq = q.shape[0], q.shape[1]
+        lib = L.load()
+        out = torch.empty((B, Hq, 1, self.D), dtype=torch.float16, device=q.device)
+        wsb = lib.gear_attn_decode_workspace(B, Hq, self.Tmax, self.bits)
+        if self._ws is None or self._ws.numel() < wsb:
+            self._ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
+        p = L.ptr
+        T = self.n_comp
+        rc = lib.gear_attn_decode_seg(
+            p(q), p(self.kcode), p(self.kscale), p(self.kmn), p(self.kPseg), p(self.kQtok), None, None,
+            p(self.vcode), p(self.vscale), p(self.vmn), p(self.vPseg), p(self.vQtok), None, None,
+            p(self.kwin) if self.n_win else None, p(self.vwin) if self.n_win else None,
+            B, Hq, self.H, self.D, T, self.n_win, self.Tmax // self.fpi, self.Tmax // self.group, self.Tmax, self.Tmax,
+            self.Tmax, self.group, self.bits, 0, self.rk, self.rv, 0, 0, self.seg0, self.R if self.lowrank else 0, self.R,
+            1.0 / math.sqrt(self.D), p(out), None, p(self._ws), self._ws.numel(), L.stream_ptr())
+        L.check(rc, "gear_attn_decode_seg")
+        return out
+
+    def maybe_compress(self):
+        """Compress the window when it holds `residual` tokens (modeling_llamagear.py:265, :335)."""
+        if self.n_win == self.R:
+            self._store_block(self.kwin, self.vwin, self._segment_of(self.n_comp))
+            self.n_win = 0

@@ -46,6 +46,9 @@ struct AttnArgs {
     int ldk, lsk;            // K code / scale row pitch
     int tcap_v, tf_k, tf_v;  // token capacity (row count) of V tensors / factor tensors
     int group, rk, rv, kk, kv;
+    int seg0, seglen;        // low-rank factor segments: tokens [0, seg0) use channel factors #0, then one set per `seglen`
+                             // tokens (seglen == 0: a single segment).  kP / vP are [nseg, B*Hkv, 128, r].
+    int64_t kP_seg_stride, vP_seg_stride;
     int tc, splits;
     float qscale;
     float* part_o;           // [B*Hq, splits, 128]
@@ -85,11 +88,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     constexpr int NWV = AD / CPW;  // packed words per V token row
+    constexpr int MAXSEG = TC_MAX / 64 + 2;
     __shared__ float qs[AD];
-    __shared__ float u[16];
+    __shared__ float u[MAXSEG][16];
     __shared__ float s[TC_MAX];
     __shared__ float oacc[AD];
-    __shared__ float wacc[16];
+    __shared__ float wacc[MAXSEG][16];
     __shared__ float red[4];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,13 +114,18 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
         qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
         oacc[tid] = 0.0f;
     }
-    if (tid < 16) wacc[tid] = 0.0f;
+    // factor segments touched by this chunk
+    auto seg_of = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
+    const int seg_first = seg_of(t0), nseg_c = seg_of(t0 + tn - 1) - seg_first + 1;
+    for (int i = tid; i < MAXSEG * 16; i += 256) (&wacc[0][0])[i] = 0.0f;
     for (int i = tid; i < a.tc; i += 256) s[i] = 0.0f;
     __syncthreads();
-    if (tid < a.rk) {  // u = Pk^T q
+    for (int i = tid; i < nseg_c * a.rk; i += 256) {  // u[seg] = Pk[seg]^T q
+        const int sl = i / a.rk, c = i % a.rk;
+        const uint16_t* pk = a.kP + (int64_t)(seg_first + sl) * a.kP_seg_stride + bhk * AD * a.rk;
         float acc = 0.0f;
-        for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(a.kP[(bhk * AD + d) * a.rk + tid]), acc);
-        u[tid] = acc;
+        for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(pk[d * a.rk + c]), acc);
+        u[sl][c] = acc;
     }
     // ------------------------------------------------------------------ 1. K side
     {
@@ -155,8 +164,9 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     if (a.rk > 0) {
         for (int t = tid; t < tn; t += 256) {
             const uint16_t* qp = a.kQ + (bhk * a.tf_k + t0 + t) * (int64_t)a.rk;
+            const float* us = u[seg_of(t0 + t) - seg_first];
             float acc = 0.0f;
-            for (int c = 0; c < a.rk; c++) acc = fmaf(h2f_bits(qp[c]), u[c], acc);
+            for (int c = 0; c < a.rk; c++) acc = fmaf(h2f_bits(qp[c]), us[c], acc);
             s[t] += acc;
         }
     }
@@ -221,25 +231,31 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
             if (lane < NWV) atomicAdd(&oacc[wv * CPW + j], v);
         }
     }
-    // w = Qv^T p (low-rank term of V, applied after the merge)
+    // w[seg] = Qv^T p per factor segment: 64-token slabs (aligned, never straddle a segment) go round-robin to the
+    // waves; the term Pv[seg] w[seg] is added to the partial output below (the unnormalised partial is linear in p)
     if (a.rv > 0) {
-        float wl[16];
+        const int wave = tid >> 6;
+        for (int sb = wave * 64; sb < tn; sb += 256) {
+            const int t = sb + lane;
+            float wl[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) wl[c] = 0.0f;
-        for (int t = tid; t < tn; t += 256) {
-            const uint16_t* qp = a.vQ + (bhk * a.tf_v + t0 + t) * (int64_t)a.rv;
-            const float p = s[t];
+            for (int c = 0; c < 16; c++) wl[c] = 0.0f;
+            if (t < tn) {
+                const uint16_t* qp = a.vQ + (bhk * a.tf_v + t0 + t) * (int64_t)a.rv;
+                const float p = s[t];
 #pragma unroll
-            for (int c = 0; c < 16; c++)
-                if (c < a.rv) wl[c] = fmaf(p, h2f_bits(qp[c]), wl[c]);
-        }
+                for (int c = 0; c < 16; c++)
+                    if (c < a.rv) wl[c] = p * h2f_bits(qp[c]);
+            }
+            const int sl = seg_of(t0 + sb) - seg_first;
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            if (c < a.rv) {
-                float v = wl[c];
+            for (int c = 0; c < 16; c++) {
+                if (c < a.rv) {
+                    float v = wl[c];
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                if (lane == 0) atomicAdd(&wacc[c], v);
+                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                    if (lane == 0) atomicAdd(&wacc[sl][c], v);
+                }
             }
         }
     }
@@ -269,8 +285,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     }
     __syncthreads();
     const int64_t po = bhq * a.splits + split;
-    if (tid < AD) a.part_o[po * AD + tid] = oacc[tid];
-    if (tid < 16) a.part_w[po * 16 + tid] = wacc[tid];
+    if (tid < AD) {
+        float o = oacc[tid];
+        for (int sl = 0; sl < nseg_c && a.rv > 0; sl++) {
+            const uint16_t* pv = a.vP + (int64_t)(seg_first + sl) * a.vP_seg_stride + (bhk * AD + tid) * a.rv;
+            for (int c = 0; c < a.rv; c++) o = fmaf(h2f_bits(pv[c]), wacc[sl][c], o);
+        }
+        a.part_o[po * AD + tid] = o;
+    }
     if (tid == 0) {
         a.part_ml[po * 2] = m;
         a.part_ml[po * 2 + 1] = l;
@@ -279,11 +301,10 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
 
 // merge the splits + the fp16 window, apply the V low-rank factor, normalise.  grid (B*Hq), block 128.
 __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
-                                                                 const uint16_t* __restrict__ vwin, int W,
+                                                                 const uint16_t* __restrict__ vwin, int W, int wcap,
                                                                  uint16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ float qs[AD];
     __shared__ float sw[64];
-    __shared__ float wsum[16];
     __shared__ float coef[64 + 64];  // per split, then per window token
     __shared__ float stat[2];
     const int tid = threadIdx.x;
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, con
     qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
     __syncthreads();
     if (tid < W) {
-        const uint16_t* kr = kwin + (bhk * W + tid) * (int64_t)AD;
+        const uint16_t* kr = kwin + (bhk * wcap + tid) * (int64_t)AD;
         float acc = 0.0f;
         for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(kr[d]), acc);
         sw[tid] = acc;
@@ -320,16 +341,9 @@ __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, con
         stat[1] = Lsum;
     }
     __syncthreads();
-    if (tid < 16) {
-        float acc = 0.0f;
-        for (int i = 0; i < ns; i++) acc = fmaf(coef[i], a.part_w[(bhq * a.splits + i) * 16 + tid], acc);
-        wsum[tid] = acc;
-    }
-    __syncthreads();
     float o = 0.0f;
     for (int i = 0; i < ns; i++) o = fmaf(coef[i], a.part_o[(bhq * a.splits + i) * AD + tid], o);
-    for (int c = 0; c < a.rv && ns > 0; c++) o = fmaf(h2f_bits(a.vP[(bhk * AD + tid) * a.rv + c]), wsum[c], o);
-    for (int j = 0; j < W; j++) o = fmaf(coef[64 + j], h2f_bits(vwin[(bhk * W + j) * (int64_t)AD + tid]), o);
+    for (int j = 0; j < W; j++) o = fmaf(coef[64 + j], h2f_bits(vwin[(bhk * wcap + j) * (int64_t)AD + tid]), o);
     out[bhq * AD + tid] = f2h_bits(o / stat[1]);
     if (lse && tid == 0) lse[bhq] = stat[0] + logf(stat[1]);
 }
@@ -355,13 +369,16 @@ extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
     return (size_t)B * Hq * splits * (AD + 16 + 2) * sizeof(float) + 256;
 }
 
-extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
                                 const void* kQ, const void* koidx, const void* koval, const void* vcode,
                                 const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
                                 const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T,
                                 int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
-                                int rk, int rv, int kk, int kv, float qscale, void* out, void* lse, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, float qscale, void* out,
+                                void* lse, void* workspace, size_t workspace_bytes, void* stream) {
+    GEAR_CHECK_ARG(wcap >= W, "gear_attn_decode: window pitch %d smaller than the window %d", wcap, W);
+    GEAR_CHECK_ARG(seglen == 0 || (seglen % 64 == 0 && seg0 % 64 == 0 && seg0 >= 0),
+                   "gear_attn_decode: factor segments must be multiples of 64 tokens (seg0=%d seglen=%d)", seg0, seglen);
     GEAR_CHECK_ARG(D == AD, "gear_attn_decode: head_dim must be 128 (got %d)", D);
     GEAR_CHECK_ARG(bits == 2 || bits == 4, "gear_attn_decode: bits must be 2 or 4 (got %d)", bits);
     GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_attn_decode: bad mode %d", mode);
@@ -388,6 +405,9 @@ extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* ks
     a.group = group; a.rk = (kP && kQ) ? rk : 0; a.rv = (vP && vQ) ? rv : 0;
     a.kk = (koidx && koval) ? kk : 0; a.kv = (voidx && voval) ? kv : 0;
     a.qscale = qscale;
+    a.seg0 = seg0; a.seglen = seglen;
+    a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
+    a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
     a.splits = plan_splits(T, bits, (int64_t)B * Hq, &a.tc);
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     a.part_o = ws;
@@ -403,7 +423,19 @@ extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* ks
         GEAR_CHECK_LAUNCH("gear_attn_decode(partial)");
     }
     hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(128), 0, st, a, (const uint16_t*)kwin,
-                       (const uint16_t*)vwin, W, (uint16_t*)out, (float*)lse);
+                       (const uint16_t*)vwin, W, wcap, (uint16_t*)out, (float*)lse);
     GEAR_CHECK_LAUNCH("gear_attn_decode(reduce)");
     return 0;
+}
+
+extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                                const void* kQ, const void* koidx, const void* koval, const void* vcode,
+                                const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
+                                const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T,
+                                int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
+                                int rk, int rv, int kk, int kv, float qscale, void* out, void* lse, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return gear_attn_decode_seg(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin,
+                                vwin, B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv, kk, kv,
+                                0, 0, W, qscale, out, lse, workspace, workspace_bytes, stream);
 }

@@ -1,0 +1,117 @@
+"""Fast single-token decode over GearKVCache: ~10 launches per layer instead of the ~60 eager torch ops the attention
+hook's forward issues per layer per token (cuda_supported_gear/modeling_llamagear.py:177-484 + decoder layer :502-560).
+
+Takes the weights of a LlamaForCausalLM_GEARKIVI (any loader that fills that module works), fuses q/k/v and gate/up
+projections into single GEMV weights, keeps the KV cache in GearKVCache (pre-allocated, kernel-native) and runs
+    add+rmsnorm -> qkv GEMV -> RoPE+append -> fused attention over the compressed cache (2 launches) -> o_proj
+    -> add+rmsnorm -> gate/up GEMV -> silu*mul -> down GEMV
+per layer.  The GEMVs are plain library GEMVs through torch (F.linear); everything touching the cache is HIP.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .cache import GearKVCache
+from .modeling_llamagear import apply_rotary_pos_emb
+
+
+class FastGearDecoder:
+    def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0):
+        self.model = model
+        cfg = model.config
+        self.cfg = cfg
+        self.Hq, self.Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.D = cfg.hidden_size // cfg.num_attention_heads
+        self.eps = cfg.rms_norm_eps
+        self.theta = float(cfg.rope_theta)
+        dev = model.lm_head.weight.device
+        self.dev = dev
+        self.layers = []
+        for i, layer in enumerate(model.model.layers):
+            at, mlp = layer.self_attn, layer.mlp
+            assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
+            self.layers.append(dict(
+                wqkv=torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], 0).contiguous(),
+                wo=at.o_proj.weight, wgu=torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], 0).contiguous(),
+                wd=mlp.down_proj.weight, n1=layer.input_layernorm.weight, n2=layer.post_attention_layernorm.weight,
+                cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i),
+                rotary=at.rotary_emb))
+        self.pos = 0
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _add_rmsnorm(self, res, delta, w):
+        B, H = res.shape
+        y = torch.empty_like(res)
+        res_out = torch.empty_like(res) if delta is not None else None
+        rc = L.load().gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(w), B, H, self.eps, L.ptr(res_out), L.ptr(y), L.stream_ptr())
+        L.check(rc, "gear_add_rmsnorm")
+        return (res_out if delta is not None else res), y
+
+    def _silu_mul(self, gu):
+        B, I2 = gu.shape
+        out = torch.empty((B, I2 // 2), dtype=gu.dtype, device=gu.device)
+        rc = L.load().gear_silu_mul(L.ptr(gu), B, I2 // 2, L.ptr(out), L.stream_ptr())
+        L.check(rc, "gear_silu_mul")
+        return out
+
+    # ------------------------------------------------------------------------------------------------ prefill
+    @torch.no_grad()
+    def prefill(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """Dense causal attention over the prompt (torch SDPA), compress each layer's K/V into its cache.
+        Returns the logits of the last position [B, vocab]."""
+        B, T = input_ids.shape
+        m = self.model.model
+        h = m.embed_tokens(input_ids)
+        pos = torch.arange(T, device=self.dev).unsqueeze(0)
+        n_rep = self.Hq // self.Hkv
+        for lw, layer in zip(self.layers, m.layers):
+            x = layer.input_layernorm(h)
+            qkv = F.linear(x, lw["wqkv"])
+            q, k, v = qkv.split([self.Hq * self.D, self.Hkv * self.D, self.Hkv * self.D], dim=-1)
+            q = q.view(B, T, self.Hq, self.D).transpose(1, 2)
+            k = k.view(B, T, self.Hkv, self.D).transpose(1, 2)
+            v = v.view(B, T, self.Hkv, self.D).transpose(1, 2)
+            cos, sin = lw["rotary"](v, pos)
+            q, k = apply_rotary_pos_emb(q, k, cos, sin)
+            lw["cache"].prefill(k, v)
+            kk = k if n_rep == 1 else k.repeat_interleave(n_rep, 1)
+            vv = v if n_rep == 1 else v.repeat_interleave(n_rep, 1)
+            a = F.scaled_dot_product_attention(q, kk, vv, is_causal=True)
+            h = h + F.linear(a.transpose(1, 2).reshape(B, T, self.Hq * self.D), lw["wo"])
+            h = h + layer.mlp(layer.post_attention_layernorm(h))
+        self.pos = T
+        return self.model.lm_head(m.norm(h[:, -1]))
+
+    # ------------------------------------------------------------------------------------------------ decode
+    @torch.no_grad()
+    def step(self, token_ids: torch.Tensor) -> torch.Tensor:
+        """token_ids [B, 1] (or [B]) -> logits [B, vocab]; advances every layer's cache by one token."""
+        m = self.model.model
+        res = m.embed_tokens(token_ids.view(-1))            # [B, hidden]
+        delta = None
+        for lw in self.layers:
+            res, x = self._add_rmsnorm(res, delta, lw["n1"])
+            qkv = F.linear(x, lw["wqkv"])
+            cache = lw["cache"]
+            q = cache.append_rope(qkv, self.Hq, self.pos, self.theta)
+            a = cache.attend(q)
+            cache.maybe_compress()
+            attn = F.linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
+            res, x = self._add_rmsnorm(res, attn, lw["n2"])
+            delta = F.linear(self._silu_mul(F.linear(x, lw["wgu"])), lw["wd"])
+        res, x = self._add_rmsnorm(res, delta, m.norm.weight)
+        self.pos += 1
+        return self.model.lm_head(x)
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, max_length: int) -> torch.Tensor:
+        logits = self.prefill(input_ids)
+        out = [input_ids]
+        nxt = logits.argmax(-1, keepdim=True)
+        out.append(nxt)
+        while sum(t.shape[1] for t in out) < max_length:
+            nxt = self.step(nxt).argmax(-1, keepdim=True)
+            out.append(nxt)
+        return torch.cat(out, dim=1)

@@ -161,6 +161,33 @@ int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const
                      int tf_v, int group, int bits, int mode, int rk, int rv, int kk, int kv, float qscale, void* out,
                      void* lse, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- decode attention with per-segment low-rank factors (the streaming cache of the attention hook) ----------
+ * As gear_attn_decode, but the channel-side factors kP / vP are [nseg, B*Hkv, 128, r]: tokens [0, seg0) use set 0 (the
+ * prefill block, cuda_supported_gear/modeling_llamagear.py:402-434), every following `seglen` tokens their own set (the
+ * 64-token decode blocks stacked on a leading buffer dim in the reference, :276-286).  seglen == 0: one segment.
+ * wcap: row pitch (tokens) of kwin / vwin, >= W (a pre-allocated window buffer).
+ */
+int gear_attn_decode_seg(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                         const void* kQ, const void* koidx, const void* koval, const void* vcode, const void* vscale,
+                         const void* vmn, const void* vP, const void* vQ, const void* voidx, const void* voval,
+                         const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T, int W, int ldk, int lsk,
+                         int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv, int kk, int kv,
+                         int seg0, int seglen, int wcap, float qscale, void* out, void* lse, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ---- per-token glue of a decode step (one launch each) ---------------------------------------------------------
+ * gear_rope_append: qkv fp16 [B, (Hq + 2 Hkv) * 128] (fused q/k/v projection of the new token) -> RoPE at `pos` on q and k
+ *   (modeling_llamagear.py:203-205), q_out fp16 [B, Hq, 128], k / v written to slot `slot` of the fp16 residual window
+ *   kwin / vwin [B*Hkv, W, 128] (the torch.cat of :256, :316).
+ * gear_add_rmsnorm: res_out = res_in + delta (delta may be NULL), y = weight * rmsnorm(res_out)   (LlamaRMSNorm + residual)
+ * gear_silu_mul: out = silu(gate) * up for gate_up = [B, 2 I]                                         (LlamaMLP)
+ */
+int gear_rope_append(const void* qkv, int B, int Hq, int Hkv, int D, int pos, float theta, void* q_out, void* kwin,
+                     void* vwin, int slot, int W, void* stream);
+int gear_add_rmsnorm(const void* res_in, const void* delta, const void* weight, int64_t rows, int H, float eps,
+                     void* res_out, void* y, void* stream);
+int gear_silu_mul(const void* gate_up, int64_t B, int I, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+"""GPU tests of the fast decode path: pre-allocated GearKVCache + segment-aware fused attention + the per-token glue
+kernels (gear_amd/cache.py, gear_amd/fast_decode.py, csrc/decode_ops.hip)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _reconstruct_cache(c):
+    """float64 [B,H,n_comp,128] K and V from the cache buffers (dequant + per-segment Q P^T)."""
+    n, g, b = c.n_comp, c.group, c.bits
+    fpi = 32 // b
+    kq = orc.unpack_tensor(host(c.kcode[:, :, :, :n // fpi]), b, 3).astype(np.float64)                # [B,H,D,n]
+    K = (kq * np.repeat(host(c.kscale[:, :, :, :n // g]).astype(np.float64), g, 3)
+         + np.repeat(host(c.kmn[:, :, :, :n // g]).astype(np.float64), g, 3)).transpose(0, 1, 3, 2)
+    vq = orc.unpack_tensor(host(c.vcode[:, :, :n]), b, 3).astype(np.float64)                           # [B,H,n,D]
+    V = vq * np.repeat(host(c.vscale[:, :, :n]).astype(np.float64), g, 3) + np.repeat(host(c.vmn[:, :, :n]).astype(np.float64), g, 3)
+    if c.lowrank:
+        t = 0
+        while t < n:
+            seg = c._segment_of(t)
+            te = c.seg0 if seg == 0 else min(n, t + c.R)
+            K[:, :, t:te] += host(c.kQtok[:, :, t:te]).astype(np.float64) @ host(c.kPseg[seg]).astype(np.float64).transpose(0, 1, 3, 2)
+            V[:, :, t:te] += host(c.vQtok[:, :, t:te]).astype(np.float64) @ host(c.vPseg[seg]).astype(np.float64).transpose(0, 1, 3, 2)
+            t = te
+    return K, V
+
+
+def _ref_attn(q, K, V, kw, vw, n_rep):
+    K = np.concatenate([K, kw.astype(np.float64)], 2)
+    V = np.concatenate([V, vw.astype(np.float64)], 2)
+    K, V = np.repeat(K, n_rep, 1), np.repeat(V, n_rep, 1)
+    s = np.einsum("bhd,bhtd->bht", q.astype(np.float64)[:, :, 0], K) / math.sqrt(128)
+    s -= s.max(-1, keepdims=True)
+    a = np.exp(s)
+    a /= a.sum(-1, keepdims=True)
+    return np.einsum("bht,bhtd->bhd", a, V)[:, :, None]
+
+
+@pytest.mark.parametrize("method,bits,Hq,Hkv,T0", [("gearlKIVI", 2, 4, 4, 200), ("gearlKIVI", 4, 4, 2, 64), ("KIVI", 2, 2, 2, 30),
+                                                   ("gearlKIVI", 2, 2, 2, 2304)])
+def test_cache_attend_matches_reconstruction(method, bits, Hq, Hkv, T0):
+    from gear_amd.cache import GearKVCache
+    torch.manual_seed(71)
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
+    B, D, steps = 2, 128, 150
+    c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
+    c.prefill(torch.randn(B, Hkv, T0, D).half().cuda(), torch.randn(B, Hkv, T0, D).half().cuda())
+    assert c.n_comp == T0 - T0 % 64 and c.n_win == T0 % 64
+    worst = 0.0
+    for i in range(steps):
+        c.append(torch.randn(B, Hkv, 1, D).half().cuda(), torch.randn(B, Hkv, 1, D).half().cuda())
+        q = torch.randn(B, Hq, 1, D).half().cuda()
+        out = c.attend(q)
+        if i % 13 == 0 or c.n_win == 64 or c.n_win == 1:
+            K, V = _reconstruct_cache(c)
+            ref = _ref_attn(host(q), K, V, host(c.kwin[:, :, :c.n_win]), host(c.vwin[:, :, :c.n_win]), Hq // Hkv)
+            worst = max(worst, rel_fro(host(out).astype(np.float64), ref))
+        c.maybe_compress()
+        assert c.seq_len == T0 + i + 1 and c.n_win < 64
+    assert worst < 2e-3, worst
+    assert c.n_comp == (T0 + steps) - (T0 + steps) % 64
+
+
+def test_glue_kernels_match_torch():
+    from gear_amd import _lib as L
+    from gear_amd.cache import GearKVCache
+    from gear_amd.modeling_llamagear import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb
+    torch.manual_seed(72)
+    B, Hq, Hkv, D = 2, 4, 2, 128
+    cc = dict(compress_method="KIVI", group_size=64, residual=64, quantize_bit=2, rank=0, rankv=0, loop=0)
+    c = GearKVCache(B, Hkv, 256, cc, "cuda")
+    rot = LlamaRotaryEmbedding(D, 4096, 10000.0).cuda()
+    for pos in (0, 1, 777, 4095):
+        c.n_win = 5
+        qkv = torch.randn(B, (Hq + 2 * Hkv) * D).half().cuda()
+        q = c.append_rope(qkv, Hq, pos, 10000.0)
+        qq, kk, vv = qkv.split([Hq * D, Hkv * D, Hkv * D], -1)
+        qq, kk, vv = qq.view(B, 1, Hq, D).transpose(1, 2), kk.view(B, 1, Hkv, D).transpose(1, 2), vv.view(B, 1, Hkv, D).transpose(1, 2)
+        cos, sin = rot(vv, torch.tensor([[pos]], device="cuda"))
+        qr, kr = apply_rotary_pos_emb(qq, kk, cos, sin)
+        assert float((q.float() - qr.float()).abs().max()) < 4e-3 * max(1.0, float(qr.abs().max()))
+        assert float((c.kwin[:, :, 5].float() - kr[:, :, 0].float()).abs().max()) < 4e-3 * max(1.0, float(kr.abs().max()))
+        assert torch.equal(c.vwin[:, :, 5], vv[:, :, 0])
+    # add + rmsnorm
+    lib = L.load()
+    H = 512
+    res, delta = torch.randn(3, H).half().cuda(), torch.randn(3, H).half().cuda()
+    norm = LlamaRMSNorm(H, 1e-5).half().cuda()
+    norm.weight.data = torch.randn(H).half().cuda()
+    y, ro = torch.empty_like(res), torch.empty_like(res)
+    L.check(lib.gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(norm.weight), 3, H, 1e-5, L.ptr(ro), L.ptr(y), L.stream_ptr()), "n")
+    assert torch.equal(ro, res + delta)
+    ref = norm(res + delta)
+    assert float((y.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+    # silu * up
+    gu = torch.randn(3, 2 * 300).half().cuda()
+    out = torch.empty(3, 300).half().cuda()
+    L.check(lib.gear_silu_mul(L.ptr(gu), 3, 300, L.ptr(out), L.stream_ptr()), "s")
+    ref = torch.nn.functional.silu(gu[:, :300]) * gu[:, 300:]
+    assert float((out.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def _tiny(method):
+    from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
+    cfg = LlamaConfigLite(vocab_size=1000, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                          num_attention_heads=4, num_key_value_heads=2, k_bits=4, v_bits=4)
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=4, rank=4, rankv=4, loop=3)
+    torch.manual_seed(0)
+    return LlamaForCausalLM_GEARKIVI(cfg, cc).half().cuda().eval()
+
+
+def test_fast_decoder_tracks_the_attention_hook_module():
+    """Quantization-only cache (no random bases): the fast path and the reference-shaped module see the same tokens and
+    must produce near-identical logits over a decode run that crosses two block boundaries."""
+    from gear_amd.fast_decode import FastGearDecoder
+    model = _tiny("KIVI")
+    ids = torch.randint(0, 1000, (1, 100)).cuda()
+    fast = FastGearDecoder(model, 512)
+    with torch.no_grad():
+        lf = fast.prefill(ids)
+        lm, past = model(ids, None, True)
+        cos = torch.nn.functional.cosine_similarity(lf.float(), lm[:, -1].float()).min()
+        assert cos > 0.999, cos
+        tok = lm[:, -1].argmax(-1, keepdim=True)
+        worst = 1.0
+        for i in range(100):
+            lf = fast.step(tok)
+            lm, past = model(tok, past, True)
+            worst = min(worst, float(torch.nn.functional.cosine_similarity(lf.float(), lm[:, -1].float()).min()))
+            tok = lm[:, -1].argmax(-1, keepdim=True)
+        assert worst > 0.995, worst
+    assert fast.layers[0]["cache"].n_comp == 192 and fast.layers[0]["cache"].n_win == 8
+
+
+def test_fast_decoder_generate_lowrank_deterministic():
+    from gear_amd.fast_decode import FastGearDecoder
+    model = _tiny("gearlKIVI")
+    ids = torch.randint(0, 1000, (2, 70)).cuda()
+    a = FastGearDecoder(model, 256, batch=2, seed=3).generate(ids, 200)
+    b = FastGearDecoder(model, 256, batch=2, seed=3).generate(ids, 200)
+    assert a.shape == (2, 200) and torch.equal(a, b) and torch.equal(a[:, :70], ids)
