@@ -53,11 +53,32 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     constexpr int RVS = RV > 0 ? RV : 1;
+    extern __shared__ uint32_t dsm[];   // [rpb][len/32] outlier bitmaps, then [rpb][len] fp16 outlier values
     const int tid = threadIdx.x;
     const int j0 = tid * 16;
     const bool active = j0 < g.len;
     const int64_t row0 = (int64_t)blockIdx.x * g.rpb;
     const int r = g.r;
+    const int mwords = g.len / 32;       // len is a multiple of 16; bitmaps are read 16 bits at a time
+    uint32_t* lmask = dsm;
+    uint16_t* lval = (uint16_t*)(dsm + (size_t)g.rpb * (mwords + 1));
+    if (g.k > 0) {
+        // the sparse part of all rows of the block goes to LDS once: the dense pass then patches its own elements and
+        // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each)
+        for (int i = tid; i < g.rpb * (mwords + 1); i += blockDim.x) lmask[i] = 0u;
+        __syncthreads();
+        const int per_row = 2 * g.k;
+        for (int e = tid; e < g.rpb * per_row; e += blockDim.x) {
+            const int ri = e / per_row;
+            const int64_t row = row0 + ri;
+            if (row < g.n_rows) {
+                const uint32_t idx = oidx[row * per_row + e % per_row];
+                atomicOr(&lmask[ri * (mwords + 1) + (idx >> 5)], 1u << (idx & 31));
+                lval[(size_t)ri * g.len + idx] = oval[row * per_row + e % per_row];
+            }
+        }
+        __syncthreads();
+    }
     // all rows of the block share the outer index (rpb divides rows_inner)
     const int ro = (int)(row0 / g.rows_inner);
     const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
@@ -108,6 +129,14 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             for (int j = 0; j < CPW; j++) {
                 float d = dequant_one<MODE>((int)((cur.words[w] >> (BITS * j)) & MASK), cur.s, cur.m);
                 f[w * CPW + j] = (MODE == 0) ? d : hround(d);
+            }
+        }
+        if (g.k > 0) {   // outlier elements: the stored value replaces the dequantized one (the low-rank term still adds)
+            const uint32_t mb = (lmask[ri * (mwords + 1) + (j0 >> 5)] >> (j0 & 31)) & 0xFFFFu;
+            if (mb) {
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (mb & (1u << j)) f[j] = h2f_bits(lval[(size_t)ri * g.len + j0 + j]);
             }
         }
         if (r > 0) {
@@ -205,13 +234,15 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
     int rpb = 8;
-    while (rpb > 1 && rows_inner % rpb != 0) rpb >>= 1;
+    while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 48 * 1024))) rpb >>= 1;
+    const size_t shmem = k > 0 ? (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) : 0;
+    GEAR_CHECK_ARG(shmem <= 64 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
     DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));
 #define GOT(B, M, STT, KD, RVV, TBB)                                                                                    \
-    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV, TBB>), grid, block, 0, st, (const uint32_t*)code,    \
+    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV, TBB>), grid, block, shmem, st, (const uint32_t*)code,    \
                        (const STT*)scale, (const STT*)mn, g, (const uint16_t*)P, (const uint16_t*)Q,                    \
                        (const uint16_t*)oidx, (const uint16_t*)oval, (uint16_t*)out)
 #define GO(B, M, STT, KD, RVV) do { if (threads <= 256) GOT(B, M, STT, KD, RVV, 256); else if (threads <= 512) GOT(B, M, STT, KD, RVV, 512); \
@@ -233,16 +264,5 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
 #undef GO
 #undef GOT
     GEAR_CHECK_LAUNCH("gear_decompress_rows");
-    if (k > 0) {
-        const int64_t n_ent = n_rows * 2 * (int64_t)k;
-        dim3 sg((unsigned)((n_ent + 255) / 256));
-#define GS(KD, RVV) hipLaunchKernelGGL((decompress_sparse_kernel<KD, RVV>), sg, dim3(256), 0, st, g, (const uint16_t*)P, \
-                                       (const uint16_t*)Q, (const uint16_t*)oidx, (const uint16_t*)oval, (uint16_t*)out)
-#define GSR(KD) do { if (r == 8) GS(KD, 8); else if (r == 4) GS(KD, 4); else if (r == 16) GS(KD, 16); else GS(KD, 0); } while (0)
-        if (kind == 0) GSR(0); else GSR(1);
-#undef GSR
-#undef GS
-        GEAR_CHECK_LAUNCH("gear_decompress_rows(sparse)");
-    }
     return 0;
 }
