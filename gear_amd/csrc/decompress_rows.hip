@@ -234,14 +234,17 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
     int rpb = 8;
-    while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 48 * 1024))) rpb >>= 1;
+    while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024))) rpb >>= 1;
     const size_t shmem = k > 0 ? (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) : 0;
-    GEAR_CHECK_ARG(shmem <= 64 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
+    GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
     DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));
 #define GOT(B, M, STT, KD, RVV, TBB)                                                                                    \
+    if (shmem > 48 * 1024)                                                                                              \
+        (void)hipFuncSetAttribute((const void*)decompress_rows_kernel<B, M, STT, KD, RVV, TBB>,                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                              \
     hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV, TBB>), grid, block, shmem, st, (const uint32_t*)code,    \
                        (const STT*)scale, (const STT*)mn, g, (const uint16_t*)P, (const uint16_t*)Q,                    \
                        (const uint16_t*)oidx, (const uint16_t*)oval, (uint16_t*)out)
