@@ -242,12 +242,14 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));
 #define GOT(B, M, STT, KD, RVV, TBB)                                                                                    \
-    if (shmem > 48 * 1024)                                                                                              \
-        (void)hipFuncSetAttribute((const void*)decompress_rows_kernel<B, M, STT, KD, RVV, TBB>,                         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                              \
-    hipLaunchKernelGGL((decompress_rows_kernel<B, M, STT, KD, RVV, TBB>), grid, block, shmem, st, (const uint32_t*)code,    \
-                       (const STT*)scale, (const STT*)mn, g, (const uint16_t*)P, (const uint16_t*)Q,                    \
-                       (const uint16_t*)oidx, (const uint16_t*)oval, (uint16_t*)out)
+    do {                                                                                                                \
+        auto kfn = decompress_rows_kernel<B, M, STT, KD, RVV, TBB>;                                                     \
+        if (shmem > 48 * 1024)                                                                                          \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);        \
+        hipLaunchKernelGGL(kfn, grid, block, shmem, st, (const uint32_t*)code, (const STT*)scale, (const STT*)mn, g,     \
+                           (const uint16_t*)P, (const uint16_t*)Q, (const uint16_t*)oidx, (const uint16_t*)oval,        \
+                           (uint16_t*)out);                                                                             \
+    } while (0)
 #define GO(B, M, STT, KD, RVV) do { if (threads <= 256) GOT(B, M, STT, KD, RVV, 256); else if (threads <= 512) GOT(B, M, STT, KD, RVV, 512); \
                                     else GOT(B, M, STT, KD, RVV, 1024); } while (0)
 #define GOR(B, M, STT, KD) do { if (r == 8) GO(B, M, STT, KD, 8); else if (r == 4) GO(B, M, STT, KD, 4); \
