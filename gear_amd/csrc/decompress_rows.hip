@@ -233,7 +233,7 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
-    int rpb = 8;
+    int rpb = (r > 0 || k == 0) ? 8 : 4;   // without factors the registers are free: prefer occupancy over LDS table size
     while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024))) rpb >>= 1;
     const size_t shmem = k > 0 ? (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
