@@ -21,6 +21,7 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 constexpr int GD = 128;          // head_dim (the Gram trick is built for 128)
 constexpr int KT_PITCH = 72;     // halfs per LDS row of the K^T staging tile [128][64 (+8 pad)]
 constexpr int TM_PITCH = 136;    // halfs per LDS row of the token-major staging tile [64][128 (+8 pad)]
+constexpr int GP = 129;          // float pitch of G in LDS: rows AND columns are bank-conflict-free
 
 __host__ __device__ constexpr int blk_index(int I, int J) {  // upper-triangular block (I <= J) -> 0..9
     return I * 4 - (I * (I - 1)) / 2 + (J - I);
@@ -34,9 +35,9 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
                                                                float* __restrict__ Wout, void* __restrict__ P_out,
                                                                int out_f16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* G = (float*)smem;                                  // [128][128]
+    float* G = (float*)smem;                                  // [128][GP]
     uint16_t* tile = (uint16_t*)smem;                         // staging (aliases G during phase 1)
-    float* Pa = (float*)(smem + GD * GD * 4);                 // [128][RP]
+    float* Pa = (float*)(smem + GD * GP * 4);                 // [128][RP]
     float* Pb = Pa + GD * RP;                                 // [128][RP]
     double* Md = (double*)(Pb + GD * RP);                     // [RP][RP]
     double* Rinv = Md + RP * RP;                              // [RP][RP]
@@ -123,22 +124,32 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
             tile_mfma();
         }
     }
-    __syncthreads();
-    for (int i = tid; i < GD * GD; i += 256) G[i] = 0.0f;
-    __syncthreads();
-    // C layout of the 32x32 MFMA: lane l, reg q -> row (q&3) + 8*(q>>2) + 4*(l>>5), col l&31
+    // the four waves hold partial Gram matrices over disjoint token subsets: add them into LDS one wave at a time
+    // (deterministic, no fp32 LDS atomics); the mirrored lower blocks are written too -- with pitch 129 neither the
+    // row-wise nor the column-wise accesses conflict.  C layout of the 32x32 MFMA: lane l, reg q ->
+    // row (q&3) + 8*(q>>2) + 4*(l>>5), col l&31
+    for (int turn = 0; turn < 4; turn++) {
+        __syncthreads();
+        if (wave == turn) {
 #pragma unroll
-    for (int I = 0; I < 4; I++)
+            for (int I = 0; I < 4; I++)
 #pragma unroll
-        for (int J = I; J < 4; J++) {
+                for (int J = I; J < 4; J++) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                int row = 32 * I + (q & 3) + 8 * (q >> 2) + 4 * kg, col = 32 * J + x;
-                float v = acc[blk_index(I, J)][q];
-                atomicAdd(&G[row * GD + col], v);
-                if (I != J) atomicAdd(&G[col * GD + row], v);
-            }
+                    for (int q = 0; q < 16; q++) {
+                        const int row = 32 * I + (q & 3) + 8 * (q >> 2) + 4 * kg, col = 32 * J + x;
+                        const float v = acc[blk_index(I, J)][q];
+                        if (turn == 0) {
+                            G[row * GP + col] = v;
+                            if (I != J) G[col * GP + row] = v;
+                        } else {
+                            G[row * GP + col] += v;
+                            if (I != J) G[col * GP + row] += v;
+                        }
+                    }
+                }
         }
+    }
     // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS
     for (int i = tid; i < GD * RP; i += 256) {
         int d = i / RP, c = i % RP;
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
         for (int i = tid; i < GD * RP; i += 256) {
             int d = i / RP, c = i % RP;
             float s = 0.0f;
-            for (int e = 0; e < GD; e++) s = fmaf(G[d * GD + e], X[e * RP + c], s);
+            for (int e = 0; e < GD; e++) s = fmaf(G[d * GP + e], X[e * RP + c], s);
             Y[i] = s;
         }
         __syncthreads();
@@ -347,7 +358,7 @@ template <int RP>
 int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int loop, const float* P0, void* P_out,
              void* Q_out, int out_dtype, float* Wws, hipStream_t st) {
     const int of16 = out_dtype == GEAR_DTYPE_F16;
-    size_t shmem = (size_t)GD * GD * 4 + 2 * (size_t)GD * RP * 4 + 2 * (size_t)RP * RP * 8;
+    size_t shmem = (size_t)GD * GP * 4 + 2 * (size_t)GD * RP * 4 + 2 * (size_t)RP * RP * 8 + 16;
     if (transposed) {
         auto kfn = lr_gram_solve_kernel<RP, false>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
