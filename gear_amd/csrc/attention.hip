@@ -120,12 +120,34 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     for (int i = tid; i < MAXSEG * 16; i += 256) (&wacc[0][0])[i] = 0.0f;
     for (int i = tid; i < a.tc; i += 256) s[i] = 0.0f;
     __syncthreads();
-    for (int i = tid; i < nseg_c * a.rk; i += 256) {  // u[seg] = Pk[seg]^T q
-        const int sl = i / a.rk, c = i % a.rk;
-        const uint16_t* pk = a.kP + (int64_t)(seg_first + sl) * a.kP_seg_stride + bhk * AD * a.rk;
-        float acc = 0.0f;
-        for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(pk[d * a.rk + c]), acc);
-        u[sl][c] = acc;
+    // u[seg] = Pk[seg]^T q: one factor row (rk contiguous fp16) per thread, reduced over the 128 channels with
+    // wave shuffles + one LDS add per wave (the serial 128-deep load loop it replaces dominated small chunks)
+    for (int i = tid; i < MAXSEG * 16; i += 256) (&u[0][0])[i] = 0.0f;
+    __syncthreads();
+    if (a.rk > 0) {
+        for (int i = tid; i < nseg_c * AD; i += 256) {   // (i / 128) is wave-uniform: 64 | 128
+            const int sl = i / AD, d = i % AD;
+            const uint16_t* pk = a.kP + (int64_t)(seg_first + sl) * a.kP_seg_stride + (bhk * AD + d) * a.rk;
+            const float qd = qs[d];
+            float pr[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) pr[c] = 0.0f;
+            if (a.rk == 8) { float t[8]; unpack8(*(const uint4*)pk, t);
+#pragma unroll
+                for (int c = 0; c < 8; c++) pr[c] = qd * t[c]; }
+            else {
+#pragma unroll
+                for (int c = 0; c < 16; c++) if (c < a.rk) pr[c] = qd * h2f_bits(pk[c]); }
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                if (c < a.rk) {
+                    float v = pr[c];
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                    if (lane == 0) atomicAdd(&u[sl][c], v);
+                }
+            }
+        }
     }
     // ------------------------------------------------------------------ 1. K side
     {
@@ -166,7 +188,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
             const uint16_t* qp = a.kQ + (bhk * a.tf_k + t0 + t) * (int64_t)a.rk;
             const float* us = u[seg_of(t0 + t) - seg_first];
             float acc = 0.0f;
-            for (int c = 0; c < a.rk; c++) acc = fmaf(h2f_bits(qp[c]), us[c], acc);
+            if (a.rk == 8) {
+                float tq[8];
+                unpack8(*(const uint4*)qp, tq);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc = fmaf(tq[c], us[c], acc);
+            } else {
+                for (int c = 0; c < a.rk; c++) acc = fmaf(h2f_bits(qp[c]), us[c], acc);
+            }
             s[t] += acc;
         }
     }
@@ -243,9 +272,16 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
             if (t < tn) {
                 const uint16_t* qp = a.vQ + (bhk * a.tf_v + t0 + t) * (int64_t)a.rv;
                 const float p = s[t];
+                if (a.rv == 8) {
+                    float tq[8];
+                    unpack8(*(const uint4*)qp, tq);
 #pragma unroll
-                for (int c = 0; c < 16; c++)
-                    if (c < a.rv) wl[c] = p * h2f_bits(qp[c]);
+                    for (int c = 0; c < 8; c++) wl[c] = p * tq[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; c++)
+                        if (c < a.rv) wl[c] = p * h2f_bits(qp[c]);
+                }
             }
             const int sl = seg_of(t0 + sb) - seg_first;
 #pragma unroll
@@ -289,7 +325,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
         float o = oacc[tid];
         for (int sl = 0; sl < nseg_c && a.rv > 0; sl++) {
             const uint16_t* pv = a.vP + (int64_t)(seg_first + sl) * a.vP_seg_stride + (bhk * AD + tid) * a.rv;
-            for (int c = 0; c < a.rv; c++) o = fmaf(h2f_bits(pv[c]), wacc[sl][c], o);
+            if (a.rv == 8) {
+                float t[8];
+                unpack8(*(const uint4*)pv, t);
+#pragma unroll
+                for (int c = 0; c < 8; c++) o = fmaf(t[c], wacc[sl][c], o);
+            } else {
+                for (int c = 0; c < a.rv; c++) o = fmaf(h2f_bits(pv[c]), wacc[sl][c], o);
+            }
         }
         a.part_o[po * AD + tid] = o;
     }

@@ -44,29 +44,46 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const uint16_t* __rest
 }
 
 // res_out = res_in + delta (fp16 add; delta may be null) ; y = weight * fp16(res_out * rsqrt(mean(res_out^2) + eps))
+// One block per row; every thread keeps its 16-byte vectors (up to 4 -> H <= 8192) in registers between the two passes.
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t* __restrict__ res_in, const uint16_t* __restrict__ delta,
                                                           const uint16_t* __restrict__ weight, int H, float eps,
                                                           uint16_t* __restrict__ res_out, uint16_t* __restrict__ y) {
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
-    const uint16_t* r = res_in + row * H;
-    const uint16_t* d = delta ? delta + row * H : nullptr;
+    const int nvec = H / 8;
+    float v[4][8];
     float ss = 0.0f;
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float v = h2f_bits(r[i]);
-        if (d) v = hround(v + h2f_bits(d[i]));
-        if (res_out) res_out[row * H + i] = f2h_bits(v);
-        ss = fmaf(v, v, ss);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int iv = threadIdx.x + 256 * p;
+        if (iv < nvec) {
+            unpack8(*(const uint4*)(res_in + row * H + iv * 8), v[p]);
+            if (delta) {
+                float d[8];
+                unpack8(*(const uint4*)(delta + row * H + iv * 8), d);
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[p][j] = hround(v[p][j] + d[j]);
+            }
+            if (res_out) *(uint4*)(res_out + row * H + iv * 8) = pack8(v[p]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss = fmaf(v[p][j], v[p][j], ss);
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float v = h2f_bits(r[i]);
-        if (d) v = hround(v + h2f_bits(d[i]));
-        y[row * H + i] = f2h_bits(h2f_bits(weight[i]) * hround(v * inv));
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int iv = threadIdx.x + 256 * p;
+        if (iv < nvec) {
+            float w[8], o[8];
+            unpack8(*(const uint4*)(weight + iv * 8), w);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = w[j] * hround(v[p][j] * inv);
+            *(uint4*)(y + row * H + iv * 8) = pack8(o);
+        }
     }
 }
 
@@ -99,6 +116,7 @@ extern "C" int gear_rope_append(const void* qkv, int B, int Hq, int Hkv, int D, 
 extern "C" int gear_add_rmsnorm(const void* res_in, const void* delta, const void* weight, int64_t rows, int H, float eps,
                                 void* res_out, void* y, void* stream) {
     GEAR_CHECK_ARG(res_in && weight && y && rows > 0 && H > 0, "gear_add_rmsnorm: bad arguments");
+    GEAR_CHECK_ARG(H % 8 == 0 && H <= 8192, "gear_add_rmsnorm: hidden size %d must be a multiple of 8 and <= 8192", H);
     hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)res_in,
                        (const uint16_t*)delta, (const uint16_t*)weight, H, eps, (uint16_t*)res_out, (uint16_t*)y);
     GEAR_CHECK_LAUNCH("gear_add_rmsnorm");
