@@ -25,7 +25,22 @@ struct RowGeom {
     int64_t inner_stride;      // elements
     int nseg, seglen;          // row = nseg segments of seglen contiguous elements
     int64_t seg_stride;        // elements
+    int seglen_shift;          // log2(seglen) if it is a power of two, else -1
+    int group_shift;           // log2(group) (group is a power of two)
 };
+
+// integer divisions by run-time values cost ~30-100 VALU instructions per lane on this VALU-bound kernel: every
+// geometry quotient goes through shifts (power-of-two group / segment length) or 32-bit scalar math (row index)
+__device__ __forceinline__ void seg_pos(const RowGeom& gm, int j, int& seg, int& pos) {
+    if (gm.nseg == 1) { seg = 0; pos = j; }
+    else if (gm.seglen_shift >= 0) { seg = j >> gm.seglen_shift; pos = j & (gm.seglen - 1); }
+    else { seg = j / gm.seglen; pos = j % gm.seglen; }
+}
+__device__ __forceinline__ int64_t row_base_of(const RowGeom& gm, int64_t r) {
+    const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;   // n_rows < 2^31 (checked on the host)
+    const uint32_t qo = ru / ri;
+    return (int64_t)qo * gm.outer_stride + (int64_t)(ru - qo * ri) * gm.inner_stride;
+}
 
 __device__ __forceinline__ uint32_t sort_key(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit)
     if (hbits == 0x8000u) hbits = 0u;  // -0 == +0 (the oracle / torch.topk compare values)
@@ -170,9 +185,9 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     const int lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
     const int j0 = tid * 16;  // first element of this lane inside the row
     const bool active = j0 < len;
-    const int seg = active ? j0 / gm.seglen : 0;
-    const int pos = active ? j0 % gm.seglen : 0;
-    const int64_t row_base = (r / gm.rows_inner) * gm.outer_stride + (r % gm.rows_inner) * gm.inner_stride;
+    int seg = 0, pos = 0;
+    if (active) seg_pos(gm, j0, seg, pos);
+    const int64_t row_base = row_base_of(gm, r);
     const int64_t off = row_base + (int64_t)seg * gm.seg_stride + pos;  // element offset of this lane's 16 values
 
     uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
@@ -432,8 +447,8 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
 #pragma unroll
     for (int w = 0; w < WPL; w++) cp[w] = words[w];
     if ((tid & (lanes_per_group - 1)) == 0) {
-        st_st<ST>(scale + off / group, qp.scale);
-        st_st<ST>(mn + off / group, qp.mn);
+        st_st<ST>(scale + (off >> gm.group_shift), qp.scale);
+        st_st<ST>(mn + (off >> gm.group_shift), qp.mn);
     }
     if (err) {
         uint4* ep = (uint4*)(err + off);
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(64) void compress_rows_wave_kernel(const uint16_t* 
 
     const int64_t r = blockIdx.x;
     const int lane = threadIdx.x;
-    const int64_t row_base = (r / gm.rows_inner) * gm.outer_stride + (r % gm.rows_inner) * gm.inner_stride;
+    const int64_t row_base = row_base_of(gm, r);
     float v[CPL][16];
     int64_t off[CPL];
     bool act[CPL];
@@ -561,7 +576,9 @@ __global__ __launch_bounds__(64) void compress_rows_wave_kernel(const uint16_t* 
         const int j0 = c * 1024 + lane * 16;
         act[c] = j0 < len;
         const int jj = act[c] ? j0 : 0;
-        off[c] = row_base + (int64_t)(jj / gm.seglen) * gm.seg_stride + jj % gm.seglen;
+        int sg, ps;
+        seg_pos(gm, jj, sg, ps);
+        off[c] = row_base + (int64_t)sg * gm.seg_stride + ps;
     }
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -710,8 +727,8 @@ __global__ __launch_bounds__(64) void compress_rows_wave_kernel(const uint16_t* 
 #pragma unroll
         for (int w = 0; w < WPL; w++) cp[w] = words[w];
         if ((lane & (lanes_per_group - 1)) == 0) {
-            st_st<ST>(scale + off[c] / group, qp.scale);
-            st_st<ST>(mn + off[c] / group, qp.mn);
+            st_st<ST>(scale + (off[c] >> gm.group_shift), qp.scale);
+            st_st<ST>(mn + (off[c] >> gm.group_shift), qp.mn);
         }
         if (err) {
             uint4* ep = (uint4*)(err + off[c]);
@@ -758,7 +775,9 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
                    "gear_compress_rows: strides must be multiples of the group size");
     GEAR_CHECK_ARG(x && code && scale && mn, "gear_compress_rows: null pointer");
     GEAR_CHECK_ARG(k == 0 || (oidx && oval), "gear_compress_rows: outlier buffers required when k > 0");
-    RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride};
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+    RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride,
+               gear_is_pow2(seglen) ? ilog2(seglen) : -1, ilog2(group)};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     // tier-0 threshold: let about 2.2 k of a normal row's elements pass on each side (at most 128 may)
     float zthr = 0.0f;
