@@ -26,7 +26,7 @@ from . import compress as C
 
 class GearKVCache:
     def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device, head_dim: int = 128,
-                 seed: int = 0):
+                 seed: int = 0, state: torch.Tensor = None):
         assert head_dim == 128
         cc = compress_config
         self.B, self.H, self.D = batch, n_kv_heads, head_dim
@@ -64,6 +64,8 @@ class GearKVCache:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._ws = None
+        # optional device-side {pos, slot, T, W} shared by all layers (the _dyn methods read it: hipGraph replay)
+        self.state = state
 
     # ------------------------------------------------------------------------------------------------ state
     @property
@@ -143,6 +145,31 @@ class GearKVCache:
             self.Tmax, self.group, self.bits, 0, self.rk, self.rv, 0, 0, self.seg0, self.R if self.lowrank else 0, self.R,
             1.0 / math.sqrt(self.D), p(out), None, p(self._ws), self._ws.numel(), L.stream_ptr())
         L.check(rc, "gear_attn_decode_seg")
+        return out
+
+    # ---- device-state variants: no host-side counters change here (a captured graph replays these launches) ----------
+    def append_rope_dyn(self, qkv: torch.Tensor, n_q_heads: int, theta: float) -> torch.Tensor:
+        q = torch.empty((self.B, n_q_heads, 1, self.D), dtype=torch.float16, device=qkv.device)
+        rc = L.load().gear_rope_append_dyn(L.ptr(qkv), self.B, n_q_heads, self.H, self.D, L.ptr(self.state), theta, L.ptr(q),
+                                           L.ptr(self.kwin), L.ptr(self.vwin), self.R, L.stream_ptr())
+        L.check(rc, "gear_rope_append_dyn")
+        return q
+
+    def attend_dyn(self, q: torch.Tensor) -> torch.Tensor:
+        B, Hq = q.shape[0], q.shape[1]
+        lib = L.load()
+        out = torch.empty((B, Hq, 1, self.D), dtype=torch.float16, device=q.device)
+        wsb = lib.gear_attn_decode_workspace(B, Hq, self.Tmax, self.bits)
+        if self._ws is None or self._ws.numel() < wsb:
+            self._ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
+        p = L.ptr
+        rc = lib.gear_attn_decode_dyn(
+            p(q), p(self.kcode), p(self.kscale), p(self.kmn), p(self.kPseg), p(self.kQtok), None, None,
+            p(self.vcode), p(self.vscale), p(self.vmn), p(self.vPseg), p(self.vQtok), None, None, p(self.kwin), p(self.vwin),
+            B, Hq, self.H, self.D, self.Tmax, self.R, self.Tmax // self.fpi, self.Tmax // self.group, self.Tmax, self.Tmax,
+            self.Tmax, self.group, self.bits, 0, self.rk, self.rv, 0, 0, self.seg0, self.R if self.lowrank else 0, self.R,
+            p(self.state), 1.0 / math.sqrt(self.D), p(out), None, p(self._ws), self._ws.numel(), L.stream_ptr())
+        L.check(rc, "gear_attn_decode_dyn")
         return out
 
     def maybe_compress(self):

@@ -49,6 +49,7 @@ struct AttnArgs {
     int seg0, seglen;        // low-rank factor segments: tokens [0, seg0) use channel factors #0, then one set per `seglen`
                              // tokens (seglen == 0: a single segment).  kP / vP are [nseg, B*Hkv, 128, r].
     int64_t kP_seg_stride, vP_seg_stride;
+    const int* dyn;          // optional device state {pos, slot, T, W}: T and W are read from it (hipGraph replay)
     int tc, splits;
     float qscale;
     float* part_o;           // [B*Hq, splits, 128]
@@ -104,7 +105,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     const int hkv = hq / n_rep;
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
     const int t0 = split * a.tc;
-    const int tn = min(a.tc, a.T - t0);  // tokens in this chunk (> 0 by construction)
+    const int Tc = a.dyn ? a.dyn[2] : a.T;
+    const int tn = min(a.tc, Tc - t0);  // tokens in this chunk
+    if (tn <= 0) {                      // grid planned for the cache capacity: chunks beyond the current length
+        const int64_t pe = bhq * a.splits + split;
+        if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
+        if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
+        return;
+    }
     const ST* kscale = (const ST*)a.kscale;
     const ST* kmn = (const ST*)a.kmn;
     const ST* vscale = (const ST*)a.vscale;
@@ -344,18 +352,20 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
 
 // merge the splits + the fp16 window, apply the V low-rank factor, normalise.  grid (B*Hq), block 128.
 __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
-                                                                 const uint16_t* __restrict__ vwin, int W, int wcap,
+                                                                 const uint16_t* __restrict__ vwin, int W_arg, int wcap,
                                                                  uint16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ float qs[AD];
     __shared__ float sw[64];
     __shared__ float coef[64 + 64];  // per split, then per window token
     __shared__ float stat[2];
     const int tid = threadIdx.x;
+    int W = W_arg;
     const int64_t bhq = blockIdx.x;
     const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
     const int hkv = hq / (a.Hq / a.Hkv);
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
-    const int ns = a.T > 0 ? a.splits : 0;
+    if (a.dyn) W = a.dyn[3];
+    const int ns = (a.dyn || a.T > 0) ? a.splits : 0;
     qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
     __syncthreads();
     if (tid < W) {
@@ -412,13 +422,13 @@ extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
     return (size_t)B * Hq * splits * (AD + 16 + 2) * sizeof(float) + 256;
 }
 
-extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
                                 const void* kQ, const void* koidx, const void* koval, const void* vcode,
                                 const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
                                 const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T,
                                 int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
-                                int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, float qscale, void* out,
-                                void* lse, void* workspace, size_t workspace_bytes, void* stream) {
+                                int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, const void* dyn_state,
+                                float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream) {
     GEAR_CHECK_ARG(wcap >= W, "gear_attn_decode: window pitch %d smaller than the window %d", wcap, W);
     GEAR_CHECK_ARG(seglen == 0 || (seglen % 64 == 0 && seg0 % 64 == 0 && seg0 >= 0),
                    "gear_attn_decode: factor segments must be multiples of 64 tokens (seg0=%d seglen=%d)", seg0, seglen);
@@ -435,6 +445,7 @@ extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void
     GEAR_CHECK_ARG(rk >= 0 && rk <= 16 && rv >= 0 && rv <= 16, "gear_attn_decode: ranks must be <= 16");
     GEAR_CHECK_ARG(q && out && workspace, "gear_attn_decode: null pointer");
     GEAR_CHECK_ARG(T == 0 || (kcode && kscale && kmn && vcode && vscale && vmn), "gear_attn_decode: payload missing");
+    GEAR_CHECK_ARG(!dyn_state || (kwin && vwin), "gear_attn_decode: a device-side state needs the window buffers");
     GEAR_CHECK_ARG(W == 0 || (kwin && vwin), "gear_attn_decode: window missing");
     GEAR_CHECK_ARG(workspace_bytes >= gear_attn_decode_workspace(B, Hq, T, bits), "gear_attn_decode: workspace too small");
     AttnArgs a;
@@ -449,6 +460,7 @@ extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void
     a.kk = (koidx && koval) ? kk : 0; a.kv = (voidx && voval) ? kv : 0;
     a.qscale = qscale;
     a.seg0 = seg0; a.seglen = seglen;
+    a.dyn = (const int*)dyn_state;
     a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
     a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
     a.splits = plan_splits(T, bits, (int64_t)B * Hq, &a.tc);
@@ -457,7 +469,7 @@ extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void
     a.part_w = a.part_o + (size_t)B * Hq * a.splits * AD;
     a.part_ml = a.part_w + (size_t)B * Hq * a.splits * 16;
     hipStream_t st = (hipStream_t)stream;
-    if (T > 0) {
+    if (T > 0 || a.dyn) {
         dim3 grid(a.splits, (unsigned)(B * Hq));
 #define GO(BI, STT) hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a)
         if (mode == 0) { if (bits == 2) GO(2, uint16_t); else GO(4, uint16_t); }
@@ -478,7 +490,19 @@ extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* ks
                                 int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
                                 int rk, int rv, int kk, int kv, float qscale, void* out, void* lse, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-    return gear_attn_decode_seg(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin,
+    return gear_attn_decode_dyn(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin,
                                 vwin, B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv, kk, kv,
-                                0, 0, W, qscale, out, lse, workspace, workspace_bytes, stream);
+                                0, 0, W, nullptr, qscale, out, lse, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                                    const void* kQ, const void* koidx, const void* koval, const void* vcode,
+                                    const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
+                                    const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D,
+                                    int T, int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits,
+                                    int mode, int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, float qscale,
+                                    void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream) {
+    return gear_attn_decode_dyn(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin,
+                                vwin, B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv, kk, kv,
+                                seg0, seglen, wcap, nullptr, qscale, out, lse, workspace, workspace_bytes, stream);
 }

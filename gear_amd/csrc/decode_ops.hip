@@ -15,7 +15,8 @@ namespace {
 __global__ __launch_bounds__(256) void rope_append_kernel(const uint16_t* __restrict__ qkv, int B, int Hq, int Hkv, int pos,
                                                           float log2_theta, uint16_t* __restrict__ q_out,
                                                           uint16_t* __restrict__ kwin, uint16_t* __restrict__ vwin,
-                                                          int slot, int W) {
+                                                          int slot, int W, const int* __restrict__ dyn) {
+    if (dyn) { pos = dyn[0]; slot = dyn[1]; }   // device-side state {pos, slot, T, W} (hipGraph replay)
     const int HT = Hq + 2 * Hkv;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (b, head, pair index 0..63)
     if (i >= (int64_t)B * HT * 64) return;
@@ -108,8 +109,33 @@ extern "C" int gear_rope_append(const void* qkv, int B, int Hq, int Hkv, int D, 
     const int64_t n = (int64_t)B * (Hq + 2 * Hkv) * 64;
     hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, B, Hq, Hkv, pos, log2f(theta), (uint16_t*)q_out, (uint16_t*)kwin, (uint16_t*)vwin,
-                       slot, W);
+                       slot, W, (const int*)nullptr);
     GEAR_CHECK_LAUNCH("gear_rope_append");
+    return 0;
+}
+
+extern "C" int gear_rope_append_dyn(const void* qkv, int B, int Hq, int Hkv, int D, const void* dyn_state, float theta,
+                                    void* q_out, void* kwin, void* vwin, int W, void* stream) {
+    GEAR_CHECK_ARG(D == 128, "gear_rope_append_dyn: head_dim must be 128 (got %d)", D);
+    GEAR_CHECK_ARG(qkv && q_out && kwin && vwin && dyn_state, "gear_rope_append_dyn: null pointer");
+    const int64_t n = (int64_t)B * (Hq + 2 * Hkv) * 64;
+    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)qkv, B, Hq, Hkv, 0, log2f(theta), (uint16_t*)q_out, (uint16_t*)kwin, (uint16_t*)vwin,
+                       0, W, (const int*)dyn_state);
+    GEAR_CHECK_LAUNCH("gear_rope_append_dyn");
+    return 0;
+}
+
+__global__ void decode_state_advance_kernel(int* st) {  // one token appended: pos, slot and W move on
+    st[0] += 1;
+    st[1] += 1;
+    st[3] += 1;
+}
+
+extern "C" int gear_decode_state_advance(void* state, void* stream) {
+    GEAR_CHECK_ARG(state, "gear_decode_state_advance: null pointer");
+    hipLaunchKernelGGL(decode_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)state);
+    GEAR_CHECK_LAUNCH("gear_decode_state_advance");
     return 0;
 }
 

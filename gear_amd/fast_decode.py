@@ -39,6 +39,14 @@ class FastGearDecoder:
                 cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i),
                 rotary=at.rotary_emb))
         self.pos = 0
+        self.batch = batch
+        # hipGraph mode: device-side {pos, slot, T, W} shared by every layer's cache, static token / logits buffers
+        self.state = torch.zeros(4, dtype=torch.int32, device=dev)
+        for lw in self.layers:
+            lw["cache"].state = self.state
+        self.graph = None
+        self.tok = torch.zeros((batch, 1), dtype=torch.long, device=dev)
+        self.logits_static = None
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _add_rmsnorm(self, res, delta, w):
@@ -105,13 +113,73 @@ class FastGearDecoder:
         self.pos += 1
         return self.model.lm_head(x)
 
+    # ------------------------------------------------------------------------------------------------ hipGraph decode
+    def _sync_state(self):
+        c = self.layers[0]["cache"]
+        self.state.copy_(torch.tensor([self.pos, c.n_win, c.n_comp, c.n_win + 1], dtype=torch.int32))
+
+    def _step_body_dyn(self):
+        """The token step with every per-token scalar read from self.state on the device: identical launches for every
+        token, so the whole thing (embedding -> 32 layers -> lm_head -> argmax -> state advance) is one graph."""
+        m = self.model.model
+        res = m.embed_tokens(self.tok.view(-1))
+        delta = None
+        for lw in self.layers:
+            res, x = self._add_rmsnorm(res, delta, lw["n1"])
+            qkv = F.linear(x, lw["wqkv"])
+            cache = lw["cache"]
+            q = cache.append_rope_dyn(qkv, self.Hq, self.theta)
+            a = cache.attend_dyn(q)
+            attn = F.linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
+            res, x = self._add_rmsnorm(res, attn, lw["n2"])
+            delta = F.linear(self._silu_mul(F.linear(x, lw["wgu"])), lw["wd"])
+        res, x = self._add_rmsnorm(res, delta, m.norm.weight)
+        logits = self.model.lm_head(x)
+        self.tok.copy_(logits.argmax(-1, keepdim=True))
+        L.check(L.load().gear_decode_state_advance(L.ptr(self.state), L.stream_ptr()), "gear_decode_state_advance")
+        return logits
+
     @torch.no_grad()
-    def generate(self, input_ids: torch.Tensor, max_length: int) -> torch.Tensor:
+    def step_graph(self, token_ids: torch.Tensor = None) -> torch.Tensor:
+        """One greedy decode token by replaying the captured graph.  token_ids (optional) overrides the token the graph
+        produced itself; returns the NEXT token [B,1] (the graph's own argmax).  Block compression (every `residual`
+        tokens) runs eagerly between replays."""
+        if token_ids is not None:
+            self.tok.copy_(token_ids.view(self.batch, 1))
+        if self.graph is None:
+            self._sync_state()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.logits_static = self._step_body_dyn()
+            self.graph = g
+        self.graph.replay()
+        self.pos += 1
+        full = False
+        for lw in self.layers:
+            c = lw["cache"]
+            c.n_win += 1
+            full = c.n_win == c.R
+        if full:
+            for lw in self.layers:
+                lw["cache"].maybe_compress()
+            self._sync_state()
+        return self.tok
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, max_length: int, graph: bool = False) -> torch.Tensor:
         logits = self.prefill(input_ids)
         out = [input_ids]
         nxt = logits.argmax(-1, keepdim=True)
         out.append(nxt)
+        if graph and sum(t.shape[1] for t in out) < max_length:
+            nxt = self.step(nxt).argmax(-1, keepdim=True)      # one eager step warms up every library handle
+            out.append(nxt)
+            self.tok.copy_(nxt)
         while sum(t.shape[1] for t in out) < max_length:
-            nxt = self.step(nxt).argmax(-1, keepdim=True)
+            if graph:
+                nxt = self.step_graph().clone()
+            else:
+                nxt = self.step(nxt).argmax(-1, keepdim=True)
             out.append(nxt)
         return torch.cat(out, dim=1)

@@ -188,6 +188,24 @@ int gear_add_rmsnorm(const void* res_in, const void* delta, const void* weight, 
                      void* res_out, void* y, void* stream);
 int gear_silu_mul(const void* gate_up, int64_t B, int I, void* out, void* stream);
 
+/* ---- device-side decode state (hipGraph-replayable token step) ---------------------------------------------------
+ * state = int32[4] {pos, slot, T, W} in device memory: position of the token being processed, its slot in the fp16 window,
+ * number of compressed tokens, number of window tokens INCLUDING that token (W = slot + 1).  The _dyn entry points read the per-token scalars from
+ * it so that a captured graph of the whole token step can be replayed unchanged; gear_decode_state_advance() moves it on
+ * by one token (pos, slot, W += 1).  gear_attn_decode_dyn plans its grid for `T` = the cache capacity; chunks beyond the
+ * current length exit at once.  With dyn_state == NULL they behave exactly like the static entry points.
+ */
+int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                         const void* kQ, const void* koidx, const void* koval, const void* vcode, const void* vscale,
+                         const void* vmn, const void* vP, const void* vQ, const void* voidx, const void* voval,
+                         const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T, int W, int ldk, int lsk,
+                         int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv, int kk, int kv,
+                         int seg0, int seglen, int wcap, const void* dyn_state, float qscale, void* out, void* lse,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int gear_rope_append_dyn(const void* qkv, int B, int Hq, int Hkv, int D, const void* dyn_state, float theta, void* q_out,
+                         void* kwin, void* vwin, int W, void* stream);
+int gear_decode_state_advance(void* state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,3 +150,16 @@ def test_fast_decoder_generate_lowrank_deterministic():
     a = FastGearDecoder(model, 256, batch=2, seed=3).generate(ids, 200)
     b = FastGearDecoder(model, 256, batch=2, seed=3).generate(ids, 200)
     assert a.shape == (2, 200) and torch.equal(a, b) and torch.equal(a[:, :70], ids)
+
+
+def test_graph_replay_matches_eager_decode():
+    """The hipGraph-captured token step (device-side pos / slot / T / W) generates exactly what the eager fast path does,
+    across block compressions (which run eagerly between replays)."""
+    from gear_amd.fast_decode import FastGearDecoder
+    for method in ("KIVI", "gearlKIVI"):
+        model = _tiny(method)
+        ids = torch.randint(0, 1000, (2, 90)).cuda()
+        a = FastGearDecoder(model, 512, batch=2, seed=5).generate(ids, 300, graph=False)
+        b = FastGearDecoder(model, 512, batch=2, seed=5).generate(ids, 300, graph=True)
+        assert a.shape == (2, 300)
+        assert torch.equal(a, b), (method, int((a != b).sum()))
