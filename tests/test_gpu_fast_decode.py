@@ -153,13 +153,28 @@ def test_fast_decoder_generate_lowrank_deterministic():
 
 
 def test_graph_replay_matches_eager_decode():
-    """The hipGraph-captured token step (device-side pos / slot / T / W) generates exactly what the eager fast path does,
-    across block compressions (which run eagerly between replays)."""
+    """The hipGraph-captured token step (device-side pos / slot / T / W) tracks the eager fast path token for token,
+    across block compressions (which run eagerly between replays).  The graph plans the attention split for the cache
+    capacity, so sums associate differently: compare logits, teacher-forced with the eager path's tokens."""
     from gear_amd.fast_decode import FastGearDecoder
     for method in ("KIVI", "gearlKIVI"):
         model = _tiny(method)
         ids = torch.randint(0, 1000, (2, 90)).cuda()
-        a = FastGearDecoder(model, 512, batch=2, seed=5).generate(ids, 300, graph=False)
-        b = FastGearDecoder(model, 512, batch=2, seed=5).generate(ids, 300, graph=True)
-        assert a.shape == (2, 300)
-        assert torch.equal(a, b), (method, int((a != b).sum()))
+        fe, fg = FastGearDecoder(model, 512, batch=2, seed=5), FastGearDecoder(model, 512, batch=2, seed=5)
+        tok = fe.prefill(ids).argmax(-1, keepdim=True)
+        fg.prefill(ids)
+        tok2 = fe.step(tok).argmax(-1, keepdim=True)
+        fg.step(tok)
+        tok = tok2
+        worst = 1.0
+        for i in range(150):
+            le = fe.step(tok)
+            nxt_g = fg.step_graph(tok)
+            lg = fg.logits_static
+            worst = min(worst, float(torch.nn.functional.cosine_similarity(le.float(), lg.float()).min()))
+            assert torch.isfinite(lg).all()
+            tok = le.argmax(-1, keepdim=True)
+        assert worst > 0.9995, (method, worst)
+        ce, cg = fe.layers[0]["cache"], fg.layers[0]["cache"]
+        assert (ce.n_comp, ce.n_win, fe.pos) == (cg.n_comp, cg.n_win, fg.pos) == (192, 50, 242)
+        assert fg.state.tolist() == [242, 50, 192, 51]
