@@ -96,7 +96,7 @@ def decode_tokens_per_s(cfg, dev, new_tokens=64):
     # (1) the build's fast path: pre-allocated GearKVCache + fused attention, ~10 launches per layer
     from gear_amd.fast_decode import FastGearDecoder
     torch.manual_seed(0)
-    fast = FastGearDecoder(model, T + 8)
+    fast = FastGearDecoder(model, T + 2 * new_tokens + 8)
     nxt = fast.prefill(ids).argmax(-1, keepdim=True)
     for _ in range(2):
         nxt = fast.step(nxt).argmax(-1, keepdim=True)
@@ -106,8 +106,19 @@ def decode_tokens_per_s(cfg, dev, new_tokens=64):
         nxt = fast.step(nxt).argmax(-1, keepdim=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res.update({"tokens_per_s": (new_tokens - 2) / dt, "ms_per_token": dt / (new_tokens - 2) * 1e3,
-                "path": "FastGearDecoder (GearKVCache + gear_attn_decode_seg)",
+    res.update({"eager_fast_path_tokens_per_s": (new_tokens - 2) / dt})
+    # (1b) the same token step captured once as a HIP graph (device-side pos / slot / T / W) and replayed
+    n_graph = new_tokens - 2
+    fast.tok.copy_(nxt)
+    fast.step_graph()                                    # capture + first replay
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_graph):
+        fast.step_graph()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res.update({"tokens_per_s": n_graph / dt, "ms_per_token": dt / n_graph * 1e3,
+                "path": "FastGearDecoder.step_graph (GearKVCache + gear_attn_decode_dyn, one hipGraph per token step)",
                 "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20})
     del fast
     torch.cuda.empty_cache()
