@@ -39,6 +39,7 @@ class FastGearDecoder:
                 cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i),
                 rotary=at.rotary_emb))
         self.pos = 0
+        self.use_gemv = True
         self.batch = batch
         # hipGraph mode: device-side {pos, slot, T, W} shared by every layer's cache, static token / logits buffers
         self.state = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -56,6 +57,16 @@ class FastGearDecoder:
         rc = L.load().gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(w), B, H, self.eps, L.ptr(res_out), L.ptr(y), L.stream_ptr())
         L.check(rc, "gear_add_rmsnorm")
         return (res_out if delta is not None else res), y
+
+    def _linear(self, x, w):
+        """x [B, K] @ w[N, K]^T for the token step: the build's fp16 GEMV for B <= 4, the library otherwise."""
+        B, K = x.shape
+        if B > 4 or K % 8 or not self.use_gemv:
+            return F.linear(x, w)
+        y = torch.empty((B, w.shape[0]), dtype=x.dtype, device=x.device)
+        rc = L.load().gear_gemv_f16(L.ptr(x), L.ptr(w), B, K, w.shape[0], L.ptr(y), L.stream_ptr())
+        L.check(rc, "gear_gemv_f16")
+        return y
 
     def _silu_mul(self, gu):
         B, I2 = gu.shape
@@ -101,17 +112,17 @@ class FastGearDecoder:
         delta = None
         for lw in self.layers:
             res, x = self._add_rmsnorm(res, delta, lw["n1"])
-            qkv = F.linear(x, lw["wqkv"])
+            qkv = self._linear(x, lw["wqkv"])
             cache = lw["cache"]
             q = cache.append_rope(qkv, self.Hq, self.pos, self.theta)
             a = cache.attend(q)
             cache.maybe_compress()
-            attn = F.linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
+            attn = self._linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
             res, x = self._add_rmsnorm(res, attn, lw["n2"])
-            delta = F.linear(self._silu_mul(F.linear(x, lw["wgu"])), lw["wd"])
+            delta = self._linear(self._silu_mul(self._linear(x, lw["wgu"])), lw["wd"])
         res, x = self._add_rmsnorm(res, delta, m.norm.weight)
         self.pos += 1
-        return self.model.lm_head(x)
+        return self._linear(x, self.model.lm_head.weight)
 
     # ------------------------------------------------------------------------------------------------ hipGraph decode
     def _sync_state(self):
@@ -126,15 +137,15 @@ class FastGearDecoder:
         delta = None
         for lw in self.layers:
             res, x = self._add_rmsnorm(res, delta, lw["n1"])
-            qkv = F.linear(x, lw["wqkv"])
+            qkv = self._linear(x, lw["wqkv"])
             cache = lw["cache"]
             q = cache.append_rope_dyn(qkv, self.Hq, self.theta)
             a = cache.attend_dyn(q)
-            attn = F.linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
+            attn = self._linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
             res, x = self._add_rmsnorm(res, attn, lw["n2"])
-            delta = F.linear(self._silu_mul(F.linear(x, lw["wgu"])), lw["wd"])
+            delta = self._linear(self._silu_mul(self._linear(x, lw["wgu"])), lw["wd"])
         res, x = self._add_rmsnorm(res, delta, m.norm.weight)
-        logits = self.model.lm_head(x)
+        logits = self._linear(x, self.model.lm_head.weight)
         self.tok.copy_(logits.argmax(-1, keepdim=True))
         L.check(L.load().gear_decode_state_advance(L.ptr(self.state), L.stream_ptr()), "gear_decode_state_advance")
         return logits

@@ -206,6 +206,11 @@ int gear_rope_append_dyn(const void* qkv, int B, int Hq, int Hkv, int D, const v
                          void* kwin, void* vwin, int W, void* stream);
 int gear_decode_state_advance(void* state, void* stream);
 
+/* ---- fp16 GEMV for the decode token step: y[b, n] = sum_k x[b, k] W[n, k], 1 <= B <= 4, K % 8 == 0 -------------------
+ * (torch.nn.functional.linear for one token; used by FastGearDecoder for the q/k/v, o, gate/up, down and lm_head GEMVs)
+ */
+int gear_gemv_f16(const void* x, const void* W, int B, int K, int N, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,3 +178,15 @@ def test_graph_replay_matches_eager_decode():
         ce, cg = fe.layers[0]["cache"], fg.layers[0]["cache"]
         assert (ce.n_comp, ce.n_win, fe.pos) == (cg.n_comp, cg.n_win, fg.pos) == (192, 49, 241)   # 90 + 1 + 150 tokens
         assert fg.state.tolist() == [241, 49, 192, 50]
+
+
+@pytest.mark.parametrize("B,K,N", [(1, 4096, 4096), (1, 11008, 4096), (2, 4096, 12288), (4, 512, 1000), (3, 4096, 32000), (1, 64, 7)])
+def test_gemv_f16_matches_library(B, K, N):
+    from gear_amd import _lib as L
+    torch.manual_seed(81)
+    x = torch.randn(B, K).half().cuda()
+    w = (torch.randn(N, K) * 0.05).half().cuda()
+    y = torch.empty(B, N).half().cuda()
+    L.check(L.load().gear_gemv_f16(L.ptr(x), L.ptr(w), B, K, N, L.ptr(y), L.stream_ptr()), "gemv")
+    ref = x.double() @ w.double().t()
+    assert rel_fro(host(y).astype(np.float64), host(ref)) < 1e-3
