@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     __shared__ float u[MAXSEG][16];
     __shared__ float s[TC_MAX];
     __shared__ float oacc[AD];
-    __shared__ float wacc[MAXSEG][16];
+    __shared__ float wacc[4][MAXSEG][16];   // one copy per wave, merged in a fixed order
     __shared__ float red[4];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     // factor segments touched by this chunk
     auto seg_of = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
     const int seg_first = seg_of(t0), nseg_c = seg_of(t0 + tn - 1) - seg_first + 1;
-    for (int i = tid; i < MAXSEG * 16; i += 256) (&wacc[0][0])[i] = 0.0f;
+    for (int i = tid; i < 4 * MAXSEG * 16; i += 256) (&wacc[0][0][0])[i] = 0.0f;
     for (int i = tid; i < a.tc; i += 256) s[i] = 0.0f;
     __syncthreads();
     // u[seg] = Pk[seg]^T q: one factor row (rk contiguous fp16) per thread, reduced over the 128 channels with
@@ -159,19 +159,26 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     }
     // ------------------------------------------------------------------ 1. K side
     {
-        const int nw = (tn + CPW - 1) / CPW;        // words in the chunk
+        // lanes = (packed word of the chunk) x (channel subset).  The word-lane count is the smallest power of two
+        // covering a full chunk (a.tc / CPW words, at most 64), so that a short chunk (128 tokens = 8 words at 2 bits)
+        // still keeps all 256 threads busy: 8 word lanes x 32 channel subsets, 4 channels each, merged with wave
+        // shuffles + one LDS add per wave.
+        const int nw = (tn + CPW - 1) / CPW;        // words in this chunk
         const int w0 = t0 / CPW;                    // t0 is a multiple of CPW
-        const int NT = 64;                          // token-word lanes per row-subset
-        const int tl = tid & (NT - 1), dsub = tid >> 6;  // 4 row-subsets (one per wave)
-        for (int wb = 0; wb < nw; wb += NT) {
-            const int w = wb + tl;
+        const int nwc = a.tc / CPW;
+        int wl = 64;
+        while (wl > 1 && (wl >> 1) >= nwc) wl >>= 1;
+        const int lw = tid & (wl - 1), dsub = tid / wl, nds = 256 / wl;
+        for (int wb = 0; wb < nw; wb += wl) {
+            const int w = wb + lw;
             float acc[CPW];
 #pragma unroll
             for (int j = 0; j < CPW; j++) acc[j] = 0.0f;
             float zacc = 0.0f;
             if (w < nw) {
                 const int g = ((w0 + w) * CPW) / a.group;
-                for (int d = dsub; d < AD; d += 4) {
+#pragma unroll 4
+                for (int d = dsub; d < AD; d += nds) {
                     const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + w0 + w];
                     const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
                     const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
@@ -181,11 +188,24 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
 #pragma unroll
                     for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((word >> (BITS * j)) & MASK), acc[j]);
                 }
+            }
 #pragma unroll
-                for (int j = 0; j < CPW; j++) {
-                    int t = w * CPW + j;
-                    if (t < tn) atomicAdd(&s[t], acc[j] + zacc);
+            for (int j = 0; j < CPW; j++) {
+                float v = acc[j] + zacc;
+                for (int msk = wl; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
+                acc[j] = v;
+            }
+            // the four waves add their channel subsets in a fixed order (float atomics would make the association,
+            // and with it the generated tokens, run-to-run dependent)
+            for (int turn = 0; turn < 4; turn++) {
+                if ((tid >> 6) == turn && lane < wl) {
+#pragma unroll
+                    for (int j = 0; j < CPW; j++) {
+                        const int t = w * CPW + j;
+                        if (t < tn) s[t] += acc[j];
+                    }
                 }
+                __syncthreads();
             }
         }
     }
@@ -249,6 +269,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
         float zacc = 0.0f;
         const int gv = (wv * CPW) / a.group;
         const int ngv = AD / a.group;
+#pragma unroll 4
         for (int t = rsub; t < tn; t += NRS) {
             const int64_t row = bhk * a.tcap_v + t0 + t;
             const uint32_t word = a.vcode[row * NWV + wv];
@@ -265,7 +286,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
         for (int j = 0; j < CPW; j++) {
             float v = acc[j] + zacc;
             for (int msk = NWV; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
-            if (lane < NWV) atomicAdd(&oacc[wv * CPW + j], v);
+            acc[j] = v;
+        }
+        for (int turn = 0; turn < 4; turn++) {   // fixed merge order, see the K side
+            if ((tid >> 6) == turn && lane < NWV) {
+#pragma unroll
+                for (int j = 0; j < CPW; j++) oacc[wv * CPW + j] += acc[j];
+            }
+            __syncthreads();
         }
     }
     // w[seg] = Qv^T p per factor segment: 64-token slabs (aligned, never straddle a segment) go round-robin to the
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
                     float v = wl[c];
 #pragma unroll
                     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                    if (lane == 0) atomicAdd(&wacc[sl][c], v);
+                    if (lane == 0) wacc[wave][sl][c] += v;
                 }
             }
         }
@@ -329,6 +357,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     }
     __syncthreads();
     const int64_t po = bhq * a.splits + split;
+#define WSUM(sl, c) ((wacc[0][sl][c] + wacc[1][sl][c]) + (wacc[2][sl][c] + wacc[3][sl][c]))
     if (tid < AD) {
         float o = oacc[tid];
         for (int sl = 0; sl < nseg_c && a.rv > 0; sl++) {
@@ -337,13 +366,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
                 float t[8];
                 unpack8(*(const uint4*)pv, t);
 #pragma unroll
-                for (int c = 0; c < 8; c++) o = fmaf(t[c], wacc[sl][c], o);
+                for (int c = 0; c < 8; c++) o = fmaf(t[c], WSUM(sl, c), o);
             } else {
-                for (int c = 0; c < a.rv; c++) o = fmaf(h2f_bits(pv[c]), wacc[sl][c], o);
+                for (int c = 0; c < a.rv; c++) o = fmaf(h2f_bits(pv[c]), WSUM(sl, c), o);
             }
         }
         a.part_o[po * AD + tid] = o;
     }
+#undef WSUM
     if (tid == 0) {
         a.part_ml[po * 2] = m;
         a.part_ml[po * 2 + 1] = l;
@@ -368,34 +398,44 @@ __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, con
     const int ns = (a.dyn || a.T > 0) ? a.splits : 0;
     qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
     __syncthreads();
-    if (tid < W) {
-        const uint16_t* kr = kwin + (bhk * wcap + tid) * (int64_t)AD;
+    {   // window scores: thread pair per token, 64 channels (8 x 16-byte loads) each
+        const int j = tid >> 1, half = tid & 1;
         float acc = 0.0f;
-        for (int d = 0; d < AD; d++) acc = fmaf(qs[d], h2f_bits(kr[d]), acc);
-        sw[tid] = acc;
+        if (j < W) {
+            const uint4* kr = (const uint4*)(kwin + (bhk * wcap + j) * (int64_t)AD + half * 64);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float t[8];
+                unpack8(kr[i], t);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc = fmaf(qs[half * 64 + i * 8 + c], t[c], acc);
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        if (j < W && half == 0) sw[j] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
-        float M = -INFINITY;
-        for (int i = 0; i < ns; i++) M = fmaxf(M, a.part_ml[(bhq * a.splits + i) * 2]);
-        for (int j = 0; j < W; j++) M = fmaxf(M, sw[j]);
-        float Lsum = 0.0f;
-        for (int i = 0; i < ns; i++) {
-            float c = __expf(a.part_ml[(bhq * a.splits + i) * 2] - M);
-            coef[i] = c;
-            Lsum += c * a.part_ml[(bhq * a.splits + i) * 2 + 1];
-        }
-        for (int j = 0; j < W; j++) {
-            float c = __expf(sw[j] - M);
-            coef[64 + j] = c;
-            Lsum += c;
-        }
-        stat[0] = M;
-        stat[1] = Lsum;
+    if (tid < 64) {   // softmax statistics over <= 64 splits and <= 64 window tokens, one lane each
+        const float mi = tid < ns ? a.part_ml[(bhq * a.splits + tid) * 2] : -INFINITY;
+        const float li = tid < ns ? a.part_ml[(bhq * a.splits + tid) * 2 + 1] : 0.0f;
+        const float sj = tid < W ? sw[tid] : -INFINITY;
+        float M = fmaxf(mi, sj);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) M = fmaxf(M, __shfl_xor(M, d, 64));
+        const float ci = tid < ns ? __expf(mi - M) : 0.0f;
+        const float cw = tid < W ? __expf(sj - M) : 0.0f;
+        coef[tid] = ci;
+        coef[64 + tid] = cw;
+        float L = fmaf(ci, li, cw);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) L += __shfl_xor(L, d, 64);
+        if (tid == 0) { stat[0] = M; stat[1] = L; }
     }
     __syncthreads();
     float o = 0.0f;
+#pragma unroll 4
     for (int i = 0; i < ns; i++) o = fmaf(coef[i], a.part_o[(bhq * a.splits + i) * AD + tid], o);
+#pragma unroll 4
     for (int j = 0; j < W; j++) o = fmaf(coef[64 + j], h2f_bits(vwin[(bhk * wcap + j) * (int64_t)AD + tid]), o);
     out[bhq * AD + tid] = f2h_bits(o / stat[1]);
     if (lse && tid == 0) lse[bhq] = stat[0] + logf(stat[1]);
