@@ -1,11 +1,12 @@
-"""Fast single-token decode over GearKVCache: ~10 launches per layer instead of the ~60 eager torch ops the attention
+"""Fast single-token decode over GearKVCache: 6 launches per layer instead of the ~60 eager torch ops the attention
 hook's forward issues per layer per token (cuda_supported_gear/modeling_llamagear.py:177-484 + decoder layer :502-560).
 
 Takes the weights of a LlamaForCausalLM_GEARKIVI (any loader that fills that module works), fuses q/k/v and gate/up
-projections into single GEMV weights, keeps the KV cache in GearKVCache (pre-allocated, kernel-native) and runs
-    add+rmsnorm -> qkv GEMV -> RoPE+append -> fused attention over the compressed cache (2 launches) -> o_proj
-    -> add+rmsnorm -> gate/up GEMV -> silu*mul -> down GEMV
-per layer.  The GEMVs are plain library GEMVs through torch (F.linear); everything touching the cache is HIP.
+projections into single GEMV weights, keeps the KV cache in GearKVCache (pre-allocated, kernel-native) and runs per layer
+    [add + RMSNorm + qkv GEMV + RoPE + window append]  ->  fused attention over the compressed cache (2 launches)
+    ->  o_proj GEMV  ->  [add + RMSNorm + gate/up GEMV + SwiGLU]  ->  down GEMV
+with the bracketed groups being one launch each (gear_gemv_qkv_rope / gear_gemv_f16_norm) for batch <= 4; larger batches
+use the library GEMM through torch plus the glue kernels.  Everything touching the cache is HIP.
 """
 from __future__ import annotations
 
@@ -34,7 +35,9 @@ class FastGearDecoder:
             assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
             self.layers.append(dict(
                 wqkv=torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], 0).contiguous(),
-                wo=at.o_proj.weight, wgu=torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], 0).contiguous(),
+                wo=at.o_proj.weight,
+                # rows interleaved (gate_0, up_0, gate_1, ...): a GEMV wave finishes whole SwiGLU pairs
+                wgu=torch.stack([mlp.gate_proj.weight, mlp.up_proj.weight], 1).reshape(-1, mlp.gate_proj.weight.shape[1]).contiguous(),
                 wd=mlp.down_proj.weight, n1=layer.input_layernorm.weight, n2=layer.post_attention_layernorm.weight,
                 cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i),
                 rotary=at.rotary_emb))
@@ -68,12 +71,48 @@ class FastGearDecoder:
         L.check(rc, "gear_gemv_f16")
         return y
 
-    def _silu_mul(self, gu):
-        B, I2 = gu.shape
-        out = torch.empty((B, I2 // 2), dtype=gu.dtype, device=gu.device)
-        rc = L.load().gear_silu_mul(L.ptr(gu), B, I2 // 2, L.ptr(out), L.stream_ptr())
-        L.check(rc, "gear_silu_mul")
-        return out
+    def _fused(self, B, K):
+        return self.use_gemv and B <= 4 and K % 8 == 0
+
+    def _norm_linear(self, res, delta, nw, w, swiglu=False):
+        """(res + delta) -> RMSNorm -> w, optionally through SwiGLU (w rows interleaved).  Returns (new residual, y).
+        One launch (gear_gemv_f16_norm) for B <= 4; norm kernel + library GEMM otherwise."""
+        B, K = res.shape
+        N = w.shape[0]
+        if self._fused(B, K):
+            y = torch.empty((B, N // 2 if swiglu else N), dtype=res.dtype, device=res.device)
+            res_out = torch.empty_like(res) if delta is not None else None
+            rc = L.load().gear_gemv_f16_norm(L.ptr(res), L.ptr(delta), L.ptr(nw), self.eps, L.ptr(w), B, K, N,
+                                             1 if swiglu else 0, L.ptr(res_out), L.ptr(y), L.stream_ptr())
+            L.check(rc, "gear_gemv_f16_norm")
+            return (res_out if delta is not None else res), y
+        res, x = self._add_rmsnorm(res, delta, nw)
+        y = F.linear(x, w)
+        if swiglu:
+            y = F.silu(y[:, 0::2]) * y[:, 1::2]
+        return res, y
+
+    def _norm_qkv_rope(self, res, delta, lw, dyn):
+        """(res + delta) -> RMSNorm -> fused q/k/v projection -> RoPE; k, v land in the cache window.  Returns
+        (new residual, q [B,Hq,1,128]).  dyn: position / slot come from the device state (graph replay)."""
+        cache = lw["cache"]
+        B, K = res.shape
+        if self._fused(B, K):
+            q = torch.empty((B, self.Hq, 1, self.D), dtype=res.dtype, device=res.device)
+            res_out = torch.empty_like(res) if delta is not None else None
+            rc = L.load().gear_gemv_qkv_rope(
+                L.ptr(res), L.ptr(delta), L.ptr(lw["n1"]), self.eps, L.ptr(lw["wqkv"]), B, K, self.Hq, self.Hkv, self.D,
+                0 if dyn else self.pos, 0 if dyn else cache.n_win, cache.R, self.theta,
+                L.ptr(self.state) if dyn else None, L.ptr(res_out), L.ptr(q), L.ptr(cache.kwin), L.ptr(cache.vwin),
+                L.stream_ptr())
+            L.check(rc, "gear_gemv_qkv_rope")
+            if not dyn:
+                cache.n_win += 1
+            return (res_out if delta is not None else res), q
+        res, x = self._add_rmsnorm(res, delta, lw["n1"])
+        qkv = F.linear(x, lw["wqkv"])
+        q = cache.append_rope_dyn(qkv, self.Hq, self.theta) if dyn else cache.append_rope(qkv, self.Hq, self.pos, self.theta)
+        return res, q
 
     # ------------------------------------------------------------------------------------------------ prefill
     @torch.no_grad()
@@ -111,18 +150,16 @@ class FastGearDecoder:
         res = m.embed_tokens(token_ids.view(-1))            # [B, hidden]
         delta = None
         for lw in self.layers:
-            res, x = self._add_rmsnorm(res, delta, lw["n1"])
-            qkv = self._linear(x, lw["wqkv"])
             cache = lw["cache"]
-            q = cache.append_rope(qkv, self.Hq, self.pos, self.theta)
+            res, q = self._norm_qkv_rope(res, delta, lw, dyn=False)
             a = cache.attend(q)
             cache.maybe_compress()
             attn = self._linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
-            res, x = self._add_rmsnorm(res, attn, lw["n2"])
-            delta = self._linear(self._silu_mul(self._linear(x, lw["wgu"])), lw["wd"])
-        res, x = self._add_rmsnorm(res, delta, m.norm.weight)
+            res, act = self._norm_linear(res, attn, lw["n2"], lw["wgu"], swiglu=True)
+            delta = self._linear(act, lw["wd"])
+        res, logits = self._norm_linear(res, delta, m.norm.weight, self.model.lm_head.weight)
         self.pos += 1
-        return self._linear(x, self.model.lm_head.weight)
+        return logits
 
     # ------------------------------------------------------------------------------------------------ hipGraph decode
     def _sync_state(self):
@@ -136,16 +173,12 @@ class FastGearDecoder:
         res = m.embed_tokens(self.tok.view(-1))
         delta = None
         for lw in self.layers:
-            res, x = self._add_rmsnorm(res, delta, lw["n1"])
-            qkv = self._linear(x, lw["wqkv"])
-            cache = lw["cache"]
-            q = cache.append_rope_dyn(qkv, self.Hq, self.theta)
-            a = cache.attend_dyn(q)
+            res, q = self._norm_qkv_rope(res, delta, lw, dyn=True)
+            a = lw["cache"].attend_dyn(q)
             attn = self._linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
-            res, x = self._add_rmsnorm(res, attn, lw["n2"])
-            delta = self._linear(self._silu_mul(self._linear(x, lw["wgu"])), lw["wd"])
-        res, x = self._add_rmsnorm(res, delta, m.norm.weight)
-        logits = self._linear(x, self.model.lm_head.weight)
+            res, act = self._norm_linear(res, attn, lw["n2"], lw["wgu"], swiglu=True)
+            delta = self._linear(act, lw["wd"])
+        res, logits = self._norm_linear(res, delta, m.norm.weight, self.model.lm_head.weight)
         self.tok.copy_(logits.argmax(-1, keepdim=True))
         L.check(L.load().gear_decode_state_advance(L.ptr(self.state), L.stream_ptr()), "gear_decode_state_advance")
         return logits

@@ -190,3 +190,68 @@ def test_gemv_f16_matches_library(B, K, N):
     L.check(L.load().gear_gemv_f16(L.ptr(x), L.ptr(w), B, K, N, L.ptr(y), L.stream_ptr()), "gemv")
     ref = x.double() @ w.double().t()
     assert rel_fro(host(y).astype(np.float64), host(ref)) < 1e-3
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_fused_norm_gemv_matches_the_unfused_chain(B):
+    """gear_gemv_f16_norm == add -> RMSNorm -> linear (-> SwiGLU) of torch on the same fp16 tensors, to fp16 rounding."""
+    from gear_amd import _lib as L
+    from gear_amd.modeling_llamagear import LlamaRMSNorm
+    lib = L.load()
+    K, N = 512, 328
+    torch.manual_seed(1)
+    res, delta = torch.randn(B, K).half().cuda(), torch.randn(B, K).half().cuda()
+    norm = LlamaRMSNorm(K, 1e-5).half().cuda()
+    norm.weight.data = (1 + 0.1 * torch.randn(K)).half().cuda()
+    W = (torch.randn(N, K) / K ** 0.5).half().cuda()
+    for d in (delta, None):
+        for swiglu in (0, 1):
+            y = torch.empty(B, N // 2 if swiglu else N).half().cuda()
+            ro = torch.empty_like(res)
+            L.check(lib.gear_gemv_f16_norm(L.ptr(res), L.ptr(d), L.ptr(norm.weight), 1e-5, L.ptr(W), B, K, N, swiglu,
+                                           L.ptr(ro), L.ptr(y), L.stream_ptr()), "gemv_norm")
+            v = res + d if d is not None else res
+            if d is not None:
+                assert torch.equal(ro, v)
+            ref = torch.nn.functional.linear(norm(v).float(), W.float())
+            if swiglu:
+                ref = torch.nn.functional.silu(ref[:, 0::2]) * ref[:, 1::2]
+            assert float((y.float() - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+    # aliasing the new residual with an input is refused (other workgroups still read it)
+    with pytest.raises(L.GearError):
+        L.check(lib.gear_gemv_f16_norm(L.ptr(res), L.ptr(delta), L.ptr(norm.weight), 1e-5, L.ptr(W), B, K, N, 0,
+                                       L.ptr(res), L.ptr(y), L.stream_ptr()), "alias")
+
+
+def test_fused_qkv_rope_matches_gemv_plus_rope_append():
+    """gear_gemv_qkv_rope == gear_add_rmsnorm -> gear_gemv_f16 -> gear_rope_append (the same rotation arithmetic on GEMV
+    outputs that differ by fp16 rounding of the folded norm scale), with host and device-side pos / slot."""
+    from gear_amd import _lib as L
+    lib = L.load()
+    B, K, Hq, Hkv, R = 2, 512, 4, 2, 64
+    torch.manual_seed(2)
+    res, delta = torch.randn(B, K).half().cuda(), torch.randn(B, K).half().cuda()
+    nw = (1 + 0.1 * torch.randn(K)).half().cuda()
+    W = (torch.randn((Hq + 2 * Hkv) * 128, K) / K ** 0.5).half().cuda()
+    pos, slot = 777, 9
+    # unfused chain
+    x, ro = torch.empty_like(res), torch.empty_like(res)
+    L.check(lib.gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(nw), B, K, 1e-5, L.ptr(ro), L.ptr(x), L.stream_ptr()), "n")
+    qkv = torch.empty(B, W.shape[0]).half().cuda()
+    L.check(lib.gear_gemv_f16(L.ptr(x), L.ptr(W), B, K, W.shape[0], L.ptr(qkv), L.stream_ptr()), "g")
+    q0 = torch.empty(B, Hq, 1, 128).half().cuda()
+    kw0, vw0 = torch.zeros(B, Hkv, R, 128).half().cuda(), torch.zeros(B, Hkv, R, 128).half().cuda()
+    L.check(lib.gear_rope_append(L.ptr(qkv), B, Hq, Hkv, 128, pos, 10000.0, L.ptr(q0), L.ptr(kw0), L.ptr(vw0), slot, R,
+                                 L.stream_ptr()), "r")
+    state = torch.tensor([pos, slot, 0, slot + 1], dtype=torch.int32).cuda()
+    for dyn in (None, state):
+        q1 = torch.empty_like(q0)
+        kw1, vw1, ro1 = torch.zeros_like(kw0), torch.zeros_like(vw0), torch.empty_like(res)
+        L.check(lib.gear_gemv_qkv_rope(L.ptr(res), L.ptr(delta), L.ptr(nw), 1e-5, L.ptr(W), B, K, Hq, Hkv, 128,
+                                       0 if dyn is not None else pos, 0 if dyn is not None else slot, R, 10000.0,
+                                       L.ptr(dyn), L.ptr(ro1), L.ptr(q1), L.ptr(kw1), L.ptr(vw1), L.stream_ptr()), "f")
+        assert torch.equal(ro1, ro)
+        for got, ref in ((q1, q0), (kw1, kw0), (vw1, vw0)):
+            assert float((got.float() - ref.float()).abs().max()) <= 6e-3 * float(ref.abs().max())
+        # only the addressed slot is written
+        assert float(kw1[:, :, :slot].abs().max()) == 0 and float(kw1[:, :, slot + 1:].abs().max()) == 0
