@@ -39,6 +39,7 @@ SIGNATURES = {
     "gear_rope_append_dyn": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp, _i, _vp]),
     "gear_decode_state_advance": (_i, [_vp, _vp]),
     "gear_gemv_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gear_gemv_f16_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gear_gemv_f16_norm": (_i, [_vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gear_gemv_qkv_rope": (_i, [_vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _vp,
                                 _vp, _vp, _vp, _vp, _vp]),

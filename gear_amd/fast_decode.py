@@ -3,10 +3,10 @@ hook's forward issues per layer per token (cuda_supported_gear/modeling_llamagea
 
 Takes the weights of a LlamaForCausalLM_GEARKIVI (any loader that fills that module works), fuses q/k/v and gate/up
 projections into single GEMV weights, keeps the KV cache in GearKVCache (pre-allocated, kernel-native) and runs per layer
-    [add + RMSNorm + qkv GEMV + RoPE + window append]  ->  fused attention over the compressed cache (2 launches)
-    ->  o_proj GEMV  ->  [add + RMSNorm + gate/up GEMV + SwiGLU]  ->  down GEMV
-with the bracketed groups being one launch each (gear_gemv_qkv_rope / gear_gemv_f16_norm) for batch <= 4; larger batches
-use the library GEMM through torch plus the glue kernels.  Everything touching the cache is HIP.
+    [RMSNorm + qkv GEMV + RoPE + window append]  ->  fused attention over the compressed cache (2 launches)
+    ->  [o_proj GEMV + residual add]  ->  [RMSNorm + gate/up GEMV + SwiGLU]  ->  [down GEMV + residual add]
+with each bracketed group being one launch (gear_gemv_qkv_rope / gear_gemv_f16_add / gear_gemv_f16_norm) for batch <= 4;
+larger batches use the library GEMM through torch.  Everything touching the cache is HIP.
 """
 from __future__ import annotations
 
@@ -33,14 +33,17 @@ class FastGearDecoder:
         for i, layer in enumerate(model.model.layers):
             at, mlp = layer.self_attn, layer.mlp
             assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
+            # RMSNorm weights are folded into the columns of the projection that follows them (the GEMV applies the
+            # row scale rsqrt(mean(h^2) + eps) to its finished dot products), gate/up rows are interleaved so a GEMV
+            # block finishes whole SwiGLU pairs
+            n1, n2 = layer.input_layernorm.weight, layer.post_attention_layernorm.weight
+            wqkv = torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], 0) * n1[None, :]
+            wgu = torch.stack([mlp.gate_proj.weight, mlp.up_proj.weight], 1).reshape(-1, n2.shape[0]) * n2[None, :]
             self.layers.append(dict(
-                wqkv=torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], 0).contiguous(),
-                wo=at.o_proj.weight,
-                # rows interleaved (gate_0, up_0, gate_1, ...): a GEMV wave finishes whole SwiGLU pairs
-                wgu=torch.stack([mlp.gate_proj.weight, mlp.up_proj.weight], 1).reshape(-1, mlp.gate_proj.weight.shape[1]).contiguous(),
-                wd=mlp.down_proj.weight, n1=layer.input_layernorm.weight, n2=layer.post_attention_layernorm.weight,
+                wqkv=wqkv.contiguous(), wo=at.o_proj.weight, wgu=wgu.contiguous(), wd=mlp.down_proj.weight,
                 cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i),
                 rotary=at.rotary_emb))
+        self.w_head = (model.lm_head.weight * model.model.norm.weight[None, :]).contiguous()
         self.pos = 0
         self.use_gemv = True
         self.batch = batch
@@ -53,66 +56,55 @@ class FastGearDecoder:
         self.logits_static = None
 
     # ------------------------------------------------------------------------------------------------ helpers
-    def _add_rmsnorm(self, res, delta, w):
-        B, H = res.shape
-        y = torch.empty_like(res)
-        res_out = torch.empty_like(res) if delta is not None else None
-        rc = L.load().gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(w), B, H, self.eps, L.ptr(res_out), L.ptr(y), L.stream_ptr())
-        L.check(rc, "gear_add_rmsnorm")
-        return (res_out if delta is not None else res), y
-
-    def _linear(self, x, w):
-        """x [B, K] @ w[N, K]^T for the token step: the build's fp16 GEMV for B <= 4, the library otherwise."""
-        B, K = x.shape
-        if B > 4 or K % 8 or not self.use_gemv:
-            return F.linear(x, w)
-        y = torch.empty((B, w.shape[0]), dtype=x.dtype, device=x.device)
-        rc = L.load().gear_gemv_f16(L.ptr(x), L.ptr(w), B, K, w.shape[0], L.ptr(y), L.stream_ptr())
-        L.check(rc, "gear_gemv_f16")
-        return y
-
     def _fused(self, B, K):
         return self.use_gemv and B <= 4 and K % 8 == 0
 
-    def _norm_linear(self, res, delta, nw, w, swiglu=False):
-        """(res + delta) -> RMSNorm -> w, optionally through SwiGLU (w rows interleaved).  Returns (new residual, y).
-        One launch (gear_gemv_f16_norm) for B <= 4; norm kernel + library GEMM otherwise."""
+    def _unit_rms(self, h):
+        """RMSNorm without its weight (folded into the next projection), fp32 statistics like LlamaRMSNorm."""
+        hf = h.float()
+        return (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + self.eps)).to(h.dtype)
+
+    def _linear_add(self, x, w, res):
+        """res + x @ w^T: the residual-stream update after o_proj / down_proj (gear_gemv_f16_add for B <= 4)."""
+        B, K = x.shape
+        if not self._fused(B, K):
+            return res + F.linear(x, w)
+        y = torch.empty_like(res)
+        rc = L.load().gear_gemv_f16_add(L.ptr(x), L.ptr(w), B, K, w.shape[0], L.ptr(res), L.ptr(y), L.stream_ptr())
+        L.check(rc, "gear_gemv_f16_add")
+        return y
+
+    def _norm_linear(self, res, w, swiglu=False):
+        """RMSNorm(res) -> w (norm weight folded into w), optionally through SwiGLU (w rows interleaved).
+        One launch (gear_gemv_f16_norm) for B <= 4; library GEMM otherwise."""
         B, K = res.shape
         N = w.shape[0]
         if self._fused(B, K):
             y = torch.empty((B, N // 2 if swiglu else N), dtype=res.dtype, device=res.device)
-            res_out = torch.empty_like(res) if delta is not None else None
-            rc = L.load().gear_gemv_f16_norm(L.ptr(res), L.ptr(delta), L.ptr(nw), self.eps, L.ptr(w), B, K, N,
-                                             1 if swiglu else 0, L.ptr(res_out), L.ptr(y), L.stream_ptr())
+            rc = L.load().gear_gemv_f16_norm(L.ptr(res), None, None, self.eps, L.ptr(w), B, K, N, 1 if swiglu else 0,
+                                             None, L.ptr(y), L.stream_ptr())
             L.check(rc, "gear_gemv_f16_norm")
-            return (res_out if delta is not None else res), y
-        res, x = self._add_rmsnorm(res, delta, nw)
-        y = F.linear(x, w)
-        if swiglu:
-            y = F.silu(y[:, 0::2]) * y[:, 1::2]
-        return res, y
+            return y
+        y = F.linear(self._unit_rms(res), w)
+        return F.silu(y[:, 0::2]) * y[:, 1::2] if swiglu else y
 
-    def _norm_qkv_rope(self, res, delta, lw, dyn):
-        """(res + delta) -> RMSNorm -> fused q/k/v projection -> RoPE; k, v land in the cache window.  Returns
-        (new residual, q [B,Hq,1,128]).  dyn: position / slot come from the device state (graph replay)."""
+    def _norm_qkv_rope(self, res, lw, dyn):
+        """RMSNorm(res) -> fused q/k/v projection -> RoPE; k, v land in the cache window.  Returns q [B,Hq,1,128].
+        dyn: position / slot come from the device state (graph replay)."""
         cache = lw["cache"]
         B, K = res.shape
         if self._fused(B, K):
             q = torch.empty((B, self.Hq, 1, self.D), dtype=res.dtype, device=res.device)
-            res_out = torch.empty_like(res) if delta is not None else None
             rc = L.load().gear_gemv_qkv_rope(
-                L.ptr(res), L.ptr(delta), L.ptr(lw["n1"]), self.eps, L.ptr(lw["wqkv"]), B, K, self.Hq, self.Hkv, self.D,
+                L.ptr(res), None, None, self.eps, L.ptr(lw["wqkv"]), B, K, self.Hq, self.Hkv, self.D,
                 0 if dyn else self.pos, 0 if dyn else cache.n_win, cache.R, self.theta,
-                L.ptr(self.state) if dyn else None, L.ptr(res_out), L.ptr(q), L.ptr(cache.kwin), L.ptr(cache.vwin),
-                L.stream_ptr())
+                L.ptr(self.state) if dyn else None, None, L.ptr(q), L.ptr(cache.kwin), L.ptr(cache.vwin), L.stream_ptr())
             L.check(rc, "gear_gemv_qkv_rope")
             if not dyn:
                 cache.n_win += 1
-            return (res_out if delta is not None else res), q
-        res, x = self._add_rmsnorm(res, delta, lw["n1"])
-        qkv = F.linear(x, lw["wqkv"])
-        q = cache.append_rope_dyn(qkv, self.Hq, self.theta) if dyn else cache.append_rope(qkv, self.Hq, self.pos, self.theta)
-        return res, q
+            return q
+        qkv = F.linear(self._unit_rms(res), lw["wqkv"])
+        return cache.append_rope_dyn(qkv, self.Hq, self.theta) if dyn else cache.append_rope(qkv, self.Hq, self.pos, self.theta)
 
     # ------------------------------------------------------------------------------------------------ prefill
     @torch.no_grad()
@@ -125,8 +117,7 @@ class FastGearDecoder:
         pos = torch.arange(T, device=self.dev).unsqueeze(0)
         n_rep = self.Hq // self.Hkv
         for lw, layer in zip(self.layers, m.layers):
-            x = layer.input_layernorm(h)
-            qkv = F.linear(x, lw["wqkv"])
+            qkv = F.linear(self._unit_rms(h), lw["wqkv"])      # input_layernorm's weight lives in wqkv's columns
             q, k, v = qkv.split([self.Hq * self.D, self.Hkv * self.D, self.Hkv * self.D], dim=-1)
             q = q.view(B, T, self.Hq, self.D).transpose(1, 2)
             k = k.view(B, T, self.Hkv, self.D).transpose(1, 2)
@@ -148,18 +139,16 @@ class FastGearDecoder:
         """token_ids [B, 1] (or [B]) -> logits [B, vocab]; advances every layer's cache by one token."""
         m = self.model.model
         res = m.embed_tokens(token_ids.view(-1))            # [B, hidden]
-        delta = None
         for lw in self.layers:
             cache = lw["cache"]
-            res, q = self._norm_qkv_rope(res, delta, lw, dyn=False)
+            q = self._norm_qkv_rope(res, lw, dyn=False)
             a = cache.attend(q)
             cache.maybe_compress()
-            attn = self._linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
-            res, act = self._norm_linear(res, attn, lw["n2"], lw["wgu"], swiglu=True)
-            delta = self._linear(act, lw["wd"])
-        res, logits = self._norm_linear(res, delta, m.norm.weight, self.model.lm_head.weight)
+            res = self._linear_add(a.view(a.shape[0], self.Hq * self.D), lw["wo"], res)
+            act = self._norm_linear(res, lw["wgu"], swiglu=True)
+            res = self._linear_add(act, lw["wd"], res)
         self.pos += 1
-        return logits
+        return self._norm_linear(res, self.w_head)
 
     # ------------------------------------------------------------------------------------------------ hipGraph decode
     def _sync_state(self):
@@ -171,14 +160,13 @@ class FastGearDecoder:
         token, so the whole thing (embedding -> 32 layers -> lm_head -> argmax -> state advance) is one graph."""
         m = self.model.model
         res = m.embed_tokens(self.tok.view(-1))
-        delta = None
         for lw in self.layers:
-            res, q = self._norm_qkv_rope(res, delta, lw, dyn=True)
+            q = self._norm_qkv_rope(res, lw, dyn=True)
             a = lw["cache"].attend_dyn(q)
-            attn = self._linear(a.view(a.shape[0], self.Hq * self.D), lw["wo"])
-            res, act = self._norm_linear(res, attn, lw["n2"], lw["wgu"], swiglu=True)
-            delta = self._linear(act, lw["wd"])
-        res, logits = self._norm_linear(res, delta, m.norm.weight, self.model.lm_head.weight)
+            res = self._linear_add(a.view(a.shape[0], self.Hq * self.D), lw["wo"], res)
+            act = self._norm_linear(res, lw["wgu"], swiglu=True)
+            res = self._linear_add(act, lw["wd"], res)
+        logits = self._norm_linear(res, self.w_head)
         self.tok.copy_(logits.argmax(-1, keepdim=True))
         L.check(L.load().gear_decode_state_advance(L.ptr(self.state), L.stream_ptr()), "gear_decode_state_advance")
         return logits

@@ -210,12 +210,14 @@ int gear_decode_state_advance(void* state, void* stream);
  * (torch.nn.functional.linear for one token; used by FastGearDecoder for the q/k/v, o, gate/up, down and lm_head GEMVs)
  */
 int gear_gemv_f16(const void* x, const void* W, int B, int K, int N, void* y, void* stream);
+/* y = res_in + W x (the residual-stream update after o_proj / down_proj); y may alias res_in, not x */
+int gear_gemv_f16_add(const void* x, const void* W, int B, int K, int N, const void* res_in, void* y, void* stream);
 
 /* Fused token-step projections (same 1 <= B <= 4, K % 8 == 0).  They fold the glue launches of a decoder layer
  * (cuda_supported_gear/modeling_llamagear.py:502-560: input_layernorm / post_attention_layernorm, :193-205 q/k/v + rotary,
  * LlamaMLP act_fn(gate) * up) into the weight stream:
  *   gear_gemv_f16_norm : v = x + delta (delta may be NULL; otherwise res_out [B,K] receives v and must not alias x/delta);
- *                        y = W . (norm_w * v) * rsqrt(mean(v^2) + eps).   swiglu != 0: W rows are interleaved
+ *                        y = W . (norm_w * v) * rsqrt(mean(v^2) + eps)  (norm_w NULL: already folded into W's columns).   swiglu != 0: W rows are interleaved
  *                        (gate_0, up_0, gate_1, up_1, ...) and y [B, N/2] = fp16(silu(gate)) * up.
  *   gear_gemv_qkv_rope : the same prologue, W = [q heads | k heads | v heads] x 128 rows; RoPE (HF rotate_half, fp16 op by
  *                        op) on q and k at `pos`; q -> q_out [B,Hq,128]; k, v -> window slot `slot` of kwin / vwin

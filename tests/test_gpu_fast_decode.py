@@ -217,6 +217,19 @@ def test_fused_norm_gemv_matches_the_unfused_chain(B):
             if swiglu:
                 ref = torch.nn.functional.silu(ref[:, 0::2]) * ref[:, 1::2]
             assert float((y.float() - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+    # norm weight folded into W's columns (norm_w NULL) + the residual-add GEMV, in place
+    Wf = (W.float() * norm.weight.float()[None, :]).half()
+    y = torch.empty(B, N).half().cuda()
+    L.check(lib.gear_gemv_f16_norm(L.ptr(res), None, None, 1e-5, L.ptr(Wf), B, K, N, 0, None, L.ptr(y), L.stream_ptr()), "folded")
+    ref = torch.nn.functional.linear(norm(res).float(), W.float())
+    assert float((y.float() - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+    for Kd in (K, 8192 + 64):   # the second shape takes the split-K path
+        xd, Wd = torch.randn(B, Kd).half().cuda(), (torch.randn(K, Kd) / Kd ** 0.5).half().cuda()
+        r0 = torch.randn(B, K).half().cuda()
+        ref = (r0.float() + torch.nn.functional.linear(xd.float(), Wd.float()).half().float()).half()
+        r1 = r0.clone()
+        L.check(lib.gear_gemv_f16_add(L.ptr(xd), L.ptr(Wd), B, Kd, K, L.ptr(r1), L.ptr(r1), L.stream_ptr()), "add")
+        assert float((r1.float() - ref.float()).abs().max()) <= 4e-3 * float(ref.abs().max())
     # aliasing the new residual with an input is refused (other workgroups still read it)
     with pytest.raises(L.GearError):
         L.check(lib.gear_gemv_f16_norm(L.ptr(res), L.ptr(delta), L.ptr(norm.weight), 1e-5, L.ptr(W), B, K, N, 0,
