@@ -16,6 +16,7 @@
 //      + V outliers of the chunk's tokens that fall into this head
 // A second kernel merges the splits and the fp16 window and applies Pv w.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -380,6 +381,282 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Short-chunk variant (chunk = 128 tokens = two 64-token slabs; the plan for contexts up to 8k, ranks 0 or 8).
+//
+// With ~14 KB of payload per workgroup the kernel above is bound by two fixed costs, both measured (tools/exp_attn.py: its
+// time does not change between 1k and 4k tokens): a chain of dependent global-load phases (factors -> K -> Qk -> V -> Qv
+// -> Pv), and instruction fetch -- a dispatch starts with a cold instruction cache and ~27 KB of unrolled straight-line
+// code is ~420 cache lines fetched from L2 one after the other.  Here (1) none of the chunk's addresses depends on computed
+// data, so EVERY load is issued into registers before the first barrier, and (2) the code is kept small: one factor row per
+// thread (a slab lies inside one factor segment because segments are multiples of 64 tokens), cross-lane sums by a halving
+// butterfly (N values over 2^k lanes in N-ish shuffles instead of N*k), per-wave LDS slots merged in a fixed order
+// (deterministic; float atomics only in the outlier terms).
+constexpr int SC = 128;
+
+// Halving butterfly over the lane bits TOP, TOP/2, ... (STEPS of them): on entry every lane holds N partial values, on exit
+// v[0 .. (N >> STEPS) - 1] hold the sums over the lane group of the values with index base + i, where
+// base = sum over steps k of (lane & (TOP >> k)) ? N >> (k + 1) : 0.  Returns base.
+template <int N, int TOP, int STEPS>
+__device__ __forceinline__ int halving_reduce(float (&v)[N], int lane) {
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) {
+        const int mask = TOP >> k, half = N >> (k + 1);
+        const bool upper = (lane & mask) != 0;
+        if (upper) base += half;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+            float lo = v[i], hi = v[i + half];
+            asm volatile("" : "+v"(lo), "+v"(hi));   // keep two plain selects (the optimiser otherwise turns them into a
+                                                     // lane-dependent index into the whole array: N compare/select pairs)
+            const float send = upper ? lo : hi;
+            const float keep = upper ? hi : lo;
+            v[i] = keep + __shfl_xor(send, mask, 64);
+        }
+    }
+    return base;
+}
+
+// 8 values summed over the 64 lanes of a wave; lanes 0, 8, ..., 56 end up with value index lane / 8 in the return value
+__device__ __forceinline__ float reduce8_over_wave(float (&v)[8], int lane) {
+    halving_reduce<8, 32, 3>(v, lane);
+    float r = v[0];
+    r += __shfl_xor(r, 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+template <int BITS, typename ST>
+__global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    constexpr int NWC = SC / CPW;    // K: packed words per channel in the chunk (8 | 16) = lanes along tokens
+    constexpr int NDS = 256 / NWC;   // K: channel subsets (32 | 16)
+    constexpr int KIT = AD / NDS;    // K: channels per thread (4 | 8)
+    constexpr int NWV = AD / CPW;    // V: packed words per token row (8 | 16) = lanes along channels
+    constexpr int NRS = 256 / NWV;   // V: token subsets (32 | 16)
+    constexpr int VIT = SC / NRS;    // V: tokens per thread (4 | 8)
+    constexpr int XS = BITS == 2 ? 3 : 2;   // butterfly steps over the in-wave subset lanes (64 / NWC = 8 | 4 of them)
+    __shared__ float qs[AD];
+    __shared__ float up[4][8];       // Pk[seg(slab)]^T q: waves 0,1 -> slab 0 (channels 0-63 / 64-127), waves 2,3 -> slab 1
+    __shared__ float sp[4][SC];      // K side: per-wave partial scores
+    __shared__ float s[SC];
+    __shared__ float op[4][AD];      // V side: per-wave partial outputs
+    __shared__ float ot[2][AD];      // Pv[seg(slab)] (Qv^T p)_slab
+    __shared__ float oacc[AD];
+    __shared__ float wsl[2][8];      // Qv^T p of the two slabs
+    __shared__ float red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x;
+    const int64_t bhq = blockIdx.y;
+    const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    const int t0 = split * SC;
+    const int Tc = a.dyn ? a.dyn[2] : a.T;
+    const int tn = min(SC, Tc - t0);
+    const int64_t po = bhq * a.splits + split;
+    if (tn <= 0) {
+        if (tid < AD) a.part_o[po * AD + tid] = 0.0f;
+        if (tid == 0) { a.part_ml[po * 2] = -INFINITY; a.part_ml[po * 2 + 1] = 0.0f; }
+        return;
+    }
+    const ST* kscale = (const ST*)a.kscale;
+    const ST* kmn = (const ST*)a.kmn;
+    const ST* vscale = (const ST*)a.vscale;
+    const ST* vmn = (const ST*)a.vmn;
+
+    // ------------------------------------------------------------------ every load of the chunk
+    const int dq = tid & (AD - 1), slab = tid >> 7;   // factor rows: one (slab, channel) per thread
+    const int tslab = min(t0 + 64 * slab, t0 + tn - 1);
+    const int seg = (a.seglen == 0 || tslab < a.seg0) ? 0 : 1 + (tslab - a.seg0) / a.seglen;
+    const float qv = h2f_bits(a.q[bhq * AD + dq]) * a.qscale;
+    const int lw = tid & (NWC - 1), dsub = tid / NWC;
+    const bool kval = lw * CPW < tn;
+    uint32_t kw[KIT];
+    float ksc[KIT], kmv[KIT];
+    {
+        const int gk = (t0 + lw * CPW) / a.group;
+#pragma unroll
+        for (int i = 0; i < KIT; i++) {
+            const int64_t ch = bhk * AD + dsub + NDS * i;
+            kw[i] = kval ? a.kcode[ch * a.ldk + t0 / CPW + lw] : 0u;
+            ksc[i] = kval ? ld_st<ST>(kscale + ch * a.lsk + gk) : 0.0f;
+            kmv[i] = kval ? ld_st<ST>(kmn + ch * a.lsk + gk) : 0.0f;
+        }
+    }
+    const int wv = tid & (NWV - 1), rsub = tid / NWV;
+    uint32_t vw[VIT];
+    float vsc[VIT], vmv[VIT];
+    {
+        const int gv = (wv * CPW) / a.group, ngv = AD / a.group;
+#pragma unroll
+        for (int i = 0; i < VIT; i++) {
+            const int t = rsub + NRS * i;
+            const int64_t row = bhk * a.tcap_v + t0 + t;
+            const bool ok = t < tn;
+            vw[i] = ok ? a.vcode[row * NWV + wv] : 0u;
+            vsc[i] = ok ? ld_st<ST>(vscale + row * ngv + gv) : 0.0f;
+            vmv[i] = ok ? ld_st<ST>(vmn + row * ngv + gv) : 0.0f;
+        }
+    }
+    uint4 kq8 = {0, 0, 0, 0}, vq8 = {0, 0, 0, 0}, kp8 = {0, 0, 0, 0}, vp8 = {0, 0, 0, 0};
+    if (a.rk) {
+        kp8 = *(const uint4*)(a.kP + (int64_t)seg * a.kP_seg_stride + (bhk * AD + dq) * 8);
+        if (tid < tn) kq8 = *(const uint4*)(a.kQ + (bhk * a.tf_k + t0 + tid) * 8);
+    }
+    if (a.rv) {
+        vp8 = *(const uint4*)(a.vP + (int64_t)seg * a.vP_seg_stride + (bhk * AD + dq) * 8);
+        if (tid < tn) vq8 = *(const uint4*)(a.vQ + (bhk * a.tf_v + t0 + tid) * 8);
+    }
+
+    // ------------------------------------------------------------------ 1. scores
+    if (tid < AD) qs[tid] = qv;
+    if (a.rk) {   // up[wave][:] = sum over this wave's 64 channels of q[d] Pk[seg(slab)][d][:]
+        float pr[8];
+        unpack8(kp8, pr);
+#pragma unroll
+        for (int c = 0; c < 8; c++) pr[c] *= qv;
+        const float r = reduce8_over_wave(pr, lane);
+        if ((lane & 7) == 0) up[wave][lane >> 3] = r;
+    }
+    __syncthreads();
+    {
+        float acc[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; j++) acc[j] = 0.0f;
+        float zacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KIT; i++) {
+            const float qd = qs[dsub + NDS * i];
+            const float sa = ksc[i] * qd;
+            zacc = fmaf(kmv[i], qd, zacc);
+#pragma unroll
+            for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((kw[i] >> (BITS * j)) & MASK), acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CPW; j++) acc[j] += zacc;
+        const int base = halving_reduce<CPW, 32, XS>(acc, lane);   // over the wave's channel subsets; 2 tokens left per lane
+        *(float2*)&sp[wave][lw * CPW + base] = make_float2(acc[0], acc[1]);
+    }
+    __syncthreads();
+    float sv = -INFINITY;
+    if (tid < tn) {
+        float v = (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
+        if (a.rk) {   // tid < 128: slab = tid / 64 = wave
+            float tq[8], acc = 0.0f;
+            unpack8(kq8, tq);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc = fmaf(tq[c], up[2 * wave][c] + up[2 * wave + 1][c], acc);
+            v += acc;
+        }
+        sv = v;
+    }
+    if (a.kk > 0) {   // K outliers inside the chunk: s[t] += q[d] (val - dequant(t, d))
+        if (tid < SC) s[tid] = sv;
+        __syncthreads();
+        if (tid < AD) {
+            const int d = tid;
+            for (int side = 0; side < 2; side++) {
+                const uint16_t* oi = a.koidx + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
+                const uint16_t* ov = a.koval + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
+                for (int i = lower_bound_u16(oi, a.kk, t0); i < a.kk; i++) {
+                    const int t = oi[i];
+                    if (t >= t0 + tn) break;
+                    const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + t / CPW];
+                    const int g = t / a.group;
+                    const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
+                    const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
+                    const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & MASK), mnv);
+                    atomicAdd(&s[t - t0], qv * (h2f_bits(ov[i]) - deq));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < SC) sv = s[tid];
+    }
+    // ------------------------------------------------------------------ 2. chunk softmax statistics
+    const float m = block_reduce_max(sv, red);
+    const float p = tid < tn ? __expf(sv - m) : 0.0f;
+    if (tid < SC) s[tid] = p;
+    const float l = block_reduce_sum(p, red);   // (contains the barrier that publishes s[])
+    // ------------------------------------------------------------------ 3. V side
+    {
+        float acc[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; j++) acc[j] = 0.0f;
+        float zacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VIT; i++) {
+            const float pt = s[rsub + NRS * i];
+            const float sa = vsc[i] * pt;
+            zacc = fmaf(vmv[i], pt, zacc);
+#pragma unroll
+            for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((vw[i] >> (BITS * j)) & MASK), acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CPW; j++) acc[j] += zacc;
+        const int base = halving_reduce<CPW, 32, XS>(acc, lane);   // over the wave's token subsets
+        *(float2*)&op[wave][wv * CPW + base] = make_float2(acc[0], acc[1]);
+    }
+    if (a.rv && tid < SC) {   // wsl[slab][:] = sum over the slab's 64 tokens of p[t] Qv[t][:]   (slab = wave)
+        float wl[8];
+        unpack8(vq8, wl);
+#pragma unroll
+        for (int c = 0; c < 8; c++) wl[c] *= p;
+        const float r = reduce8_over_wave(wl, lane);
+        if ((lane & 7) == 0) wsl[wave][lane >> 3] = r;
+    }
+    __syncthreads();
+    if (a.rv) {   // the unnormalised partial is linear in p: ot[slab][d] = Pv[seg(slab)][d][:] . wsl[slab]
+        float t[8], acc = 0.0f;
+        unpack8(vp8, t);
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc = fmaf(t[c], wsl[slab][c], acc);
+        ot[slab][dq] = (slab * 64 < tn) ? acc : 0.0f;
+        __syncthreads();
+    }
+    float o = 0.0f;
+    if (tid < AD) {
+        o = (op[0][tid] + op[1][tid]) + (op[2][tid] + op[3][tid]);
+        if (a.rv) o += ot[0][tid] + ot[1][tid];
+    }
+    if (a.kv > 0) {   // V outliers of the chunk's tokens that fall into this head's 128 columns
+        if (tid < AD) oacc[tid] = o;
+        __syncthreads();
+        if (tid < tn) {
+            const int c_lo = hkv * AD, c_hi = c_lo + AD;
+            const int ngv = AD / a.group;
+            const int64_t orow = (int64_t)b * a.tcap_v + t0 + tid;
+            const int64_t row = bhk * a.tcap_v + t0 + tid;
+            for (int side = 0; side < 2; side++) {
+                const uint16_t* oi = a.voidx + (orow * 2 + side) * a.kv;
+                const uint16_t* ov = a.voval + (orow * 2 + side) * a.kv;
+                for (int i = lower_bound_u16(oi, a.kv, c_lo); i < a.kv; i++) {
+                    const int col = oi[i];
+                    if (col >= c_hi) break;
+                    const int d = col - c_lo;
+                    const uint32_t word = a.vcode[row * NWV + d / CPW];
+                    const float sc = ld_st<ST>(vscale + row * ngv + d / a.group);
+                    const float mnv = ld_st<ST>(vmn + row * ngv + d / a.group);
+                    const float deq = fmaf(sc, (float)((word >> (BITS * (d % CPW))) & MASK), mnv);
+                    atomicAdd(&oacc[d], p * (h2f_bits(ov[i]) - deq));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < AD) o = oacc[tid];
+    }
+    if (tid < AD) a.part_o[po * AD + tid] = o;
+    if (tid == 0) {
+        a.part_ml[po * 2] = m;
+        a.part_ml[po * 2 + 1] = l;
+    }
+}
+
 // merge the splits + the fp16 window, apply the V low-rank factor, normalise.  grid (B*Hq), block 128.
 __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
                                                                  const uint16_t* __restrict__ vwin, int W_arg, int wcap,
@@ -441,8 +718,11 @@ __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, con
     if (lse && tid == 0) lse[bhq] = stat[0] + logf(stat[1]);
 }
 
-int plan_splits(int T, int bits, int64_t bhq, int* tc_out) {
+int plan_splits(int T, int bits, int64_t bhq, bool fast_ranks, int* tc_out, bool* small) {
+    *small = false;
     if (T <= 0) { *tc_out = 64; return 1; }
+    // contexts up to 8k (ranks 0 / 8): 128-token chunks (<= 64 splits for the reduce kernel) -> attn_decode_partial_small
+    if (T <= 64 * SC && fast_ranks && !getenv("GEAR_ATTN_GENERIC")) { *tc_out = SC; *small = true; return (T + SC - 1) / SC; }
     // enough workgroups to cover the chip a few times over, chunks a multiple of 64 tokens
     int splits = 1;
     while (splits < 64 && (int64_t)splits * bhq < 1024 && T / (splits * 2) >= 128) splits *= 2;
@@ -457,9 +737,9 @@ int plan_splits(int T, int bits, int64_t bhq, int* tc_out) {
 }  // namespace
 
 extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
-    int tc;
-    int splits = plan_splits(T, bits, (int64_t)B * Hq, &tc);
-    return (size_t)B * Hq * splits * (AD + 16 + 2) * sizeof(float) + 256;
+    // sized for the largest plan (64 splits) so that a buffer obtained for the cache capacity serves every shorter length
+    (void)T; (void)bits;
+    return (size_t)B * Hq * 64 * (AD + 16 + 2) * sizeof(float) + 256;
 }
 
 extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
@@ -503,7 +783,8 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
     a.dyn = (const int*)dyn_state;
     a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
     a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
-    a.splits = plan_splits(T, bits, (int64_t)B * Hq, &a.tc);
+    bool small;
+    a.splits = plan_splits(T, bits, (int64_t)B * Hq, (a.rk == 0 || a.rk == 8) && (a.rv == 0 || a.rv == 8), &a.tc, &small);
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     a.part_o = ws;
     a.part_w = a.part_o + (size_t)B * Hq * a.splits * AD;
@@ -511,7 +792,11 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
     hipStream_t st = (hipStream_t)stream;
     if (T > 0 || a.dyn) {
         dim3 grid(a.splits, (unsigned)(B * Hq));
-#define GO(BI, STT) hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a)
+#define GO(BI, STT)                                                                                             \
+    do {                                                                                                        \
+        if (small) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT>), grid, dim3(256), 0, st, a);    \
+        else hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a);              \
+    } while (0)
         if (mode == 0) { if (bits == 2) GO(2, uint16_t); else GO(4, uint16_t); }
         else           { if (bits == 2) GO(2, float); else GO(4, float); }
 #undef GO

@@ -49,8 +49,11 @@ def _ref_attn(q, K, V, kw, vw, n_rep):
 
 @pytest.mark.parametrize("method,bits,Hq,Hkv,T0", [("gearlKIVI", 2, 4, 4, 200), ("gearlKIVI", 4, 4, 2, 64), ("KIVI", 2, 2, 2, 30),
                                                    ("gearlKIVI", 2, 2, 2, 2304)])
-def test_cache_attend_matches_reconstruction(method, bits, Hq, Hkv, T0):
+@pytest.mark.parametrize("kernel", ["planned", "generic"])
+def test_cache_attend_matches_reconstruction(monkeypatch, kernel, method, bits, Hq, Hkv, T0):
     from gear_amd.cache import GearKVCache
+    if kernel == "generic":
+        monkeypatch.setenv("GEAR_ATTN_GENERIC", "1")
     torch.manual_seed(71)
     cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
     B, D, steps = 2, 128, 150

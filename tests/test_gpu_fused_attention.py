@@ -73,8 +73,17 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("B,Hq,Hkv,T,W,bits,mode,rank,k_out", CASES)
-def test_fused_decode_attention(B, Hq, Hkv, T, W, bits, mode, rank, k_out):
+@pytest.fixture(params=["planned", "generic"])
+def attn_kernel(request, monkeypatch):
+    """planned: contexts <= 8k run the 128-token-chunk kernel (every load issued up front); generic: force the
+    variable-chunk kernel that longer contexts use, on the same cases."""
+    if request.param == "generic":
+        monkeypatch.setenv("GEAR_ATTN_GENERIC", "1")
+    return request.param
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,T,W,bits,mode,rank,k_out", CASES + [(1, 2, 1, 8320, 3, 2, "fp32", 8, 20)])
+def test_fused_decode_attention(attn_kernel, B, Hq, Hkv, T, W, bits, mode, rank, k_out):
     from gear_amd import compress as C
     from gear_amd.attention import decode_attention
     torch.manual_seed(61)
