@@ -657,15 +657,17 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     }
 }
 
-// merge the splits + the fp16 window, apply the V low-rank factor, normalise.  grid (B*Hq), block 128.
-__global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
+// merge the splits + the fp16 window, normalise.  grid (B*Hq), block 512 = 4 groups x 128 channels: the groups share the
+// splits / window rows between them so that every thread's loads are one batch (the whole kernel is a latency chain).
+__global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
                                                                  const uint16_t* __restrict__ vwin, int W_arg, int wcap,
                                                                  uint16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ float qs[AD];
     __shared__ float sw[64];
     __shared__ float coef[64 + 64];  // per split, then per window token
+    __shared__ float og[4][AD];
     __shared__ float stat[2];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, d = tid & (AD - 1), grp = tid >> 7;
     int W = W_arg;
     const int64_t bhq = blockIdx.x;
     const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
@@ -673,49 +675,61 @@ __global__ __launch_bounds__(128) void attn_decode_reduce_kernel(AttnArgs a, con
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
     if (a.dyn) W = a.dyn[3];
     const int ns = (a.dyn || a.T > 0) ? a.splits : 0;
-    qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
+    // loads that depend on nothing: q, this thread's 16 channels of window token tid / 8, the split statistics
+    const int j = tid >> 3, part = tid & 7;
+    uint4 k0 = {0, 0, 0, 0}, k1 = {0, 0, 0, 0};
+    if (j < W) {
+        const uint4* kr = (const uint4*)(kwin + (bhk * wcap + j) * (int64_t)AD + part * 16);
+        k0 = kr[0];
+        k1 = kr[1];
+    }
+    float mi = -INFINITY, li = 0.0f;
+    if (tid < ns) {
+        mi = a.part_ml[(bhq * a.splits + tid) * 2];
+        li = a.part_ml[(bhq * a.splits + tid) * 2 + 1];
+    }
+    if (tid < AD) qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
     __syncthreads();
-    {   // window scores: thread pair per token, 64 channels (8 x 16-byte loads) each
-        const int j = tid >> 1, half = tid & 1;
-        float acc = 0.0f;
-        if (j < W) {
-            const uint4* kr = (const uint4*)(kwin + (bhk * wcap + j) * (int64_t)AD + half * 64);
+    {   // window scores: 8 threads per token
+        float t[8], acc = 0.0f;
+        unpack8(k0, t);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float t[8];
-                unpack8(kr[i], t);
+        for (int c = 0; c < 8; c++) acc = fmaf(qs[part * 16 + c], t[c], acc);
+        unpack8(k1, t);
 #pragma unroll
-                for (int c = 0; c < 8; c++) acc = fmaf(qs[half * 64 + i * 8 + c], t[c], acc);
-            }
-        }
+        for (int c = 0; c < 8; c++) acc = fmaf(qs[part * 16 + 8 + c], t[c], acc);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 1, 64);
-        if (j < W && half == 0) sw[j] = acc;
+        if (j < W && part == 0) sw[j] = acc;
     }
     __syncthreads();
     if (tid < 64) {   // softmax statistics over <= 64 splits and <= 64 window tokens, one lane each
-        const float mi = tid < ns ? a.part_ml[(bhq * a.splits + tid) * 2] : -INFINITY;
-        const float li = tid < ns ? a.part_ml[(bhq * a.splits + tid) * 2 + 1] : 0.0f;
         const float sj = tid < W ? sw[tid] : -INFINITY;
         float M = fmaxf(mi, sj);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) M = fmaxf(M, __shfl_xor(M, d, 64));
+        for (int x = 32; x >= 1; x >>= 1) M = fmaxf(M, __shfl_xor(M, x, 64));
         const float ci = tid < ns ? __expf(mi - M) : 0.0f;
         const float cw = tid < W ? __expf(sj - M) : 0.0f;
         coef[tid] = ci;
         coef[64 + tid] = cw;
         float L = fmaf(ci, li, cw);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) L += __shfl_xor(L, d, 64);
+        for (int x = 32; x >= 1; x >>= 1) L += __shfl_xor(L, x, 64);
         if (tid == 0) { stat[0] = M; stat[1] = L; }
     }
     __syncthreads();
     float o = 0.0f;
-#pragma unroll 4
-    for (int i = 0; i < ns; i++) o = fmaf(coef[i], a.part_o[(bhq * a.splits + i) * AD + tid], o);
-#pragma unroll 4
-    for (int j = 0; j < W; j++) o = fmaf(coef[64 + j], h2f_bits(vwin[(bhk * wcap + j) * (int64_t)AD + tid]), o);
-    out[bhq * AD + tid] = f2h_bits(o / stat[1]);
-    if (lse && tid == 0) lse[bhq] = stat[0] + logf(stat[1]);
+#pragma unroll 8
+    for (int i = grp; i < ns; i += 4) o = fmaf(coef[i], a.part_o[(bhq * a.splits + i) * AD + d], o);
+#pragma unroll 8
+    for (int r = grp; r < W; r += 4) o = fmaf(coef[64 + r], h2f_bits(vwin[(bhk * wcap + r) * (int64_t)AD + d]), o);
+    og[grp][d] = o;
+    __syncthreads();
+    if (tid < AD) {
+        out[bhq * AD + tid] = f2h_bits(((og[0][tid] + og[1][tid]) + (og[2][tid] + og[3][tid])) / stat[1]);
+        if (lse && tid == 0) lse[bhq] = stat[0] + logf(stat[1]);
+    }
 }
 
 int plan_splits(int T, int bits, int64_t bhq, bool fast_ranks, int* tc_out, bool* small) {
@@ -802,7 +816,7 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
 #undef GO
         GEAR_CHECK_LAUNCH("gear_attn_decode(partial)");
     }
-    hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(128), 0, st, a, (const uint16_t*)kwin,
+    hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(512), 0, st, a, (const uint16_t*)kwin,
                        (const uint16_t*)vwin, W, wcap, (uint16_t*)out, (float*)lse);
     GEAR_CHECK_LAUNCH("gear_attn_decode(reduce)");
     return 0;

@@ -68,18 +68,18 @@ struct GemvArgs {
 };
 
 template <int NB, int SK, bool NORM, int EPI>
-__global__ __launch_bounds__(256) void gemv_tok_kernel(GemvArgs a) {
-    constexpr int RPB = 4 / SK;   // rows per block
-    static_assert(EPI != EPI_ROPE || SK == 1, "RoPE blocks hold 4 rows");
+__global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_kernel(GemvArgs a) {
+    constexpr int WPB = EPI == EPI_ROPE ? 4 * SK : 4;   // waves per block (RoPE blocks always hold 4 rows)
+    constexpr int RPB = WPB / SK;                       // rows per block
     static_assert(EPI != EPI_SWIGLU || SK <= 2, "SwiGLU blocks hold at least one pair");
-    __shared__ float part[4][NB], ssp[4][NB];
+    __shared__ float part[WPB][NB], ssp[WPB][NB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rsub = wave / SK, kp = wave % SK;
     int row, head = 0, pu = 0;
     if (EPI == EPI_ROPE) {
         head = blockIdx.x >> 5;
         pu = blockIdx.x & 31;
-        row = head * 128 + 2 * pu + (wave & 1) + 64 * (wave >> 1);
+        row = head * 128 + 2 * pu + (rsub & 1) + 64 * (rsub >> 1);
     } else {
         row = min((int)blockIdx.x * RPB + rsub, a.N - 1);
     }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void gemv_tok_kernel(GemvArgs a) {
 
 template <int SK, bool NORM, int EPI>
 void launch_nb(int B, unsigned blocks, hipStream_t st, const GemvArgs& a) {
-    dim3 grid(blocks), block(256);
+    dim3 grid(blocks), block(EPI == EPI_ROPE ? 256 * SK : 256);
     if (B == 1) hipLaunchKernelGGL((gemv_tok_kernel<1, SK, NORM, EPI>), grid, block, 0, st, a);
     else if (B == 2) hipLaunchKernelGGL((gemv_tok_kernel<2, SK, NORM, EPI>), grid, block, 0, st, a);
     else if (B == 3) hipLaunchKernelGGL((gemv_tok_kernel<3, SK, NORM, EPI>), grid, block, 0, st, a);
@@ -252,7 +252,8 @@ extern "C" int gear_gemv_qkv_rope(const void* x, const void* delta, const void* 
     a.eps = eps; a.W = (const uint16_t*)Wqkv; a.K = K; a.N = (Hq + 2 * Hkv) * 128;
     a.Hq = Hq; a.Hkv = Hkv; a.pos = pos; a.slot = slot; a.wcap = wcap; a.log2_theta = log2f(theta);
     a.dyn = (const int*)dyn_state; a.q_out = (uint16_t*)q_out; a.kwin = (uint16_t*)kwin; a.vwin = (uint16_t*)vwin;
-    launch_nb<1, true, EPI_ROPE>(B, (unsigned)((Hq + 2 * Hkv) * 32), (hipStream_t)stream, a);
+    if (pick_sk(K, a.N, 2) == 2) launch_nb<2, true, EPI_ROPE>(B, (unsigned)((Hq + 2 * Hkv) * 32), (hipStream_t)stream, a);
+    else launch_nb<1, true, EPI_ROPE>(B, (unsigned)((Hq + 2 * Hkv) * 32), (hipStream_t)stream, a);
     GEAR_CHECK_LAUNCH("gear_gemv_qkv_rope");
     return 0;
 }
