@@ -13,9 +13,13 @@
 // only the r-vector of the other factor changes per row.  Dense phase: one 32-byte store per lane per row.
 // Sparse phase (after a barrier): the few outlier positions of the block's rows are overwritten with
 // fp16(value + low-rank term).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 template <int N>
 __device__ __forceinline__ void load_halfs(const uint16_t* p, float* f) {
@@ -39,6 +43,7 @@ struct DGeom {
     int nseg, seglen;
     int64_t seg_stride;
     int len, group, T, D, r, k, rpb;
+    int patch;   // outliers: 1 = overwrite in global memory after the dense pass (no LDS table), 0 = LDS table
     int64_t n_rows;
 };
 
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const int mwords = g.len / 32;       // len is a multiple of 16; bitmaps are read 16 bits at a time
     uint32_t* lmask = dsm;
     uint16_t* lval = (uint16_t*)(dsm + (size_t)g.rpb * (mwords + 1));
-    if (g.k > 0) {
+    if (g.k > 0 && !g.patch) {
         // the sparse part of all rows of the block goes to LDS once: the dense pass then patches its own elements and
         // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each)
         for (int i = tid; i < g.rpb * (mwords + 1); i += blockDim.x) lmask[i] = 0u;
@@ -84,14 +89,27 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
 
     // ---- the 16 x r factor block of this lane's columns (row-independent)
-    float gb[16][RVS];
+    // kept as packed fp16 pairs: the row term is RV/2 v_dot2_f32_f16 per element (exact products, fp32 accumulate) and
+    // the block costs RV/2 registers per column instead of RV
+    constexpr int RV2 = RV > 0 ? RV / 2 : 1;
+    uint32_t gb[16][RV2];
     const uint16_t* gbp = nullptr;
     if (active && r > 0) {
         if (KIND == 0) gbp = P + (((int64_t)ro * g.nseg + seg) * g.D + pos) * r;   // P[bh, pos.., :]
         else gbp = Q + ((int64_t)ro * g.T + j0) * r;                                // Q[bh, j0.., :]
         if (RV > 0) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) load_halfs<RVS>(gbp + j * RVS, gb[j]);
+            for (int j = 0; j < 16; j++) {
+                if (RV == 4) { uint2 t = *(const uint2*)(gbp + j * 4); gb[j][0] = t.x; gb[j][1 % RV2] = t.y; }
+                else {
+#pragma unroll
+                    for (int h = 0; h < RV2 / 4; h++) {
+                        const uint4 t = ((const uint4*)(gbp + j * RVS))[h];
+                        gb[j][(4 * h) % RV2] = t.x; gb[j][(4 * h + 1) % RV2] = t.y;
+                        gb[j][(4 * h + 2) % RV2] = t.z; gb[j][(4 * h + 3) % RV2] = t.w;
+                    }
+                }
+            }
         }
     }
 
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         }
     };
     const int nrows = active ? (int)((g.n_rows - row0) < g.rpb ? (g.n_rows - row0) : g.rpb) : 0;
-    RowIn cur, nxt;
+    RowIn cur = {}, nxt = {};
     if (nrows > 0) fetch(0, cur);
     for (int ri = 0; ri < nrows; ri++) {
         if (ri + 1 < nrows) fetch(ri + 1, nxt);
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                 f[w * CPW + j] = (MODE == 0) ? d : hround(d);
             }
         }
-        if (g.k > 0) {   // outlier elements: the stored value replaces the dequantized one (the low-rank term still adds)
+        if (g.k > 0 && !g.patch) {   // outlier elements: the stored value replaces the dequantized one (low-rank still adds)
             const uint32_t mb = (lmask[ri * (mwords + 1) + (j0 >> 5)] >> (j0 & 31)) & 0xFFFFu;
             if (mb) {
 #pragma unroll
@@ -141,15 +159,13 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         }
         if (r > 0) {
             if (RV > 0) {
-                float fv[RVS];
-                if (RV == 4) { fv[0] = h2f_bits((uint16_t)(cur.fv0.x & 0xFFFFu)); fv[1 % RVS] = h2f_bits((uint16_t)(cur.fv0.x >> 16));
-                               fv[2 % RVS] = h2f_bits((uint16_t)(cur.fv0.y & 0xFFFFu)); fv[3 % RVS] = h2f_bits((uint16_t)(cur.fv0.y >> 16)); }
-                else { unpack8(cur.fv0, fv); if (RV == 16) unpack8(cur.fv1, fv + (RVS > 8 ? 8 : 0)); }
+                const uint32_t fv[8] = {cur.fv0.x, cur.fv0.y, cur.fv0.z, cur.fv0.w, cur.fv1.x, cur.fv1.y, cur.fv1.z, cur.fv1.w};
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     float acc = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < RVS; c++) acc = fmaf(fv[c], gb[j][c], acc);
+                    for (int c = 0; c < RV2; c++)
+                        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, fv[c]), __builtin_bit_cast(half2_t, gb[j][c]), acc, false);
                     f[j] += acc;
                 }
             } else {
@@ -170,6 +186,41 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         op[0] = pack8(f);
         op[1] = pack8(f + 8);
         cur = nxt;
+    }
+    if (g.k > 0 && g.patch) {
+        // Sparse pass over the rows this block has just written: the lines are still dirty in L2, so the 2-byte stores
+        // merge there instead of costing an HBM read-modify-write each (what a separate kernel pays), and the dense loop
+        // above stays free of per-element checks and of the LDS table that capped occupancy at 2 blocks per CU.
+        __syncthreads();   // (workgroup-scope release/acquire: the dense stores are in L2 before any overwrite is issued)
+        const int per_row = 2 * g.k;
+        const int total = (int)min((int64_t)g.rpb, g.n_rows - row0) * per_row;
+        for (int e = tid; e < total; e += blockDim.x) {
+            const int ri = e / per_row;
+            const int64_t row = row0 + ri;
+            const int rin = (int)(row % g.rows_inner);
+            const uint32_t idx = oidx[row * per_row + e % per_row];
+            float v = h2f_bits(oval[row * per_row + e % per_row]);
+            const int sg = (int)idx / g.seglen, ps = (int)idx % g.seglen;
+            if (r > 0) {
+                int64_t bh, t, d;
+                if (KIND == 0) { bh = (int64_t)ro * g.nseg + sg; t = rin; d = ps; }
+                else { bh = ro; t = idx; d = rin; }
+                const uint16_t* qp = Q + (bh * g.T + t) * r;
+                const uint16_t* pp = P + (bh * g.D + d) * r;
+                float acc = 0.0f;
+                if (RV > 0) {
+                    float qa[RVS], pb[RVS];
+                    load_halfs<RVS>(qp, qa);
+                    load_halfs<RVS>(pp, pb);
+#pragma unroll
+                    for (int c = 0; c < RVS; c++) acc = fmaf(qa[c], pb[c], acc);
+                } else {
+                    for (int c = 0; c < r; c++) acc = fmaf(h2f_bits(qp[c]), h2f_bits(pp[c]), acc);
+                }
+                v += acc;
+            }
+            out[(int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)sg * g.seg_stride + ps] = f2h_bits(v);
+        }
     }
 }
 
@@ -233,11 +284,17 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
-    int rpb = (r > 0 || k == 0) ? 8 : 4;   // without factors the registers are free: prefer occupancy over LDS table size
-    while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024))) rpb >>= 1;
-    const size_t shmem = k > 0 ? (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) : 0;
+    const char* pe = getenv("GEAR_DECOMP_PATCH");
+    const int patch = pe ? atoi(pe) : 0;   // measured: 0.81 ms (patch) vs 0.72 ms (table) on the 7B / 4k V tensor
+    // rows per block, measured on the 7B / 4k tensors (V / K^T ms): factors only: 16 rows 0.48 / 0.42, 8 rows 0.51 / 0.47
+    // (fewer reloads of the lane's factor block); with the LDS outlier table: 4 rows 0.64 / 0.62, 8 rows 0.70 / 0.75
+    // (35 KB instead of 70 KB of LDS per block = twice the resident blocks)
+    int rpb = patch ? 8 : (k > 0 ? 4 : (r > 0 ? 16 : 8));
+    if (const char* re = getenv("GEAR_DECOMP_RPB")) rpb = atoi(re);
+    while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && !patch && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024))) rpb >>= 1;
+    const size_t shmem = (k > 0 && !patch) ? (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
-    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, n_rows};
+    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));

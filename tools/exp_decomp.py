@@ -10,7 +10,12 @@ x = torch.randn(L, H, T, D, device="cuda", dtype=torch.float16)
 P0 = torch.rand(L, H, D, 8, device="cuda")
 for kind in ("v", "k"):
     comp = C.compress_value if kind == "v" else C.compress_key
-    for (k, r) in ((0, 0), (40, 0), (0, 8), (40, 8)):
+    for (k, r) in ((40, 0), (0, 8), (40, 8)):
         p = comp(x, 2, 64, k_out=k, rank=r, loop=3, mode="fp32", P0=P0 if r else None)
-        t = timeit(lambda: C.decompress(p, transposed_out=True))
-        print(f"decompress {kind} k={k:2d} r={r}: {t:.3f} ms")
+        res = []
+        for env in ({"GEAR_DECOMP_PATCH": "0"}, {"GEAR_DECOMP_PATCH": "0", "GEAR_DECOMP_RPB": "4"}, {"GEAR_DECOMP_PATCH": "0", "GEAR_DECOMP_RPB": "2"},
+                    {"GEAR_DECOMP_PATCH": "0", "GEAR_DECOMP_RPB": "16"}):
+            os.environ.pop("GEAR_DECOMP_RPB", None)
+            os.environ.update(env)
+            res.append(f"{timeit(lambda: C.decompress(p, transposed_out=True)):.3f}")
+        print(f"decompress {kind} k={k:2d} r={r}: table rpb 8 / 4 / 2 / 16 = {' / '.join(res)} ms")
