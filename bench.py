@@ -34,6 +34,7 @@ CONFIGS = {
     "c2": ("Llama-2-7B", 32, 32, 128, 2048, 4, 64, 4, 3, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+TRAFFIC_C3 = None      # HBM bytes per compress_rows launch from the PMC passes (profiles/), filled in once measured
 
 
 def parse():
@@ -190,9 +191,8 @@ def main():
 
     def step():
         stage("t0")
-        kt = C.transpose_last2(K)                                # K^T, what the attention hook hands over (llamagear.py:268)
-        stage("k_transpose")
-        pk = C.compress_key_t(kt, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k)
+        # K^T re-layout (what the attention hook hands over, llamagear.py:268) + compress, cache-blocked over the layers
+        pk = C.compress_key(K, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k)
         stage("k_compress")
         pv = C.compress_value(V, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v)
         stage("v_compress")
@@ -228,7 +228,7 @@ def main():
     value = 2 * fp16_bytes_job * args.steps / dt / 1e9   # through compress + through decompress
 
     # ---- per-stage GPU time (HIP events on the launch stream), averaged over the timed steps
-    names = ["k_transpose", "k_compress", "v_compress", "k_decompress", "v_decompress"]
+    names = ["k_compress", "v_compress", "k_decompress", "v_decompress"]   # k_compress includes the K^T re-layout
     prev = "t0"
     stages = {}
     for nme in names:
@@ -240,25 +240,39 @@ def main():
     # is timed as its own event interval in a dedicated loop (the compress stages above also contain the low-rank
     # launches).  Algorithmic bytes per launch (DESIGN.md "compress_rows"): read 2n; write codes n*b/8 +
     # scale/mn 8n/g (fp32) + error 2n + outliers rows*2k*4.
-    n = n_elem_rank
-    from gear_amd.compress import _compress_rows
-    geom = (layers * T, T, Hl * T * D, D, Hl, D, T * D)
+    # Launches are the ones the step issues: one per chunk of layers (gear_amd/compress.py cache blocking), V geometry
+    # and K^T geometry alternating -- both are the same kernel symbol, so this is also what the rocprofv3 kernel
+    # summary averages over.
+    from gear_amd.compress import compress_rows_once, _batches_per_chunk
+    nb = _batches_per_chunk(layers, Hl * T * D * 2)
+    n = nb * Hl * T * D                               # elements per launch
+    geom_v = (nb * T, T, Hl * T * D, D, Hl, D, T * D)
+    geom_k = (nb * Hl * D, D, D * T, T, 1, T, 0)
+    errb = torch.empty((nb, Hl, T, D), dtype=torch.float16, device=dev)
+    ktb = C.transpose_last2(K[:nb])
+    chunks = [(b0, b0 + nb) for b0 in range(0, layers - nb + 1, nb)]
+
+    def rows_pass():
+        for b0, b1 in chunks:
+            compress_rows_once(V[b0:b1], geom_v, group, bits, 1, k_val, True, err=errb)
+            compress_rows_once(ktb, geom_k, group, bits, 1, k_key, True, err=errb.view(nb, Hl, D, T))
     for _ in range(2):
-        _compress_rows(V, geom, group, bits, 1, k_val, True)
+        rows_pass()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        _compress_rows(V, geom, group, bits, 1, k_val, True)
+        rows_pass()
     e1.record()
     torch.cuda.synchronize()
-    rows_ms = e0.elapsed_time(e1) / reps
-    alg_bytes = 2 * n + n * bits / 8 + 8 * n / group + 2 * n + layers * T * 2 * k_val * 4
+    rows_ms = e0.elapsed_time(e1) / (reps * 2 * len(chunks))
+    k_avg = 0.5 * (nb * T * 2 * k_val + nb * Hl * D * 2 * k_key)   # outlier entries per launch (V rows / K^T rows)
+    alg_bytes = 2 * n + n * bits / 8 + 8 * n / group + 2 * n + k_avg * 4
     achieved = alg_bytes / (rows_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed in profiles/r1_pmc_traffic_compress_rows.md (FETCH_SIZE x2 per
     # the gfx950 correction + WRITE_SIZE); measured for exactly this launch (C3, 1 GPU, all layers), null otherwise
-    traffic = 2.592e9 if (args.config == "c3" and world == 1 and not args.layers) else None
-    roofline = {"bound": "hbm", "kernel": "compress_rows_kernel<V>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    traffic = TRAFFIC_C3 if (args.config == "c3" and world == 1 and not args.layers and nb == 4) else None
+    roofline = {"bound": "hbm", "kernel": "compress_rows_kernel<2,1,float> (per 4-layer chunk, V and K^T launches)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": rows_ms}
 
@@ -300,7 +314,7 @@ def main():
                                    f"{bits}-bit g={group} per-channel K / per-token V + rank-{rnk} (loop {loop}) + "
                                    f"{sparsity * 100:.0f}% outliers (BASELINE configs[{2 if args.config == 'c3' else 1}])",
                        "parallelism": f"head-shard x{world}", "k_outliers_per_side": [k_key, k_val]},
-            "compress_GBps": fp16_bytes_job / ((stages["k_transpose"] + stages["k_compress"] + stages["v_compress"]) * 1e-3) / 1e9,
+            "compress_GBps": fp16_bytes_job / ((stages["k_compress"] + stages["v_compress"]) * 1e-3) / 1e9,
             "decompress_GBps": fp16_bytes_job / ((stages["k_decompress"] + stages["v_decompress"]) * 1e-3) / 1e9,
             "stage_ms": stages,
             "payload_ratio": (2 * n_elem_rank * 2) / (pk.nbytes() + pv.nbytes()),

@@ -17,6 +17,8 @@ Layouts
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -69,9 +71,10 @@ def draw_p0(B, H, S, Dm, rank, device):
     return p.to(device)
 
 
-def lowrank(E: torch.Tensor, rank: int, loop: int, P0: torch.Tensor, transposed: bool = False, out_dtype=torch.float16):
+def lowrank(E: torch.Tensor, rank: int, loop: int, P0: torch.Tensor, transposed: bool = False, out_dtype=torch.float16,
+            out=None):
     """Power iteration on the GPU.  E [B,H,S,Dm] (or [B,H,Dm,S] if transposed), fp16 / fp32.  Returns P [B,H,Dm,r],
-    Q [B,H,S,r]."""
+    Q [B,H,S,r] (written into `out` = (P, Q) when given)."""
     assert E.dim() == 4
     B, H = E.shape[:2]
     S, Dm = (E.shape[3], E.shape[2]) if transposed else (E.shape[2], E.shape[3])
@@ -82,8 +85,12 @@ def lowrank(E: torch.Tensor, rank: int, loop: int, P0: torch.Tensor, transposed:
     if E.dtype not in (torch.float16, torch.float32):
         raise L.GearError(f"lowrank: unsupported dtype {E.dtype}")
     lib = L.load()
-    P = torch.empty((B, H, Dm, rank), dtype=out_dtype, device=E.device)
-    Q = torch.empty((B, H, S, rank), dtype=out_dtype, device=E.device)
+    if out is None:
+        P = torch.empty((B, H, Dm, rank), dtype=out_dtype, device=E.device)
+        Q = torch.empty((B, H, S, rank), dtype=out_dtype, device=E.device)
+    else:
+        P, Q = out
+        assert P.is_contiguous() and Q.is_contiguous() and P.dtype == out_dtype and Q.dtype == out_dtype
     wsb = lib.gear_lowrank_workspace(B * H, S, Dm, rank)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=E.device)
     rc = lib.gear_lowrank(L.ptr(E), 0 if E.dtype == torch.float16 else 1, 1 if transposed else 0, B * H, S, Dm, rank,
@@ -93,22 +100,45 @@ def lowrank(E: torch.Tensor, rank: int, loop: int, P0: torch.Tensor, transposed:
     return P, Q
 
 
-def _compress_rows(x, geom, group, bits, mode, k, want_err):
-    n_rows, rows_inner, outer, inner, nseg, seglen, segstride = geom
+def _alloc_rows(shape, n_rows, group, bits, mode, k, dev):
     fpi = 32 // bits
-    dev = x.device
     sdt = torch.float16 if mode == 0 else torch.float32
-    code = torch.empty(x.shape[:-1] + (x.shape[-1] // fpi,), dtype=torch.int32, device=dev)
-    scale = torch.empty(x.shape[:-1] + (x.shape[-1] // group,), dtype=sdt, device=dev)
+    code = torch.empty(shape[:-1] + (shape[-1] // fpi,), dtype=torch.int32, device=dev)
+    scale = torch.empty(shape[:-1] + (shape[-1] // group,), dtype=sdt, device=dev)
     mn = torch.empty_like(scale)
-    err = torch.empty_like(x) if want_err else None
     oidx = torch.empty((n_rows, 2 * k), dtype=torch.int16, device=dev) if k > 0 else None
     oval = torch.empty((n_rows, 2 * k), dtype=torch.float16, device=dev) if k > 0 else None
+    return code, scale, mn, oidx, oval
+
+
+def _compress_rows(x, geom, group, bits, mode, k, out, err):
+    """One gear_compress_rows launch: x (contiguous view) -> out = (code, scale, mn, oidx, oval) views, error into err."""
+    n_rows, rows_inner, outer, inner, nseg, seglen, segstride = geom
+    code, scale, mn, oidx, oval = out
     rc = L.load().gear_compress_rows(L.ptr(x), n_rows, rows_inner, outer, inner, nseg, seglen, segstride, group, bits,
                                      mode, k, L.ptr(code), L.ptr(scale), L.ptr(mn), L.ptr(err), L.ptr(oidx), L.ptr(oval),
                                      None, L.stream_ptr())
     L.check(rc, "gear_compress_rows")
-    return code, scale, mn, err, oidx, oval
+
+
+def compress_rows_once(x, geom, group, bits, mode, k, want_err, err=None):
+    """Allocate the outputs and run ONE gear_compress_rows launch over x (benchmarks / profiling tools)."""
+    n_rows = geom[0]
+    out = _alloc_rows(tuple(x.shape), n_rows, group, bits, mode, k, x.device)
+    if want_err and err is None:
+        err = torch.empty_like(x)
+    _compress_rows(x, geom, group, bits, mode, k, out, err if want_err else None)
+    return out + (err,)
+
+
+def _batches_per_chunk(B: int, bytes_per_batch: int) -> int:
+    """Cache blocking over the leading (batch / layer) dimension: the error matrix a chunk writes (and the K^T re-layout
+    it reads) is consumed again by the low-rank kernels right away, so a chunk is sized to stay in the 256 MB Infinity
+    Cache instead of making two more trips through HBM.  GEAR_CHUNK_MB overrides (0 = one chunk)."""
+    mb = int(os.environ.get("GEAR_CHUNK_MB", "0"))
+    if mb <= 0:
+        return B
+    return max(1, min(B, (mb << 20) // max(1, bytes_per_batch)))
 
 
 def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
@@ -119,37 +149,78 @@ def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank:
     L.require_gpu(v)
     B, H, T, D = v.shape
     m = _MODES[mode]
-    geom = (B * T, T, H * T * D, D, H, D, T * D)
-    code, scale, mn, err, oidx, oval = _compress_rows(v, geom, group, bits, m, k_out, rank > 0)
-    P = Q = None
+    dev = v.device
+    code, scale, mn, oidx, oval = _alloc_rows(v.shape, B * T, group, bits, m, k_out, dev)
+    P = Q = err = None
+    nb = B
     if rank > 0:
         if P0 is None:
-            P0 = draw_p0(B, H, T, D, rank, v.device)
-        P, Q = lowrank(err, rank, loop, P0, transposed=False)
+            P0 = draw_p0(B, H, T, D, rank, dev)
+        nb = _batches_per_chunk(B, H * T * D * 2)
+        err = torch.empty((nb, H, T, D), dtype=torch.float16, device=dev)   # reused by every chunk: stays cache-resident
+        P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
+        Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
+    for b0 in range(0, B, nb):
+        b1 = min(B, b0 + nb)
+        n = b1 - b0
+        geom = (n * T, T, H * T * D, D, H, D, T * D)
+        out = (code[b0:b1], scale[b0:b1], mn[b0:b1],
+               oidx[b0 * T:b1 * T] if oidx is not None else None, oval[b0 * T:b1 * T] if oval is not None else None)
+        _compress_rows(v[b0:b1], geom, group, bits, m, k_out, out, err[:n] if err is not None else None)
+        if rank > 0:
+            lowrank(err[:n], rank, loop, P0[b0:b1], transposed=False, out=(P[b0:b1], Q[b0:b1]))
     if oidx is not None:
         oidx, oval = oidx.view(B, T, 2 * k_out), oval.view(B, T, 2 * k_out)
     return Payload("v", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
+
+
+def _compress_key_impl(src: torch.Tensor, src_is_transposed: bool, bits, group, k_out, rank, loop, mode, P0) -> Payload:
+    assert src.dim() == 4 and src.dtype == torch.float16
+    src = src.contiguous()
+    L.require_gpu(src)
+    if src_is_transposed:
+        B, H, D, T = src.shape
+    else:
+        B, H, T, D = src.shape
+    m = _MODES[mode]
+    dev = src.device
+    code, scale, mn, oidx, oval = _alloc_rows((B, H, D, T), B * H * D, group, bits, m, k_out, dev)
+    P = Q = err = ktb = None
+    nb = _batches_per_chunk(B, H * T * D * 2) if (rank > 0 or not src_is_transposed) else B
+    if rank > 0:
+        if P0 is None:
+            P0 = draw_p0(B, H, T, D, rank, dev)
+        err = torch.empty((nb, H, D, T), dtype=torch.float16, device=dev)   # E^T of one chunk, reused
+        P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
+        Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
+    if not src_is_transposed:
+        ktb = torch.empty((nb, H, D, T), dtype=torch.float16, device=dev)   # K^T of one chunk, reused
+    lib = L.load()
+    for b0 in range(0, B, nb):
+        b1 = min(B, b0 + nb)
+        n = b1 - b0
+        if src_is_transposed:
+            kt = src[b0:b1]
+        else:
+            kt = ktb[:n]
+            L.check(lib.gear_transpose_f16(L.ptr(src[b0:b1]), n * H, T, D, L.ptr(kt), L.stream_ptr()), "gear_transpose_f16")
+        geom = (n * H * D, D, D * T, T, 1, T, 0)
+        r0, r1 = b0 * H * D, b1 * H * D
+        out = (code[b0:b1], scale[b0:b1], mn[b0:b1],
+               oidx[r0:r1] if oidx is not None else None, oval[r0:r1] if oval is not None else None)
+        _compress_rows(kt, geom, group, bits, m, k_out, out, err[:n] if err is not None else None)
+        if rank > 0:
+            lowrank(err[:n], rank, loop, P0[b0:b1], transposed=True, out=(P[b0:b1], Q[b0:b1]))   # err is E^T [n,H,D,T]
+    if oidx is not None:
+        oidx, oval = oidx.view(B, H, D, 2 * k_out), oval.view(B, H, D, 2 * k_out)
+    return Payload("k", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
 
 
 def compress_key_t(kt: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
                    mode="fp32", P0: Optional[torch.Tensor] = None) -> Payload:
     """K^T [B,H,D,T] fp16 (what the attention hook passes, modeling_llamagear.py:268) -> Payload
     (per-channel groups along T; outliers per channel row along T)."""
-    assert kt.dim() == 4 and kt.dtype == torch.float16
-    kt = kt.contiguous()
-    L.require_gpu(kt)
-    B, H, D, T = kt.shape
-    m = _MODES[mode]
-    geom = (B * H * D, D, D * T, T, 1, T, 0)
-    code, scale, mn, err, oidx, oval = _compress_rows(kt, geom, group, bits, m, k_out, rank > 0)
-    P = Q = None
-    if rank > 0:
-        if P0 is None:
-            P0 = draw_p0(B, H, T, D, rank, kt.device)
-        P, Q = lowrank(err, rank, loop, P0, transposed=True)     # err is E^T [B,H,D,T]
-    if oidx is not None:
-        oidx, oval = oidx.view(B, H, D, 2 * k_out), oval.view(B, H, D, 2 * k_out)
-    return Payload("k", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
+    return _compress_key_impl(kt, True, bits, group, k_out, rank, loop, mode, P0)
 
 
 def transpose_last2(x: torch.Tensor) -> torch.Tensor:
@@ -165,9 +236,11 @@ def transpose_last2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def compress_key(k: torch.Tensor, *args, **kw) -> Payload:
-    """K [B,H,T,D] fp16 (token-major) -> Payload (the K^T re-layout runs on the HIP transpose kernel)."""
-    return compress_key_t(transpose_last2(k), *args, **kw)
+def compress_key(k: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
+                 mode="fp32", P0: Optional[torch.Tensor] = None) -> Payload:
+    """K [B,H,T,D] fp16 (token-major) -> Payload.  The K^T re-layout (HIP transpose kernel) runs chunk by chunk into a
+    reused buffer right before the chunk is compressed, so K^T never makes a round trip through HBM."""
+    return _compress_key_impl(k, False, bits, group, k_out, rank, loop, mode, P0)
 
 
 def decompress(p: Payload, transposed_out: bool = False) -> torch.Tensor:

@@ -96,6 +96,28 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// sum over all 64 lanes, returned to every lane through an SGPR: 4 DPP steps inside the rows of 16, row_bcast15 / row_bcast31
+// across the rows (lane 63 holds the total), one v_readlane.  6 VALU instead of 6 x (4 VALU + ds_bpermute) for a shuffle
+// butterfly (__shfl_xor computes a bounds-checked lane index for every step).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = row16_sum(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// inclusive prefix sum over the 64 lanes of a packed counter (fields must not overflow into each other)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#define GEAR_DPP_SHR(x, ctrl, rm) ((x) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rm), 0xF, true))
+    v = GEAR_DPP_SHR(v, 0x111, 0xF);   // row_shr:1
+    v = GEAR_DPP_SHR(v, 0x112, 0xF);   // row_shr:2
+    v = GEAR_DPP_SHR(v, 0x114, 0xF);   // row_shr:4
+    v = GEAR_DPP_SHR(v, 0x118, 0xF);   // row_shr:8
+#undef GEAR_DPP_SHR
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 // ------------------------------------------------------------------ the group quantizer arithmetic
 // MODE 0: fp16-stepwise (cuda_supported_gear/quant/new_pack.py:237-240, :277-278)
 // MODE 1: fp32         (GenerationBench/.../Simulated/compress_function.py:24-28)

@@ -459,6 +459,402 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
 
 
 // =====================================================================================================
+// fp32-arithmetic rows (MODE 1), second generation of the workgroup kernel above.  Same selection (tier-0 Gaussian
+// thresholds -> candidates -> ballot bisection -> bitonic sort, histogram radix select as the exact fallback), but the
+// dense part was rebuilt around what the PMC counters showed (VALU-issue-bound, ~1000 VALU instructions per wave and
+// row of which ~100 were per-element compare/select chains and ~32 branches):
+//   * the lane's 16 elements stay PACKED (8 words of 2 x fp16) wherever the arithmetic is exact in fp16: row sum and
+//     sum of squares by v_dot2_f32_f16, group min/max by v_pk_min/max_f16 with the outlier halves masked to +-inf,
+//     error = x - dequant by v_pk_add_f16 (a single rounding of an exact difference, identical to rounding the fp32
+//     difference), outlier halves of the error cleared by one v_bfi per word;
+//   * the per-element outlier handling is gone: the selecting wave marks each outlier's half-word in LDS (the raw-copy
+//     region, free after the candidate emission), a lane reads its 8 mask words back with two ds_read_b128; the code of
+//     a filled position (the same for every outlier of a group: quant(mean)) is patched into the packed word with a
+//     2-bit-per-element mask spread from the lane's 16 flag bits;
+//   * quantization is branch-free: reciprocal multiply, one OR-ed "within 1e-5 of a rounding tie" flag per lane, and
+//     only a lane that raises it redoes its 16 divisions exactly; codes are packed by a Horner chain in fp32 (exact
+//     below 2^16) instead of 16 convert + shift-or pairs; the clamp is one v_med3.
+// Bit-exact against the same oracle as the first kernel (tests/test_gpu_compress.py runs both).
+// =====================================================================================================
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// flag bits (one per element) -> BITS bits per element, for the CPW elements of one packed word
+template <int BITS>
+__device__ __forceinline__ uint32_t spread_flags(uint32_t f) {
+    if (BITS == 2) {
+        uint32_t x = f & 0xFFFFu;
+        x = (x | (x << 8)) & 0x00FF00FFu;
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x * 3u;
+    } else if (BITS == 4) {
+        uint32_t x = f & 0xFFu;
+        x = (x | (x << 12)) & 0x000F000Fu;
+        x = (x | (x << 6)) & 0x03030303u;
+        x = (x | (x << 3)) & 0x11111111u;
+        return x * 15u;
+    } else {
+        uint32_t x = f & 0xFu;
+        x = (x | (x << 14)) & 0x00030003u;
+        x = (x | (x << 7)) & 0x01010101u;
+        return x * 255u;
+    }
+}
+
+template <int BITS, typename ST>
+__global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
+                                          uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
+                                          uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
+                                          uint16_t* __restrict__ oval, float* __restrict__ omean) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int WPL = BITS / 2;
+    constexpr int CPW = 32 / BITS;
+    constexpr int HC = 16 / BITS;            // codes per 16-bit half of a packed word
+    __shared__ uint32_t hist[3][256];
+    __shared__ unsigned long long wave_tot[16];
+    __shared__ float wave_sum[16];
+    __shared__ int sh[8];
+    __shared__ uint32_t cand[2][CAND_CAP];
+    __shared__ uint32_t omask[2][512];
+    __shared__ uint32_t wave_thr[2][16];
+    extern __shared__ uint32_t rawlds[];     // [blockDim.x][8]: raw copy during the emission, then the half-word marks
+
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const int j0 = tid * 16;
+    const bool active = j0 < len;
+    int seg = 0, pos = 0;
+    if (active) seg_pos(gm, j0, seg, pos);
+    const int64_t off = row_base_of(gm, r) + (int64_t)seg * gm.seg_stride + pos;
+
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
+    if (active) {
+        const uint4* p = (const uint4*)(x + off);
+        ra = p[0];
+        rb = p[1];
+    }
+    const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+
+    uint32_t outl = 0u;                      // bit j: element j of this lane is an outlier (either side)
+    uint32_t m[8];                           // 0xFFFF in the half-word of every outlier element
+#pragma unroll
+    for (int w = 0; w < 8; w++) m[w] = 0u;
+    float mean = 0.0f;
+    if (k > 0) {
+        // ---------------- row sum / sum of squares on the packed halves (exact products, fp32 accumulate)
+        const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+        float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const half2v xv = __builtin_bit_cast(half2v, rw[w]);
+            s = __builtin_amdgcn_fdot2(xv, ones, s, false);
+            s2 = __builtin_amdgcn_fdot2(xv, xv, s2, false);
+        }
+        s = wave_sum_dpp(s);
+        s2 = wave_sum_dpp(s2);
+        if (lane == 0) { wave_sum[wave] = s; wave_thr[0][wave] = __float_as_uint(s2); }
+        for (int i = tid; i < 2 * 512; i += blockDim.x) (&omask[0][0])[i] = 0u;
+        __syncthreads();
+        float tot1 = 0.0f, tot2 = 0.0f;
+        for (int w = 0; w < nw; w++) { tot1 += wave_sum[w]; tot2 += __uint_as_float(wave_thr[0][w]); }
+        mean = tot1 / (float)len;
+        bool use_hist = (k > 64) || (zthr <= 0.0f);
+        bool payload_done = false;
+        uint32_t flag_lo = 0u, flag_hi = 0u;
+        if (!use_hist) {
+            // ---------------- tier 0: Gaussian-guess thresholds, validated by the survivor counts (see the kernel above)
+            const float sd = sqrtf(fmaxf(tot2 / (float)len - mean * mean, 0.0f));
+            const float thi = mean + zthr * sd, tlo = mean - zthr * sd;
+            const uint32_t th = f2h_bits(thi), tl = f2h_bits(tlo);
+            const half2v thi2 = __builtin_bit_cast(half2v, th | (th << 16)), tlo2 = __builtin_bit_cast(half2v, tl | (tl << 16));
+            uint32_t sg_hi = 0u, sg_lo = 0u;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const half2v xv = __builtin_bit_cast(half2v, rw[w]);
+                const uint32_t dh = __builtin_bit_cast(uint32_t, (half2v)(xv - thi2));
+                const uint32_t dl = __builtin_bit_cast(uint32_t, (half2v)(tlo2 - xv));
+                sg_hi |= (dh & 0x80008000u) >> w;
+                sg_lo |= (dl & 0x80008000u) >> w;
+                rawlds[tid * 8 + w] = rw[w];
+            }
+            uint32_t mh = active ? (~sg_hi & 0xFF00FF00u) : 0u, ml = active ? (~sg_lo & 0xFF00FF00u) : 0u;
+            // Candidates are compacted IN INDEX ORDER into one region per wave (wave-level prefix sum of the lane counts on
+            // DPP, no returning LDS atomics): the selecting wave then sees them sorted by index, so ties at the threshold
+            // value resolve "lower index first" by position and the outputs come out sorted without a sort.
+            const int wcap = min(64, CAND_CAP / nw);
+            const uint32_t cntp = (uint32_t)__popc(mh) | ((uint32_t)__popc(ml) << 16);
+            const uint32_t incl = wave_incl_scan_u32(cntp);
+            const uint32_t excl = incl - cntp;
+            if (lane == 63) wave_thr[1][wave] = incl;
+            // smallest element index left in a mask (bit 15-w <-> element 2w, bit 31-w <-> element 2w+1), removed from it
+            auto next_j = [](uint32_t& msk) {
+                const uint32_t e16 = msk & 0xFFFFu, o16 = msk >> 16;
+                const int we = e16 ? __clz(e16) - 16 : 99, wo = o16 ? __clz(o16) - 16 : 99;   // w = 15 - msb
+                if (we <= wo) { msk &= ~(0x8000u >> we); return 2 * we; }
+                msk &= ~(0x80000000u >> wo);
+                return 2 * wo + 1;
+            };
+            int slot = (int)(excl & 0xFFFFu);
+            while (mh) {
+                const int j = next_j(mh);
+                const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                if (slot < wcap) cand[0][wave * wcap + slot] = (bits << 16) | (uint32_t)(j0 + j);
+                slot++;
+            }
+            slot = (int)(excl >> 16);
+            while (ml) {
+                const int j = next_j(ml);
+                const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                if (slot < wcap) cand[1][wave * wcap + slot] = (bits << 16) | (uint32_t)(j0 + j);
+                slot++;
+            }
+            // the raw copy is dead now: the lane clears its slot, which becomes its half-word outlier marks
+            *(uint4*)&rawlds[tid * 8] = make_uint4(0, 0, 0, 0);
+            *(uint4*)&rawlds[tid * 8 + 4] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            uint32_t nh = 0, nl = 0;
+            bool over = false;
+            for (int w = 0; w < nw; w++) {
+                const uint32_t c = wave_thr[1][w];
+                nh += c & 0xFFFFu;
+                nl += c >> 16;
+                over |= ((c & 0xFFFFu) > (uint32_t)wcap) || ((c >> 16) > (uint32_t)wcap);
+            }
+            use_hist = over || (nh < (uint32_t)k) || (nl < (uint32_t)k) || (nh > 128u) || (nl > 128u);   // block-uniform
+            if (!use_hist) {
+                for (int side = 0; side < 2; side++) {
+                    if (wave != ((nw > 1) ? side : 0)) continue;
+                    const uint32_t n = side == 0 ? nh : nl;
+                    // candidate g of the concatenated (index-ordered) list lives in region w at offset g - sum of the counts before
+                    int w0 = 0, o0 = lane, w1 = 0, o1 = lane + 64;
+                    for (int w = 0; w + 1 < nw; w++) {
+                        const uint32_t c = wave_thr[1][w];
+                        const int cw = (int)(side == 0 ? (c & 0xFFFFu) : (c >> 16));
+                        if (w0 == w && o0 >= cw) { o0 -= cw; w0++; }
+                        if (w1 == w && o1 >= cw) { o1 -= cw; w1++; }
+                    }
+                    const bool v0 = (uint32_t)lane < n, v1 = (uint32_t)(lane + 64) < n;
+                    const uint32_t c0 = v0 ? cand[side][w0 * wcap + o0] : 0u, c1 = v1 ? cand[side][w1 * wcap + o1] : 0u;
+                    // order key, larger = selected first (large side: the value key; small side: its complement); +1 so that
+                    // 0 means "no candidate"
+                    const uint32_t ka = sort_key(c0 >> 16), kb = sort_key(c1 >> 16);
+                    const uint32_t x0 = v0 ? (side == 0 ? ka : 0xFFFFu - ka) + 1u : 0u;
+                    const uint32_t x1 = v1 ? (side == 0 ? kb : 0xFFFFu - kb) + 1u : 0u;
+                    uint32_t lo_b = 1u, hi_b = 0x10000u;   // largest Kt with count(x >= Kt) >= k   (count(x >= 1) = n >= k)
+                    for (int it = 0; it < 17; it++) {
+                        const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                        const int cnt = __popcll(__ballot(x0 >= mid)) + __popcll(__ballot(x1 >= mid));
+                        if (cnt >= k) lo_b = mid; else hi_b = mid - 1u;
+                    }
+                    const int above = __popcll(__ballot(x0 > lo_b)) + __popcll(__ballot(x1 > lo_b));
+                    const int need = k - above;                      // how many of the ties at the threshold value are taken
+                    const bool t0 = x0 == lo_b, t1 = x1 == lo_b;
+                    const unsigned long long bt0 = __ballot(t0), bt1 = __ballot(t1);
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    const int r0 = __popcll(bt0 & lt), r1 = __popcll(bt0) + __popcll(bt1 & lt);
+                    const bool s0 = x0 > lo_b || (t0 && r0 < need), s1 = x1 > lo_b || (t1 && r1 < need);
+                    const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+                    const int p0 = __popcll(b0 & lt), p1 = __popcll(b0) + __popcll(b1 & lt);
+                    uint16_t* oi = oidx + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                    uint16_t* ov = oval + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                    if (s0) {
+                        const uint32_t idx = c0 & 0xFFFFu;
+                        oi[p0] = (uint16_t)idx;
+                        ov[p0] = (uint16_t)(c0 >> 16);
+                        atomicOr(&omask[side][idx >> 5], 1u << (idx & 31));
+                        ((uint16_t*)rawlds)[idx] = (uint16_t)0xFFFFu;
+                    }
+                    if (s1) {
+                        const uint32_t idx = c1 & 0xFFFFu;
+                        oi[p1] = (uint16_t)idx;
+                        ov[p1] = (uint16_t)(c1 >> 16);
+                        atomicOr(&omask[side][idx >> 5], 1u << (idx & 31));
+                        ((uint16_t*)rawlds)[idx] = (uint16_t)0xFFFFu;
+                    }
+                }
+                __syncthreads();
+                if (active) {
+                    flag_hi = (omask[0][j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
+                    flag_lo = (omask[1][j0 >> 5] >> (j0 & 31)) & 0xFFFFu;
+                    const uint4 ma = *(const uint4*)&rawlds[tid * 8], mb = *(const uint4*)&rawlds[tid * 8 + 4];
+                    m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w;
+                    m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
+                }
+                payload_done = true;
+            }
+        }
+        if (use_hist) {
+            // ---------------- exact fallback: two-level radix select on the 16-bit order key (as in the kernel above)
+            uint32_t hb[16], key[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                hb[j] = (rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                key[j] = sort_key(hb[j]);
+            }
+            for (int i = tid; i < 3 * 256; i += blockDim.x) (&hist[0][0])[i] = 0u;
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) atomicAdd(&hist[0][key[j] >> 8], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                find_crossing<true>(hist[0], k, &sh[0], &sh[1]);
+                find_crossing<false>(hist[0], k, &sh[2], &sh[3]);
+            }
+            __syncthreads();
+            const uint32_t bin_hi = (uint32_t)sh[0], bin_lo = (uint32_t)sh[2];
+            const int need_hi = sh[1], need_lo = sh[3];
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((key[j] >> 8) == bin_hi) atomicAdd(&hist[1][key[j] & 255u], 1u);
+                    if ((key[j] >> 8) == bin_lo) atomicAdd(&hist[2][key[j] & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                find_crossing<true>(hist[1], need_hi, &sh[4], &sh[5]);
+                find_crossing<false>(hist[2], need_lo, &sh[6], &sh[7]);
+            }
+            __syncthreads();
+            const uint32_t thr_hi = (bin_hi << 8) | (uint32_t)sh[4];
+            const uint32_t thr_lo = (bin_lo << 8) | (uint32_t)sh[6];
+            const int take_hi = sh[5], take_lo = sh[7];
+            unsigned long long eq = 0;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    eq += (key[j] == thr_hi) ? 1ull : 0ull;
+                    eq += (key[j] == thr_lo) ? (1ull << 32) : 0ull;
+                }
+            }
+            unsigned long long ex = block_excl_scan(eq, wave_tot, nullptr);
+            int rank_hi = (int)(ex & 0xFFFFFFFFull), rank_lo = (int)(ex >> 32);
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (key[j] < thr_lo) flag_lo |= 1u << j;
+                    else if (key[j] == thr_lo) { if (rank_lo < take_lo) flag_lo |= 1u << j; rank_lo++; }
+                    if (key[j] > thr_hi) flag_hi |= 1u << j;
+                    else if (key[j] == thr_hi) { if (rank_hi < take_hi) flag_hi |= 1u << j; rank_hi++; }
+                }
+            }
+            unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
+            unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
+            int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
+            uint16_t* oi = oidx + r * (int64_t)(2 * k);
+            uint16_t* ov = oval + r * (int64_t)(2 * k);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (flag_lo & (1u << j)) {
+                    if (slot_lo < k) { oi[slot_lo] = (uint16_t)(j0 + j); ov[slot_lo] = (uint16_t)hb[j]; }
+                    slot_lo++;
+                }
+                if (flag_hi & (1u << j)) {
+                    if (slot_hi < k) { oi[k + slot_hi] = (uint16_t)(j0 + j); ov[k + slot_hi] = (uint16_t)hb[j]; }
+                    slot_hi++;
+                }
+            }
+            const uint32_t fl = flag_lo | flag_hi;
+#pragma unroll
+            for (int w = 0; w < 8; w++) m[w] = (((fl >> (2 * w)) & 1u) ? 0xFFFFu : 0u) | (((fl >> (2 * w + 1)) & 1u) ? 0xFFFF0000u : 0u);
+            (void)payload_done;
+        }
+        outl = flag_lo | flag_hi;
+        if (tid == 0 && omean) omean[r] = mean;
+    }
+
+    // ---------------- group min / max over the elements that are not outliers (packed fp16 min/max are exact), plus the
+    // fill value (the fp32 row mean, compress_function.py:279-283 / :315-319) when the lane holds an outlier
+    half2v lo2, hi2;
+    {
+        const uint32_t PINF = 0x7C007C00u, NINF = 0xFC00FC00u;
+        lo2 = __builtin_bit_cast(half2v, bfi32(m[0], PINF, rw[0]));
+        hi2 = __builtin_bit_cast(half2v, bfi32(m[0], NINF, rw[0]));
+#pragma unroll
+        for (int w = 1; w < 8; w++) {
+            lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(half2v, bfi32(m[w], PINF, rw[w])));
+            hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(half2v, bfi32(m[w], NINF, rw[w])));
+        }
+    }
+    float lo = fminf((float)lo2.x, (float)lo2.y), hi = fmaxf((float)hi2.x, (float)hi2.y);
+    lo = fminf(lo, outl ? mean : INFINITY);
+    hi = fmaxf(hi, outl ? mean : -INFINITY);
+    const int lanes_per_group = group / 16;
+    for (int mm = 1; mm < lanes_per_group; mm <<= 1) {
+        lo = fminf(lo, __shfl_xor(lo, mm, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, mm, 64));
+    }
+    if (!active) return;
+    const float qscale = div_rn(hi - lo, (float)LEVELS), qmn = lo;        // make_qparams<1>
+    const float inv = (qscale != 0.0f) ? div_rn(1.0f, qscale) : 0.0f;      // zero-range group: every code 0 (defect B6)
+    // ---------------- quantize: reciprocal multiply; a lane that sees a quotient within 1e-5 of a rounding tie (the only
+    // place where t * (1/s) and t / s can round differently; 1e-3 for 8-bit codes) redoes its elements by division
+    constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
+    float xq[16], rq[16];
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        xq[j] = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+        const float c = (xq[j] - qmn) * inv;
+        rq[j] = rintf(c);
+        tie |= fabsf(c - rq[j]) > TIE;
+    }
+    if (tie) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) rq[j] = (qscale != 0.0f) ? rintf(div_rn(xq[j] - qmn, qscale)) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) rq[j] = __builtin_amdgcn_fmed3f(rq[j], 0.0f, (float)LEVELS);
+    // ---------------- pack: Horner chains in fp32 over the HC codes of each 16-bit half (exact: < 2^16)
+    uint32_t words[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; w++) {
+        float hl = rq[w * CPW + HC - 1], hh = rq[w * CPW + 2 * HC - 1];
+#pragma unroll
+        for (int i = HC - 2; i >= 0; i--) {
+            hl = fmaf(hl, (float)(1 << BITS), rq[w * CPW + i]);
+            hh = fmaf(hh, (float)(1 << BITS), rq[w * CPW + HC + i]);
+        }
+        words[w] = (uint32_t)hl | ((uint32_t)hh << 16);
+    }
+    if (outl) {   // filled positions: every outlier of the group carries quant(mean)
+        float cm = (qscale != 0.0f) ? rintf(div_rn(mean - qmn, qscale)) : 0.0f;
+        cm = __builtin_amdgcn_fmed3f(cm, 0.0f, (float)LEVELS);
+        const uint32_t qrep = (uint32_t)cm * (0xFFFFFFFFu / (uint32_t)LEVELS);
+#pragma unroll
+        for (int w = 0; w < WPL; w++) words[w] = bfi32(spread_flags<BITS>(outl >> (w * CPW)), qrep, words[w]);
+    }
+    uint32_t* cp = code + off / CPW;
+#pragma unroll
+    for (int w = 0; w < WPL; w++) cp[w] = words[w];
+    if ((tid & (lanes_per_group - 1)) == 0) {
+        st_st<ST>(scale + (off >> gm.group_shift), qscale);
+        st_st<ST>(mn + (off >> gm.group_shift), qmn);
+    }
+    if (err) {
+        // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
+        uint32_t ew[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const float d0 = __fadd_rn(__fmul_rn(rq[2 * w], qscale), qmn), d1 = __fadd_rn(__fmul_rn(rq[2 * w + 1], qscale), qmn);
+            const uint32_t dw = (uint32_t)f2h_bits(d0) | ((uint32_t)f2h_bits(d1) << 16);
+            const half2v e2 = __builtin_bit_cast(half2v, rw[w]) - __builtin_bit_cast(half2v, dw);
+            ew[w] = __builtin_bit_cast(uint32_t, e2) & ~m[w];
+        }
+        uint4* ep = (uint4*)(err + off);
+        ep[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]);
+        ep[1] = make_uint4(ew[4], ew[5], ew[6], ew[7]);
+    }
+}
+
+
+// =====================================================================================================
 // Wave-per-row variant (the fast path): ONE wave owns the whole row.  Lane l holds CPL chunks of 16 consecutive
 // elements (chunk c = elements [1024 c + 16 l, +16)), so global accesses stay fully coalesced, every reduction is a
 // DPP / shuffle butterfly, and there is no workgroup barrier on the critical path (the block IS the wave): far more
@@ -816,15 +1212,24 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
                        (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
                        (float*)omean)
+#define GO2(B)                                                                                                         \
+    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
+                       (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,   \
+                       (float*)omean)
     if (mode == 0) {
         if (bits == 2) GO(2, 0, uint16_t);
         else if (bits == 4) GO(4, 0, uint16_t);
         else GO(8, 0, uint16_t);
-    } else {
+    } else if (getenv("GEAR_ROWS_V1")) {   // first-generation workgroup kernel (kept for A/B runs and as a cross-check)
         if (bits == 2) GO(2, 1, float);
         else if (bits == 4) GO(4, 1, float);
         else GO(8, 1, float);
+    } else {
+        if (bits == 2) GO2(2);
+        else if (bits == 4) GO2(4);
+        else GO2(8);
     }
+#undef GO2
 #undef GO
     GEAR_CHECK_LAUNCH("gear_compress_rows");
     return 0;

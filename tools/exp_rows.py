@@ -28,11 +28,11 @@ def main():
     for bits in (2, 4):
         for k in (0, 40):
             for err in (False, True):
-                t = timeit(lambda: C._compress_rows(x, gv, 64, bits, 1, k, err))
+                t = timeit(lambda: C.compress_rows_once(x, gv, 64, bits, 1, k, err))
                 print(f"rows V  b{bits} k={k:2d} err={err}: {t:.3f} ms")
-        t = timeit(lambda: C._compress_rows(xt, gk, 64, bits, 1, 40, True))
+        t = timeit(lambda: C.compress_rows_once(xt, gk, 64, bits, 1, 40, True))
         print(f"rows K^T b{bits} k=40 err=True: {t:.3f} ms")
-        t = timeit(lambda: C._compress_rows(x, gv, 64, bits, 0, 0, True))
+        t = timeit(lambda: C.compress_rows_once(x, gv, 64, bits, 0, 0, True))
         print(f"rows V  b{bits} mode fp16 k=0 err=True: {t:.3f} ms")
         t = timeit(lambda: new_pack.triton_quantize_and_pack_along_last_dim(x, 64, bits))
         print(f"quant_lastdim b{bits} fp16: {t:.3f} ms")

@@ -7,13 +7,13 @@ L, H, T, D = 8, 32, 4096, 128
 x = torch.randn(L, H, T, D, device="cuda", dtype=torch.float16)
 gv = (L * T, T, H * T * D, D, H, D, T * D)
 for _ in range(3):
-    C._compress_rows(x, gv, 64, 2, 1, 40, True)
+    C.compress_rows_once(x, gv, 64, 2, 1, 40, True)
 torch.cuda.synchronize()
 os.environ["GEAR_ROWS_HIST_ONLY"] = "1"
 for _ in range(3):
-    C._compress_rows(x, gv, 64, 2, 1, 40, True)
+    C.compress_rows_once(x, gv, 64, 2, 1, 40, True)
 torch.cuda.synchronize()
 del os.environ["GEAR_ROWS_HIST_ONLY"]
 for _ in range(3):
-    C._compress_rows(x, gv, 64, 2, 1, 0, True)
+    C.compress_rows_once(x, gv, 64, 2, 1, 0, True)
 torch.cuda.synchronize()
