@@ -11,6 +11,8 @@
 //   32x32 blocks of G (contraction over tokens), then the solve (CholeskyQR2 in fp64 for orth(P), one Cholesky for Q).
 // Kernel 2: Q' = E W -- lanes own 8 tokens and stream the 128 channels (K^T layout) or 16 lanes share a token row
 //   (token-major layout); plain fp32 FMAs, HBM-bound.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -298,11 +300,13 @@ __global__ __launch_bounds__(256) void lr_qpass_kt_kernel(const uint16_t* __rest
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        if (t0 + j >= S) break;
-        for (int c = 0; c < r; c++) {
-            int64_t o = (bh * S + t0 + j) * r + c;
-            if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[j][c]);
-            else ((float*)Q_out)[o] = acc[j][c];
+#pragma unroll
+        for (int c = 0; c < RP; c++) {   // static indices only: a run-time index would push acc[][] into scratch memory
+            if (t0 + j < S && c < r) {
+                int64_t o = (bh * S + t0 + j) * r + c;
+                if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[j][c]);
+                else ((float*)Q_out)[o] = acc[j][c];
+            }
         }
     }
 }
@@ -345,10 +349,94 @@ __global__ __launch_bounds__(256) void lr_qpass_tm_kernel(const uint16_t* __rest
                 store_halfs<RP>((uint16_t*)Q_out + (bh * S + row) * (int64_t)RP, acc);
                 continue;
             }
-            for (int c = 0; c < r; c++) {
-                int64_t o = (bh * S + row) * r + c;
-                if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[c]);
-                else ((float*)Q_out)[o] = acc[c];
+#pragma unroll
+            for (int c = 0; c < RP; c++) {
+                if (c < r) {
+                    int64_t o = (bh * S + row) * r + c;
+                    if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[c]);
+                    else ((float*)Q_out)[o] = acc[c];
+                }
+            }
+        }
+    }
+}
+
+// token-major layout on the matrix cores: Q'^T [c][token] = W^T [c][channel] . E^T [channel][token], one
+// v_mfma_f32_32x32x16_f16 tile = 32 tokens x (RP of 32 rows used).  The B operand of lane (token n, k-half) is 8
+// consecutive channels of ONE token row = one 16-byte global load (no LDS staging, no transpose); the 16-lane DPP
+// reductions and the 64 fp32 FMAs per row of the VALU kernel above (~110 VALU per 16 bytes) disappear.  W (fp32) is split
+// into an fp16 head and an fp16 remainder (two MFMAs per k-step), which keeps ~22 bits of it.
+// C layout (lane l, register q): row (q & 3) + 8 (q >> 2) + 4 (l >> 5), column l & 31: a lane ends up with 4 consecutive
+// rank columns of its token = one 8-byte store.
+template <int RP>
+__global__ __launch_bounds__(256) void lr_qpass_tm_mfma_kernel(const uint16_t* __restrict__ E, const float* __restrict__ W,
+                                                               int S, int r, void* __restrict__ Q_out, int out_f16) {
+    constexpr int NT = 4;   // 32-token tiles per wave
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[16 * RP * 8], Al[16 * RP * 8];   // [k / 8][m][k % 8]
+    const int64_t bh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < GD * RP; idx += 256) {
+        const int k = idx / RP, m = idx % RP;
+        const float w = W[(bh * GD + k) * RP + m];
+        const uint16_t hi = f2h_bits(w);
+        const uint16_t lo = f2h_bits(w - h2f_bits(hi));
+        const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
+        Ah[pos] = hi;
+        Al[pos] = lo;
+    }
+    __syncthreads();
+    const int n = lane & 31, kg = lane >> 5;
+    const int tbase = (blockIdx.x * 4 + wave) * NT * 32;
+    union U { uint4 u; half8_t h; };
+    uint4 raw[2][8];
+    auto load_tile = [&](int it, uint4 (&dst)[8]) {
+        const int token = tbase + it * 32 + n;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            dst[ks] = make_uint4(0, 0, 0, 0);
+            if (token < S) dst[ks] = *(const uint4*)(E + (bh * S + token) * (int64_t)GD + 16 * ks + 8 * kg);
+        }
+    };
+    load_tile(0, raw[0]);
+#pragma unroll
+    for (int it = 0; it < NT; it++) {
+        if (tbase + it * 32 >= S) break;
+        if (it + 1 < NT) load_tile(it + 1, raw[(it + 1) & 1]);
+        float16_t acc;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            U ah, al, b;
+            ah.u = al.u = make_uint4(0, 0, 0, 0);
+            if (n < RP) {
+                ah.u = *(const uint4*)&Ah[((2 * ks + kg) * RP + n) * 8];
+                al.u = *(const uint4*)&Al[((2 * ks + kg) * RP + n) * 8];
+            }
+            b.u = raw[it & 1][ks];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, acc, 0, 0, 0);
+        }
+        const int token = tbase + it * 32 + n;
+        if (token >= S) continue;
+#pragma unroll
+        for (int qb = 0; qb < (RP + 7) / 8; qb++) {   // register block qb holds rank columns 8 qb + 4 kg + (0..3)
+            const int c0 = 8 * qb + 4 * kg;
+            if (c0 >= RP) continue;
+            if (out_f16 && r == RP) {
+                uint2 v;
+                v.x = (uint32_t)f2h_bits(acc[4 * qb]) | ((uint32_t)f2h_bits(acc[4 * qb + 1]) << 16);
+                v.y = (uint32_t)f2h_bits(acc[4 * qb + 2]) | ((uint32_t)f2h_bits(acc[4 * qb + 3]) << 16);
+                *(uint2*)((uint16_t*)Q_out + (bh * S + token) * (int64_t)RP + c0) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (c0 + i < r) {
+                        const int64_t o = (bh * S + token) * r + c0 + i;
+                        if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[4 * qb + i]);
+                        else ((float*)Q_out)[o] = acc[4 * qb + i];
+                    }
+                }
             }
         }
     }
@@ -369,8 +457,12 @@ int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int lo
         auto kfn = lr_gram_solve_kernel<RP, true>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16);
-        hipLaunchKernelGGL((lr_qpass_tm_kernel<RP>), dim3((S + 127) / 128, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
-                           Q_out, of16);
+        if (getenv("GEAR_QPASS_VALU"))
+            hipLaunchKernelGGL((lr_qpass_tm_kernel<RP>), dim3((S + 127) / 128, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
+                               Q_out, of16);
+        else
+            hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<RP>), dim3((S + 511) / 512, (unsigned)bh), dim3(256), 0, st, E, Wws, S,
+                               r, Q_out, of16);
     }
     GEAR_CHECK_LAUNCH("gear_lowrank(gram)");
     return 0;
