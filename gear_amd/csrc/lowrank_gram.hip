@@ -110,19 +110,28 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
             for (int J = I; J < 4; J++)
                 acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
     };
+    uint4 stgC[4];
     stage_load(0, stgA);
     if (64 < S) stage_load(64, stgB);
-    for (int t0 = 0; t0 < S; t0 += 128) {       // two tiles per trip, two tiles of loads in flight
+    if (128 < S) stage_load(128, stgC);
+    for (int t0 = 0; t0 < S; t0 += 192) {       // three tiles per trip, three tiles (48 KB per workgroup) of loads in flight
         __syncthreads();
         stage_store(stgA);
         __syncthreads();
-        if (t0 + 128 < S) stage_load(t0 + 128, stgA);
+        if (t0 + 192 < S) stage_load(t0 + 192, stgA);
         tile_mfma();
         if (t0 + 64 < S) {
             __syncthreads();
             stage_store(stgB);
             __syncthreads();
-            if (t0 + 192 < S) stage_load(t0 + 192, stgB);
+            if (t0 + 256 < S) stage_load(t0 + 256, stgB);
+            tile_mfma();
+        }
+        if (t0 + 128 < S) {
+            __syncthreads();
+            stage_store(stgC);
+            __syncthreads();
+            if (t0 + 320 < S) stage_load(t0 + 320, stgC);
             tile_mfma();
         }
     }
@@ -141,13 +150,8 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
                     for (int q = 0; q < 16; q++) {
                         const int row = 32 * I + (q & 3) + 8 * (q >> 2) + 4 * kg, col = 32 * J + x;
                         const float v = acc[blk_index(I, J)][q];
-                        if (turn == 0) {
-                            G[row * GP + col] = v;
-                            if (I != J) G[col * GP + row] = v;
-                        } else {
-                            G[row * GP + col] += v;
-                            if (I != J) G[col * GP + row] += v;
-                        }
+                        if (turn == 0) G[row * GP + col] = v;   // blocks on or above the diagonal only: G is symmetric and
+                        else G[row * GP + col] += v;            // matmulG reads G(d, e) below the diagonal as G(e, d)
                     }
                 }
         }
@@ -158,54 +162,105 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
         Pa[i] = (c < r) ? P0[(bh * GD + d) * r + c] : 0.0f;
     }
     __syncthreads();
-    auto matmulG = [&](const float* X, float* Y) {  // Y = G X   ([128][RP])
-        for (int i = tid; i < GD * RP; i += 256) {
-            int d = i / RP, c = i % RP;
-            float s = 0.0f;
-            for (int e = 0; e < GD; e++) s = fmaf(G[d * GP + e], X[e * RP + c], s);
-            Y[i] = s;
+    // Y = G X ([128][RP]).  Thread (d = tid / 2, h = tid & 1) accumulates the RP outputs of row d over half of the e range
+    // (e = (i & 31) + 64 (i >> 5) + 32 h: with the pitch of 129 floats the 64 lanes of a wave hit 64 different banks, for
+    // the direct access G[d][e] and for the mirrored one G[e][d] alike), then the two halves meet through DPP.
+    // One G read feeds RP FMAs (the first version spent two LDS reads per FMA and was LDS-bound).
+    auto matmulG = [&](const float* X, float* Y) {
+        const int d = tid >> 1, h = tid & 1;
+        const int dlow = d & ~31;        // e < dlow lies below the diagonal blocks
+        float acc[RP];
+#pragma unroll
+        for (int c = 0; c < RP; c++) acc[c] = 0.0f;
+#pragma unroll 4
+        for (int i = 0; i < 64; i++) {
+            const int e = (i & 31) + 64 * (i >> 5) + 32 * h;
+            const float g = (e < dlow) ? G[e * GP + d] : G[d * GP + e];
+#pragma unroll
+            for (int c4 = 0; c4 < RP; c4 += 4) {
+                const float4 xv = *(const float4*)&X[e * RP + c4];
+                acc[c4] = fmaf(g, xv.x, acc[c4]);
+                acc[c4 + 1] = fmaf(g, xv.y, acc[c4 + 1]);
+                acc[c4 + 2] = fmaf(g, xv.z, acc[c4 + 2]);
+                acc[c4 + 3] = fmaf(g, xv.w, acc[c4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < RP; c++) acc[c] = GEAR_DPP_ADD(acc[c], 0xB1);   // + the partner lane (quad_perm xor 1)
+        if (h == 0) {
+#pragma unroll
+            for (int c4 = 0; c4 < RP; c4 += 4) *(float4*)&Y[d * RP + c4] = make_float4(acc[c4], acc[c4 + 1], acc[c4 + 2], acc[c4 + 3]);
         }
         __syncthreads();
     };
-    auto chol_inverse = [&]() {  // Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0
-        if (tid == 0) {
-            double Rm[RP][RP];
+    // Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0.  Lane m of wave 0 owns column m of R and of
+    // R^-1 (the first version ran the whole factorisation on ONE thread: ~2500 dependent fp64 instructions with 44
+    // divisions / square roots, three times per head); the pivots' reciprocal square roots come from v_rsq_f64 + Newton.
+    auto chol_inverse = [&]() {
+        double* Rl = Rinv + RP * RP;   // R staged for the back substitution
+        if (tid < 64) {
+            const int m = lane;
+            double col[RP], rin[RP], rinvd[RP];
             bool dead[RP];
-            for (int j = 0; j < RP; j++)
-                for (int i = 0; i < RP; i++) Rm[i][j] = 0.0;
+#pragma unroll
             for (int j = 0; j < RP; j++) {
-                double dg = Md[j * RP + j];
-                double d = dg;
-                for (int kk = 0; kk < j; kk++) d -= Rm[kk][j] * Rm[kk][j];
-                dead[j] = !(d > 1e-12 * dg) || !(dg > 0.0);
-                if (dead[j]) { Rm[j][j] = 1.0; continue; }
-                double rjj = sqrt(d);
-                Rm[j][j] = rjj;
-                for (int m = j + 1; m < RP; m++) {
-                    double s = Md[j * RP + m];
-                    for (int kk = 0; kk < j; kk++) s -= Rm[kk][j] * Rm[kk][m];
-                    Rm[j][m] = s / rjj;
+                double sacc = (m < RP) ? Md[j * RP + m] : 0.0;
+#pragma unroll
+                for (int kk = 0; kk < RP; kk++) {
+                    if (kk < j) {
+                        const double rkj = __shfl(col[kk], j, 64);    // R[kk][j]
+                        sacc -= rkj * col[kk];
+                    }
                 }
+                const double dj = __shfl(sacc, j, 64), dg = Md[j * RP + j];
+                dead[j] = !(dj > 1e-12 * dg) || !(dg > 0.0);
+                double rs = 1.0;
+                if (!dead[j]) {
+                    rs = __builtin_amdgcn_rsq(dj);
+                    rs = rs * (1.5 - 0.5 * dj * rs * rs);
+                    rs = rs * (1.5 - 0.5 * dj * rs * rs);
+                }
+                rinvd[j] = dead[j] ? 0.0 : rs;
+                col[j] = (m == j) ? (dead[j] ? 1.0 : dj * rs) : ((m > j && !dead[j]) ? sacc * rs : 0.0);
             }
-            for (int j = 0; j < RP; j++) {
-                for (int i = 0; i < RP; i++) Rinv[i * RP + j] = 0.0;
-                if (dead[j]) continue;
-                Rinv[j * RP + j] = 1.0 / Rm[j][j];
-                for (int i = j - 1; i >= 0; i--) {
-                    double s = 0.0;
-                    for (int kk = i + 1; kk <= j; kk++) s += Rm[i][kk] * Rinv[kk * RP + j];
-                    Rinv[i * RP + j] = dead[i] ? 0.0 : -s / Rm[i][i];
-                }
+            if (m < RP) {
+#pragma unroll
+                for (int kk = 0; kk < RP; kk++) Rl[kk * RP + m] = col[kk];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bool deadm = false;
+#pragma unroll
+            for (int j = 0; j < RP; j++) deadm = (m == j) ? dead[j] : deadm;
+            // column m of R^-1 by back substitution: Rinv[m][m] = 1 / R[m][m]; Rinv[i][m] = -(sum_{i<kk<=m} R[i][kk] Rinv[kk][m]) / R[i][i]
+#pragma unroll
+            for (int i = RP - 1; i >= 0; i--) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < RP; kk++)
+                    if (kk > i) sacc += Rl[i * RP + kk] * ((kk <= m) ? rin[kk] : 0.0);
+                rin[i] = (i == m) ? rinvd[i] : ((i < m && !deadm) ? -sacc * rinvd[i] : 0.0);
+            }
+            if (m < RP) {
+#pragma unroll
+                for (int i = 0; i < RP; i++) Rinv[i * RP + m] = rin[i];
             }
         }
         __syncthreads();
     };
-    auto gram_small = [&](const float* A, const float* B) {  // Md = A^T B  (fp64 accumulate)
-        for (int i = tid; i < RP * RP; i += 256) {
-            int a = i / RP, b = i % RP;
-            double s = 0.0;
-            for (int d = 0; d < GD; d++) s += (double)A[d * RP + a] * (double)B[d * RP + b];
-            Md[i] = s;
+    auto gram_small = [&](const float* A, const float* B) {  // Md = A^T B  (fp64 accumulate), 4 lanes per output
+        for (int o = tid >> 2; o < RP * RP; o += 64) {
+            const int a = o / RP, b = o % RP, part = tid & 3;
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < GD / 4; i++) {
+                const int d = 4 * i + part;
+                sacc += (double)A[d * RP + a] * (double)B[d * RP + b];
+            }
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            if (part == 0) Md[o] = sacc;
         }
         __syncthreads();
     };
@@ -446,7 +501,7 @@ template <int RP>
 int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int loop, const float* P0, void* P_out,
              void* Q_out, int out_dtype, float* Wws, hipStream_t st) {
     const int of16 = out_dtype == GEAR_DTYPE_F16;
-    size_t shmem = (size_t)GD * GP * 4 + 2 * (size_t)GD * RP * 4 + 2 * (size_t)RP * RP * 8 + 16;
+    size_t shmem = (size_t)GD * GP * 4 + 2 * (size_t)GD * RP * 4 + 3 * (size_t)RP * RP * 8 + 16;
     if (transposed) {
         auto kfn = lr_gram_solve_kernel<RP, false>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
