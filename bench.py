@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the number)")
-    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
-                    help="2: the K chain and the V chain of a step run on two HIP streams (they are independent); 1: one stream")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 4, 8),
+                    help="1: one stream; 2: the K chain and the V chain of a step run on two HIP streams (they are independent); "
+                         "4 / 8: each of them additionally split into 2 / 4 groups of layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the full-model decode tokens/s leg")
     return ap.parse_args()
@@ -204,25 +205,32 @@ def main():
         stage("v_decompress")
         return pk, pv, kr, vr
 
-    s_k, s_v = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    n_str = max(2, args.streams)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
+    parts = n_str // 2                      # groups of layers per tensor kind
+    lb = [(layers * i // parts, layers * (i + 1) // parts) for i in range(parts)]
 
-    def step_two_streams():
-        # K and V are independent: their compress -> decompress chains run on two HIP streams, so the VALU-bound row
-        # compressor of one tensor overlaps the HBM-bound low-rank / decompress kernels of the other
+    def step_streams():
+        # K and V (and groups of layers) are independent: their compress -> decompress chains run on separate HIP streams,
+        # so the VALU-bound row compressor of one chain overlaps the HBM-bound low-rank / decompress kernels of another
         cur = torch.cuda.current_stream()
-        s_k.wait_stream(cur)
-        s_v.wait_stream(cur)
-        with torch.cuda.stream(s_k):
-            pk = C.compress_key(K, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k)
-            kr = C.decompress(pk, transposed_out=True)
-        with torch.cuda.stream(s_v):
-            pv = C.compress_value(V, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v)
-            vr = C.decompress(pv)
-        cur.wait_stream(s_k)
-        cur.wait_stream(s_v)
-        return pk, pv, kr, vr
+        outs = []
+        for i, (l0, l1) in enumerate(lb):
+            sk, sv = pool[2 * i], pool[2 * i + 1]
+            sk.wait_stream(cur)
+            sv.wait_stream(cur)
+            with torch.cuda.stream(sk):
+                pk = C.compress_key(K[l0:l1], bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k[l0:l1])
+                kr = C.decompress(pk, transposed_out=True)
+            with torch.cuda.stream(sv):
+                pv = C.compress_value(V[l0:l1], bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v[l0:l1])
+                vr = C.decompress(pv)
+            outs.append((pk, pv, kr, vr))
+        for st in pool:
+            cur.wait_stream(st)
+        return outs[0] if parts == 1 else outs
 
-    step = step_two_streams if args.streams == 2 else step_serial
+    step = step_streams if args.streams >= 2 else step_serial
 
     def sync():
         torch.cuda.synchronize()
@@ -244,7 +252,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    pk, pv, kr, vr = out
+    del out
     n_elem_rank = K.numel()                       # per tensor kind, this rank
     fp16_bytes_job = 2 * n_elem_rank * 2 * world  # K + V, whole job
     value = 2 * fp16_bytes_job * args.steps / dt / 1e9   # through compress + through decompress
@@ -252,7 +260,7 @@ def main():
     # ---- per-stage GPU time (HIP events on the launch stream): a dedicated serial pass, outside the timed region
     ev.clear()
     for _ in range(3):
-        step_serial()
+        pk, pv, kr, vr = out = step_serial()     # (also the whole-model payloads the attention leg below runs on)
     torch.cuda.synchronize()
     names = ["k_compress", "v_compress", "k_decompress", "v_decompress"]   # k_compress includes the K^T re-layout
     prev = "t0"
@@ -297,8 +305,9 @@ def main():
     achieved = alg_bytes / (rows_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed in profiles/r1_pmc_traffic_compress_rows.md (FETCH_SIZE x2 per
     # the gfx950 correction + WRITE_SIZE); measured for exactly this launch (C3, 1 GPU, all layers), null otherwise
-    traffic = TRAFFIC_C3 if (args.config == "c3" and world == 1 and not args.layers and nb == 4) else None
-    roofline = {"bound": "hbm", "kernel": "compress_rows_kernel<2,1,float> (per 4-layer chunk, V and K^T launches)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    traffic = TRAFFIC_C3 if (args.config == "c3" and world == 1 and not args.layers and nb == layers) else None
+    roofline = {"bound": "hbm", "kernel": f"compress_rows_fp32_kernel<{bits}, float> (V-layout and K^T-layout launches, {nb} layers each)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": rows_ms}
 

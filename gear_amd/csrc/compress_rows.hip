@@ -561,13 +561,16 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         __syncthreads();
         float tot1 = 0.0f, tot2 = 0.0f;
         for (int w = 0; w < nw; w++) { tot1 += wave_sum[w]; tot2 += __uint_as_float(wave_thr[0][w]); }
-        mean = tot1 / (float)len;
+        // (a power-of-two length divides exactly by a multiply; the oracle's mean is sum / len in fp32)
+        const float rlen = div_rn(1.0f, (float)len);
+        mean = ((len & (len - 1)) == 0) ? tot1 * rlen : tot1 / (float)len;
         bool use_hist = (k > 64) || (zthr <= 0.0f);
         bool payload_done = false;
         uint32_t flag_lo = 0u, flag_hi = 0u;
         if (!use_hist) {
             // ---------------- tier 0: Gaussian-guess thresholds, validated by the survivor counts (see the kernel above)
-            const float sd = sqrtf(fmaxf(tot2 / (float)len - mean * mean, 0.0f));
+            // (the thresholds are a guess that the survivor counts validate: approximate reciprocal / square root do)
+            const float sd = __builtin_amdgcn_sqrtf(fmaxf(tot2 * rlen - mean * mean, 0.0f));
             const float thi = mean + zthr * sd, tlo = mean - zthr * sd;
             const uint32_t th = f2h_bits(thi), tl = f2h_bits(tlo);
             const half2v thi2 = __builtin_bit_cast(half2v, th | (th << 16)), tlo2 = __builtin_bit_cast(half2v, tl | (tl << 16));

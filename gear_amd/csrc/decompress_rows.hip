@@ -44,6 +44,7 @@ struct DGeom {
     int64_t seg_stride;
     int len, group, T, D, r, k, rpb;
     int patch;   // outliers: 1 = overwrite in global memory after the dense pass (no LDS table), 0 = LDS table
+    int trows;   // rows covered by one fill of the LDS outlier table (divides rpb; the block refills it rpb / trows times)
     int64_t n_rows;
 };
 
@@ -66,16 +67,18 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const int r = g.r;
     const int mwords = g.len / 32;       // len is a multiple of 16; bitmaps are read 16 bits at a time
     uint32_t* lmask = dsm;
-    uint16_t* lval = (uint16_t*)(dsm + (size_t)g.rpb * (mwords + 1));
-    if (g.k > 0 && !g.patch) {
-        // the sparse part of all rows of the block goes to LDS once: the dense pass then patches its own elements and
-        // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each)
-        for (int i = tid; i < g.rpb * (mwords + 1); i += blockDim.x) lmask[i] = 0u;
+    uint16_t* lval = (uint16_t*)(dsm + (size_t)g.trows * (mwords + 1));
+    // the sparse part of `trows` rows of the block goes to LDS at a time: the dense pass then patches its own elements and
+    // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each).  The
+    // table is refilled every trows rows so that its size (and with it the number of resident blocks) does not grow with
+    // the number of rows a block keeps its register-resident factor block for.
+    auto fill_table = [&](int rbase) {
+        for (int i = tid; i < g.trows * (mwords + 1); i += blockDim.x) lmask[i] = 0u;
         __syncthreads();
         const int per_row = 2 * g.k;
-        for (int e = tid; e < g.rpb * per_row; e += blockDim.x) {
+        for (int e = tid; e < g.trows * per_row; e += blockDim.x) {
             const int ri = e / per_row;
-            const int64_t row = row0 + ri;
+            const int64_t row = row0 + rbase + ri;
             if (row < g.n_rows) {
                 const uint32_t idx = oidx[row * per_row + e % per_row];
                 atomicOr(&lmask[ri * (mwords + 1) + (idx >> 5)], 1u << (idx & 31));
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             }
         }
         __syncthreads();
-    }
+    };
     // all rows of the block share the outer index (rpb divides rows_inner)
     const int ro = (int)(row0 / g.rows_inner);
     const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
@@ -138,7 +141,14 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const int nrows = active ? (int)((g.n_rows - row0) < g.rpb ? (g.n_rows - row0) : g.rpb) : 0;
     RowIn cur = {}, nxt = {};
     if (nrows > 0) fetch(0, cur);
-    for (int ri = 0; ri < nrows; ri++) {
+    const bool table = g.k > 0 && !g.patch;
+    const int nrows_blk = (int)((g.n_rows - row0) < g.rpb ? (g.n_rows - row0) : g.rpb);   // (block-uniform)
+    for (int ri = 0; ri < nrows_blk; ri++) {
+        if (table && ri % g.trows == 0) {
+            if (ri) __syncthreads();        // everyone is done reading the previous fill
+            fill_table(ri);
+        }
+        if (!active) continue;
         if (ri + 1 < nrows) fetch(ri + 1, nxt);
         float f[16];
 #pragma unroll
@@ -150,11 +160,12 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             }
         }
         if (g.k > 0 && !g.patch) {   // outlier elements: the stored value replaces the dequantized one (low-rank still adds)
-            const uint32_t mb = (lmask[ri * (mwords + 1) + (j0 >> 5)] >> (j0 & 31)) & 0xFFFFu;
+            const int rt = ri % g.trows;
+            const uint32_t mb = (lmask[rt * (mwords + 1) + (j0 >> 5)] >> (j0 & 31)) & 0xFFFFu;
             if (mb) {
 #pragma unroll
                 for (int j = 0; j < 16; j++)
-                    if (mb & (1u << j)) f[j] = h2f_bits(lval[(size_t)ri * g.len + j0 + j]);
+                    if (mb & (1u << j)) f[j] = h2f_bits(lval[(size_t)rt * g.len + j0 + j]);
             }
         }
         if (r > 0) {
@@ -287,14 +298,19 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     const char* pe = getenv("GEAR_DECOMP_PATCH");
     const int patch = pe ? atoi(pe) : 0;   // measured: 0.81 ms (patch) vs 0.72 ms (table) on the 7B / 4k V tensor
     // rows per block, measured on the 7B / 4k tensors (V / K^T ms): factors only: 16 rows 0.48 / 0.42, 8 rows 0.51 / 0.47
-    // (fewer reloads of the lane's factor block); with the LDS outlier table: 4 rows 0.64 / 0.62, 8 rows 0.70 / 0.75
-    // (35 KB instead of 70 KB of LDS per block = twice the resident blocks)
-    int rpb = patch ? 8 : (k > 0 ? 4 : (r > 0 ? 16 : 8));
+    // (fewer reloads of the lane's factor block).  The LDS outlier table covers 4 rows (35 KB) and is refilled inside the
+    // block: outliers + factors 0.58 / 0.54 with 16 rows per block (0.64 / 0.62 when the block itself was 4 rows, 0.70 /
+    // 0.75 with an 8-row table = 70 KB = half the resident blocks)
+    int rpb = patch ? 8 : (r > 0 ? 16 : 8);
     if (const char* re = getenv("GEAR_DECOMP_RPB")) rpb = atoi(re);
-    while (rpb > 1 && (rows_inner % rpb != 0 || (k > 0 && !patch && (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024))) rpb >>= 1;
-    const size_t shmem = (k > 0 && !patch) ? (size_t)rpb * ((len / 32 + 1) * 4 + len * 2) : 0;
+    while (rpb > 1 && rows_inner % rpb != 0) rpb >>= 1;
+    int trows = rpb < 4 ? rpb : 4;            // rows per fill of the LDS outlier table (35 KB at 4096 columns)
+    if (const char* te = getenv("GEAR_DECOMP_TROWS")) trows = atoi(te);
+    if (trows > rpb) trows = rpb;
+    while (trows > 1 && (rpb % trows != 0 || (size_t)trows * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024)) trows >>= 1;
+    const size_t shmem = (k > 0 && !patch) ? (size_t)trows * ((len / 32 + 1) * 4 + len * 2) : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
-    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, n_rows};
+    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));

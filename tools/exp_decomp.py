@@ -13,9 +13,9 @@ for kind in ("v", "k"):
     for (k, r) in ((40, 0), (0, 8), (40, 8)):
         p = comp(x, 2, 64, k_out=k, rank=r, loop=3, mode="fp32", P0=P0 if r else None)
         res = []
-        for env in ({"GEAR_DECOMP_PATCH": "0"}, {"GEAR_DECOMP_PATCH": "0", "GEAR_DECOMP_RPB": "4"}, {"GEAR_DECOMP_PATCH": "0", "GEAR_DECOMP_RPB": "2"},
-                    {"GEAR_DECOMP_PATCH": "0", "GEAR_DECOMP_RPB": "16"}):
+        for env in ({}, {"GEAR_DECOMP_RPB": "8"}, {"GEAR_DECOMP_RPB": "16", "GEAR_DECOMP_TROWS": "2"}, {"GEAR_DECOMP_RPB": "4"}):
             os.environ.pop("GEAR_DECOMP_RPB", None)
+            os.environ.pop("GEAR_DECOMP_TROWS", None)
             os.environ.update(env)
             res.append(f"{timeit(lambda: C.decompress(p, transposed_out=True)):.3f}")
-        print(f"decompress {kind} k={k:2d} r={r}: table rpb 8 / 4 / 2 / 16 = {' / '.join(res)} ms")
+        print(f"decompress {kind} k={k:2d} r={r}: default (16 rows, table 4) / 8 rows / 16 rows table 2 / 4 rows = {' / '.join(res)} ms")
