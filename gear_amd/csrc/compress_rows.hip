@@ -795,7 +795,8 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     }
     if (!active) return;
     const float qscale = div_rn(hi - lo, (float)LEVELS), qmn = lo;        // make_qparams<1>
-    const float inv = (qscale != 0.0f) ? div_rn(1.0f, qscale) : 0.0f;      // zero-range group: every code 0 (defect B6)
+    // (v_rcp_f32 is within 1 ulp: far inside the 1e-5 tie guard below.)  Zero-range group: every code 0 (defect B6)
+    const float inv = (qscale != 0.0f) ? __builtin_amdgcn_rcpf(qscale) : 0.0f;
     // ---------------- quantize: reciprocal multiply; a lane that sees a quotient within 1e-5 of a rounding tie (the only
     // place where t * (1/s) and t / s can round differently; 1e-3 for 8-bit codes) redoes its elements by division
     constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
@@ -827,7 +828,9 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         words[w] = (uint32_t)hl | ((uint32_t)hh << 16);
     }
     if (outl) {   // filled positions: every outlier of the group carries quant(mean)
-        float cm = (qscale != 0.0f) ? rintf(div_rn(mean - qmn, qscale)) : 0.0f;
+        const float cq = (mean - qmn) * inv;
+        float cm = rintf(cq);
+        if (fabsf(cq - cm) > TIE) cm = (qscale != 0.0f) ? rintf(div_rn(mean - qmn, qscale)) : 0.0f;
         cm = __builtin_amdgcn_fmed3f(cm, 0.0f, (float)LEVELS);
         const uint32_t qrep = (uint32_t)cm * (0xFFFFFFFFu / (uint32_t)LEVELS);
 #pragma unroll
