@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 4, 8),
                     help="1: one stream; 2: the K chain and the V chain of a step run on two HIP streams (they are independent); "
                          "4 / 8: each of them additionally split into 2 / 4 groups of layers")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step's launches once as a hipGraph and replay it (takes the host enqueue cost out of short "
+                         "steps; measured within noise of eager launches at every size tried, so it is off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the full-model decode tokens/s leg")
     return ap.parse_args()
@@ -238,13 +241,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         out = step()
+    sync()
+    run_step, graphed = step, False
+    if args.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            graph.replay()                      # one untimed replay
+            run_step, graphed = graph.replay, True
+        except Exception as e:                  # capture is an optimisation of the host side only: fall back to eager
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
     sync()
     ev.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        run_step()
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -349,7 +364,7 @@ def main():
                                    f"{bits}-bit g={group} per-channel K / per-token V + rank-{rnk} (loop {loop}) + "
                                    f"{sparsity * 100:.0f}% outliers (BASELINE configs[{2 if args.config == 'c3' else 1}])",
                        "parallelism": f"head-shard x{world}", "k_outliers_per_side": [k_key, k_val],
-                       "streams": args.streams},
+                       "streams": args.streams, "hipgraph": graphed},
             "compress_GBps": fp16_bytes_job / ((stages["k_compress"] + stages["v_compress"]) * 1e-3) / 1e9,
             "decompress_GBps": fp16_bytes_job / ((stages["k_decompress"] + stages["v_decompress"]) * 1e-3) / 1e9,
             "stage_ms": stages,
