@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the number)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="debug only: run ONE rank's shard of an N-GPU job on this GPU (H/N heads, k/N V outliers); invalidates the number")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 4, 8),
                     help="1: one stream; 2: the K chain and the V chain of a step run on two HIP streams (they are independent); "
                          "4 / 8: each of them additionally split into 2 / 4 groups of layers")
@@ -172,12 +174,13 @@ def main():
     model, layers, H, D, T, bits, group, rnk, loop, sparsity = cfg
     if args.layers:
         layers = args.layers
-    assert H % world == 0, "KV heads must divide across ranks"
-    Hl = H // world
+    shards = args.emulate_world if (args.emulate_world and world == 1) else world
+    assert H % shards == 0, "KV heads must divide across ranks"
+    Hl = H // shards
     # k per side: reference formula on the FULL row (compress_function.py:300-303); per-shard V rows take k/N
     k_full = C.outlier_count(1, H, T, D, sparsity)
     k_key = k_full
-    k_val = max(1, k_full // world)
+    k_val = max(1, k_full // shards)
 
     torch.manual_seed(1234 + rank)
     K = torch.empty((layers, Hl, T, D), dtype=torch.float16, device=dev)

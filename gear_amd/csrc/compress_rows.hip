@@ -513,14 +513,23 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     constexpr int WPL = BITS / 2;
     constexpr int CPW = 32 / BITS;
     constexpr int HC = 16 / BITS;            // codes per 16-bit half of a packed word
-    __shared__ uint32_t hist[3][256];
     __shared__ unsigned long long wave_tot[16];
     __shared__ float wave_sum[16];
     __shared__ int sh[8];
-    __shared__ uint32_t cand[2][CAND_CAP];
-    __shared__ uint32_t omask[2][512];
     __shared__ uint32_t wave_thr[2][16];
-    extern __shared__ uint32_t rawlds[];     // [blockDim.x][8]: raw copy during the emission, then the half-word marks
+    // Dynamic LDS, sized by the host for the row length (a 512-element row of an 8-way head shard needs 3.2 KB, not the
+    // 20 KB of the 16384-element worst case: LDS is what bounds the number of resident one-wave workgroups):
+    //   [ rawlds: blockDim x 8 words (raw copy during the emission, then the half-word outlier marks)
+    //   | cand: 2 sides x nw regions x wcap composites ]      -- the radix-select histograms (3 x 256) alias this part
+    //   [ omask: 2 x ceil(len / 32) words ]
+    extern __shared__ uint32_t dynlds[];
+    const int nw_ = (blockDim.x + 63) >> 6, wcap_ = min(64, CAND_CAP / nw_);
+    uint32_t* rawlds = dynlds;
+    uint32_t* cand0 = dynlds + blockDim.x * 8;
+    uint32_t* cand[2] = {cand0, cand0 + nw_ * wcap_};
+    uint32_t (*hist)[256] = (uint32_t (*)[256])dynlds;
+    const int uw = max(768, (int)blockDim.x * 8 + 2 * nw_ * wcap_), mw = (len + 31) >> 5;
+    uint32_t* omask[2] = {dynlds + uw, dynlds + uw + mw};
 
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -557,7 +566,7 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         s = wave_sum_dpp(s);
         s2 = wave_sum_dpp(s2);
         if (lane == 0) { wave_sum[wave] = s; wave_thr[0][wave] = __float_as_uint(s2); }
-        for (int i = tid; i < 2 * 512; i += blockDim.x) (&omask[0][0])[i] = 0u;
+        for (int i = tid; i < 2 * mw; i += blockDim.x) omask[0][i] = 0u;
         __syncthreads();
         float tot1 = 0.0f, tot2 = 0.0f;
         for (int w = 0; w < nw; w++) { tot1 += wave_sum[w]; tot2 += __uint_as_float(wave_thr[0][w]); }
@@ -588,7 +597,7 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             // Candidates are compacted IN INDEX ORDER into one region per wave (wave-level prefix sum of the lane counts on
             // DPP, no returning LDS atomics): the selecting wave then sees them sorted by index, so ties at the threshold
             // value resolve "lower index first" by position and the outputs come out sorted without a sort.
-            const int wcap = min(64, CAND_CAP / nw);
+            const int wcap = wcap_;
             const uint32_t cntp = (uint32_t)__popc(mh) | ((uint32_t)__popc(ml) << 16);
             const uint32_t incl = wave_incl_scan_u32(cntp);
             const uint32_t excl = incl - cntp;
@@ -1218,8 +1227,11 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
                        (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
                        (float*)omean)
+    const int nwh = threads / 64, wcaph = (64 < CAND_CAP / nwh) ? 64 : CAND_CAP / nwh;
+    const int uwh = (768 > threads * 8 + 2 * nwh * wcaph) ? 768 : threads * 8 + 2 * nwh * wcaph;
+    const size_t lds2 = ((size_t)uwh + 2 * (size_t)((len + 31) / 32)) * 4;
 #define GO2(B)                                                                                                         \
-    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
+    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
                        (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,   \
                        (float*)omean)
     if (mode == 0) {
