@@ -34,7 +34,7 @@ CONFIGS = {
     "c2": ("Llama-2-7B", 32, 32, 128, 2048, 4, 64, 4, 3, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_C3 = None      # HBM bytes per compress_rows launch from the PMC passes (profiles/), filled in once measured
+TRAFFIC_C3 = 2.4917e9   # HBM bytes per compress_rows launch (mean of the V and K^T launches), profiles/r1_pmc_traffic_rows_fp32.md
 
 
 def parse():
@@ -321,8 +321,8 @@ def main():
     k_avg = 0.5 * (nb * T * 2 * k_val + nb * Hl * D * 2 * k_key)   # outlier entries per launch (V rows / K^T rows)
     alg_bytes = 2 * n + n * bits / 8 + 8 * n / group + 2 * n + k_avg * 4
     achieved = alg_bytes / (rows_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC passes committed in profiles/r1_pmc_traffic_compress_rows.md (FETCH_SIZE x2 per
-    # the gfx950 correction + WRITE_SIZE); measured for exactly this launch (C3, 1 GPU, all layers), null otherwise
+    # HBM bytes per launch from the PMC passes committed in profiles/r1_pmc_traffic_rows_fp32.md (FETCH_SIZE x2 per the
+    # gfx950 correction + WRITE_SIZE); measured for exactly these launches (C3, 1 GPU, all layers), null otherwise
     traffic = TRAFFIC_C3 if (args.config == "c3" and world == 1 and not args.layers and nb == layers) else None
     roofline = {"bound": "hbm", "kernel": f"compress_rows_fp32_kernel<{bits}, float> (V-layout and K^T-layout launches, {nb} layers each)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
