@@ -809,18 +809,21 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     // ---------------- quantize: reciprocal multiply; a lane that sees a quotient within 1e-5 of a rounding tie (the only
     // place where t * (1/s) and t / s can round differently; 1e-3 for 8-bit codes) redoes its elements by division
     constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
-    float xq[16], rq[16];
+    float rq[16];
     bool tie = false;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        xq[j] = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
-        const float c = (xq[j] - qmn) * inv;
+        const float xv = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+        const float c = (xv - qmn) * inv;
         rq[j] = rintf(c);
         tie |= fabsf(c - rq[j]) > TIE;
     }
     if (tie) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) rq[j] = (qscale != 0.0f) ? rintf(div_rn(xq[j] - qmn, qscale)) : 0.0f;
+        for (int j = 0; j < 16; j++) {
+            const float xv = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+            rq[j] = (qscale != 0.0f) ? rintf(div_rn(xv - qmn, qscale)) : 0.0f;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) rq[j] = __builtin_amdgcn_fmed3f(rq[j], 0.0f, (float)LEVELS);
