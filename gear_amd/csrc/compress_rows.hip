@@ -504,6 +504,44 @@ __device__ __forceinline__ uint32_t spread_flags(uint32_t f) {
     }
 }
 
+// single-instruction forms the compiler does not pick by itself here: v_bfi_b32 for (a & m) | (b & ~m) (it shares b & ~m
+// between the +inf and -inf variants: 4 instructions for two results), packed / scalar min and max WITHOUT the
+// canonicalising max(x, x) that IEEE minNum semantics put in front of every operand (inputs are never signalling NaNs here:
+// they are loaded fp16 data or +-inf constants), and the fp16 -> fp32 convert folded into the subtract (v_fma_mix_f32).
+__device__ __forceinline__ uint32_t vbfi(uint32_t m, uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmin16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmax16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ float fmin_raw(float a, float bb) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ float fmax_raw(float a, float bb) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+// float(half HI ? high : low of w) - mn, one rounding (the convert is exact)
+template <int HI>
+__device__ __forceinline__ float sub_mix(uint32_t w, float one, float negmn) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(one), "v"(negmn));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(one), "v"(negmn));
+    return r;
+}
+
 template <int BITS, typename ST>
 __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
                                           uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
@@ -783,24 +821,32 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
 
     // ---------------- group min / max over the elements that are not outliers (packed fp16 min/max are exact), plus the
     // fill value (the fp32 row mean, compress_function.py:279-283 / :315-319) when the lane holds an outlier
-    half2v lo2, hi2;
+    uint32_t lo2, hi2;
     {
         const uint32_t PINF = 0x7C007C00u, NINF = 0xFC00FC00u;
-        lo2 = __builtin_bit_cast(half2v, bfi32(m[0], PINF, rw[0]));
-        hi2 = __builtin_bit_cast(half2v, bfi32(m[0], NINF, rw[0]));
+        lo2 = vbfi(m[0], PINF, rw[0]);
+        hi2 = vbfi(m[0], NINF, rw[0]);
 #pragma unroll
         for (int w = 1; w < 8; w++) {
-            lo2 = __builtin_elementwise_min(lo2, __builtin_bit_cast(half2v, bfi32(m[w], PINF, rw[w])));
-            hi2 = __builtin_elementwise_max(hi2, __builtin_bit_cast(half2v, bfi32(m[w], NINF, rw[w])));
+            lo2 = pkmin16(lo2, vbfi(m[w], PINF, rw[w]));
+            hi2 = pkmax16(hi2, vbfi(m[w], NINF, rw[w]));
         }
     }
-    float lo = fminf((float)lo2.x, (float)lo2.y), hi = fmaxf((float)hi2.x, (float)hi2.y);
-    lo = fminf(lo, outl ? mean : INFINITY);
-    hi = fmaxf(hi, outl ? mean : -INFINITY);
+    float lo = fmin_raw(h2f_bits((uint16_t)(lo2 & 0xFFFFu)), h2f_bits((uint16_t)(lo2 >> 16)));
+    float hi = fmax_raw(h2f_bits((uint16_t)(hi2 & 0xFFFFu)), h2f_bits((uint16_t)(hi2 >> 16)));
+    lo = fmin_raw(lo, outl ? mean : INFINITY);
+    hi = fmax_raw(hi, outl ? mean : -INFINITY);
     const int lanes_per_group = group / 16;
-    for (int mm = 1; mm < lanes_per_group; mm <<= 1) {
-        lo = fminf(lo, __shfl_xor(lo, mm, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, mm, 64));
+    if (lanes_per_group == 4) {   // the usual group of 64: the four lanes of a DPP quad
+        lo = fmin_raw(lo, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lo), 0xB1, 0xF, 0xF, true)));
+        hi = fmax_raw(hi, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hi), 0xB1, 0xF, 0xF, true)));
+        lo = fmin_raw(lo, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lo), 0x4E, 0xF, 0xF, true)));
+        hi = fmax_raw(hi, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hi), 0x4E, 0xF, 0xF, true)));
+    } else {
+        for (int mm = 1; mm < lanes_per_group; mm <<= 1) {
+            lo = fminf(lo, __shfl_xor(lo, mm, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, mm, 64));
+        }
     }
     if (!active) return;
     const float qscale = div_rn(hi - lo, (float)LEVELS), qmn = lo;        // make_qparams<1>
@@ -811,12 +857,13 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
     float rq[16];
     bool tie = false;
+    const float one = 1.0f, negmn = -qmn;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float xv = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
-        const float c = (xv - qmn) * inv;
-        rq[j] = rintf(c);
-        tie |= fabsf(c - rq[j]) > TIE;
+    for (int w = 0; w < 8; w++) {
+        const float c0 = sub_mix<0>(rw[w], one, negmn) * inv, c1 = sub_mix<1>(rw[w], one, negmn) * inv;
+        rq[2 * w] = rintf(c0);
+        rq[2 * w + 1] = rintf(c1);
+        tie = tie || (fabsf(c0 - rq[2 * w]) > TIE) || (fabsf(c1 - rq[2 * w + 1]) > TIE);
     }
     if (tie) {
 #pragma unroll
