@@ -858,13 +858,19 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     float rq[16];
     bool tie = false;
     const float one = 1.0f, negmn = -qmn;
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float dmax = 0.0f;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
-        const float c0 = sub_mix<0>(rw[w], one, negmn) * inv, c1 = sub_mix<1>(rw[w], one, negmn) * inv;
-        rq[2 * w] = rintf(c0);
-        rq[2 * w + 1] = rintf(c1);
-        tie = tie || (fabsf(c0 - rq[2 * w]) > TIE) || (fabsf(c1 - rq[2 * w + 1]) > TIE);
+        float2v t = {sub_mix<0>(rw[w], one, negmn), sub_mix<1>(rw[w], one, negmn)};
+        const float2v c = t * inv;                       // v_pk_mul_f32
+        float2v rr = {rintf(c.x), rintf(c.y)};
+        const float2v d = c - rr;                        // v_pk_add_f32
+        rq[2 * w] = rr.x;
+        rq[2 * w + 1] = rr.y;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
     }
+    tie = dmax > TIE;
     if (tie) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
