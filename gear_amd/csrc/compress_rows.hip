@@ -915,8 +915,9 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         for (int w = 0; w < 8; w++) {
             const float d0 = __fadd_rn(__fmul_rn(rq[2 * w], qscale), qmn), d1 = __fadd_rn(__fmul_rn(rq[2 * w + 1], qscale), qmn);
             const uint32_t dw = (uint32_t)f2h_bits(d0) | ((uint32_t)f2h_bits(d1) << 16);
-            const half2v e2 = __builtin_bit_cast(half2v, rw[w]) - __builtin_bit_cast(half2v, dw);
-            ew[w] = __builtin_bit_cast(uint32_t, e2) & ~m[w];
+            uint32_t e2;   // x - d in packed fp16 (the optimiser otherwise negates d in fp32 first), outlier halves cleared
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rw[w]), "v"(dw));
+            ew[w] = vbfi(m[w], 0u, e2);
         }
         uint4* ep = (uint4*)(err + off);
         ep[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]);
