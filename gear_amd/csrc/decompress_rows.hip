@@ -59,21 +59,21 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     constexpr int RVS = RV > 0 ? RV : 1;
-    extern __shared__ uint32_t dsm[];   // [rpb][len/32] outlier bitmaps, then [rpb][len] fp16 outlier values
+    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];   // [trows][len] fp16 outlier values (0xFFFF = none)
     const int tid = threadIdx.x;
     const int j0 = tid * 16;
     const bool active = j0 < g.len;
     const int64_t row0 = (int64_t)blockIdx.x * g.rpb;
     const int r = g.r;
-    const int mwords = g.len / 32;       // len is a multiple of 16; bitmaps are read 16 bits at a time
-    uint32_t* lmask = dsm;
-    uint16_t* lval = (uint16_t*)(dsm + (size_t)g.trows * (mwords + 1));
+    // LDS outlier table: trows x len fp16, 0xFFFF (a NaN no payload value has) = "no outlier here"
+    uint16_t* lval = (uint16_t*)dsm;
     // the sparse part of `trows` rows of the block goes to LDS at a time: the dense pass then patches its own elements and
     // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each).  The
     // table is refilled every trows rows so that its size (and with it the number of resident blocks) does not grow with
     // the number of rows a block keeps its register-resident factor block for.
     auto fill_table = [&](int rbase) {
-        for (int i = tid; i < g.trows * (mwords + 1); i += blockDim.x) lmask[i] = 0u;
+        for (int i = tid; i < g.trows * (g.len / 8); i += blockDim.x)
+            ((uint4*)lval)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         __syncthreads();
         const int per_row = 2 * g.k;
         for (int e = tid; e < g.trows * per_row; e += blockDim.x) {
@@ -81,7 +81,6 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             const int64_t row = row0 + rbase + ri;
             if (row < g.n_rows) {
                 const uint32_t idx = oidx[row * per_row + e % per_row];
-                atomicOr(&lmask[ri * (mwords + 1) + (idx >> 5)], 1u << (idx & 31));
                 lval[(size_t)ri * g.len + idx] = oval[row * per_row + e % per_row];
             }
         }
@@ -154,19 +153,30 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
 #pragma unroll
         for (int w = 0; w < WPL; w++) {
 #pragma unroll
-            for (int j = 0; j < CPW; j++) {
-                float d = dequant_one<MODE>((int)((cur.words[w] >> (BITS * j)) & MASK), cur.s, cur.m);
-                f[w * CPW + j] = (MODE == 0) ? d : hround(d);
-            }
+            for (int j = 0; j < CPW; j++)
+                f[w * CPW + j] = dequant_one<MODE>((int)((cur.words[w] >> (BITS * j)) & MASK), cur.s, cur.m);
         }
-        if (g.k > 0 && !g.patch) {   // outlier elements: the stored value replaces the dequantized one (low-rank still adds)
+        // the dequantized values as packed fp16 (MODE 1: this is the reference's cast of the fp32 result; MODE 0: exact)
+        uint4 d0 = pack8(f), d1 = pack8(f + 8);
+        if (table) {
+            // outlier elements: the stored value replaces the dequantized one (the low-rank term still adds).  Branch-free:
+            // the lane's 32 bytes of the table row, half-words that are not the sentinel select the table value
+            // (per word: xor, min(x, 1), 0 - x, v_bfi -- the first version walked 16 branchy ds_read_u16 blocks)
             const int rt = ri % g.trows;
-            const uint32_t mb = (lmask[rt * (mwords + 1) + (j0 >> 5)] >> (j0 & 31)) & 0xFFFFu;
-            if (mb) {
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    if (mb & (1u << j)) f[j] = h2f_bits(lval[(size_t)rt * g.len + j0 + j]);
-            }
+            const uint4 t0 = *(const uint4*)&lval[(size_t)rt * g.len + j0], t1 = *(const uint4*)&lval[(size_t)rt * g.len + j0 + 8];
+            auto sel = [](uint32_t tw, uint32_t dw) {
+                uint32_t x = ~tw, mk, rr;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(mk) : "v"(x), "v"(0x00010001u));
+                asm("v_pk_sub_u16 %0, %1, %2" : "=v"(mk) : "v"(0u), "v"(mk));
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(rr) : "v"(mk), "v"(tw), "v"(dw));
+                return rr;
+            };
+            d0 = make_uint4(sel(t0.x, d0.x), sel(t0.y, d0.y), sel(t0.z, d0.z), sel(t0.w, d0.w));
+            d1 = make_uint4(sel(t1.x, d1.x), sel(t1.y, d1.y), sel(t1.z, d1.z), sel(t1.w, d1.w));
+        }
+        if (r > 0) {
+            unpack8(d0, f);
+            unpack8(d1, f + 8);
         }
         if (r > 0) {
             if (RV > 0) {
@@ -194,8 +204,13 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             }
         }
         uint4* op = (uint4*)(out + cur.off);
-        op[0] = pack8(f);
-        op[1] = pack8(f + 8);
+        if (r > 0) {
+            op[0] = pack8(f);
+            op[1] = pack8(f + 8);
+        } else {
+            op[0] = d0;
+            op[1] = d1;
+        }
         cur = nxt;
     }
     if (g.k > 0 && g.patch) {
@@ -308,7 +323,7 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     if (const char* te = getenv("GEAR_DECOMP_TROWS")) trows = atoi(te);
     if (trows > rpb) trows = rpb;
     while (trows > 1 && (rpb % trows != 0 || (size_t)trows * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024)) trows >>= 1;
-    const size_t shmem = (k > 0 && !patch) ? (size_t)trows * ((len / 32 + 1) * 4 + len * 2) : 0;
+    const size_t shmem = (k > 0 && !patch) ? (size_t)trows * len * 2 : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
     DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
