@@ -71,21 +71,45 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each).  The
     // table is refilled every trows rows so that its size (and with it the number of resident blocks) does not grow with
     // the number of rows a block keeps its register-resident factor block for.
+    // The entries of the next fill are loaded into registers one fill ahead (2 per thread cover 4 rows x 2k <= 512 entries
+    // for 256 threads; more than that falls back to loading inside the fill), so a fill is LDS work only.
+    constexpr int PF = 2;
+    uint16_t pf_idx[PF], pf_val[PF];
+    const int per_row_t = 2 * g.k, fill_n = g.trows * per_row_t;
+    const bool pf_ok = fill_n <= PF * (int)blockDim.x;
+    auto prefetch_entries = [&](int rbase) {
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int e = tid + q * (int)blockDim.x;
+            const int64_t row = row0 + rbase + e / per_row_t;
+            pf_idx[q] = 0; pf_val[q] = 0;
+            if (e < fill_n && row < g.n_rows && rbase < g.rpb) {
+                pf_idx[q] = oidx[row * per_row_t + e % per_row_t];
+                pf_val[q] = oval[row * per_row_t + e % per_row_t];
+            }
+        }
+    };
     auto fill_table = [&](int rbase) {
         for (int i = tid; i < g.trows * (g.len / 8); i += blockDim.x)
             ((uint4*)lval)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         __syncthreads();
-        const int per_row = 2 * g.k;
-        for (int e = tid; e < g.trows * per_row; e += blockDim.x) {
-            const int ri = e / per_row;
-            const int64_t row = row0 + rbase + ri;
-            if (row < g.n_rows) {
-                const uint32_t idx = oidx[row * per_row + e % per_row];
-                lval[(size_t)ri * g.len + idx] = oval[row * per_row + e % per_row];
+        if (pf_ok) {
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int e = tid + q * (int)blockDim.x;
+                if (e < fill_n && row0 + rbase + e / per_row_t < g.n_rows) lval[(size_t)(e / per_row_t) * g.len + pf_idx[q]] = pf_val[q];
+            }
+            prefetch_entries(rbase + g.trows);
+        } else {
+            for (int e = tid; e < fill_n; e += blockDim.x) {
+                const int ri = e / per_row_t;
+                const int64_t row = row0 + rbase + ri;
+                if (row < g.n_rows) lval[(size_t)ri * g.len + oidx[row * per_row_t + e % per_row_t]] = oval[row * per_row_t + e % per_row_t];
             }
         }
         __syncthreads();
     };
+    if (g.k > 0 && !g.patch && pf_ok) prefetch_entries(0);
     // all rows of the block share the outer index (rpb divides rows_inner)
     const int ro = (int)(row0 / g.rows_inner);
     const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
