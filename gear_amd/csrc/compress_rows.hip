@@ -544,6 +544,7 @@ __device__ __forceinline__ float sub_mix(uint32_t w, float one, float negmn) {
 
 template <int BITS, typename ST>
 __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
+                                          float rlen,
                                           uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
                                           uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
                                           uint16_t* __restrict__ oval, float* __restrict__ omean) {
@@ -604,12 +605,14 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         s = wave_sum_dpp(s);
         s2 = wave_sum_dpp(s2);
         if (lane == 0) { wave_sum[wave] = s; wave_thr[0][wave] = __float_as_uint(s2); }
-        for (int i = tid; i < 2 * mw; i += blockDim.x) omask[0][i] = 0u;
+        if (tid < 2 * mw) omask[0][tid] = 0u;                                  // (2 mw <= blockDim + 2)
+        if (tid + (int)blockDim.x < 2 * mw) omask[0][tid + blockDim.x] = 0u;
         __syncthreads();
-        float tot1 = 0.0f, tot2 = 0.0f;
-        for (int w = 0; w < nw; w++) { tot1 += wave_sum[w]; tot2 += __uint_as_float(wave_thr[0][w]); }
-        // (a power-of-two length divides exactly by a multiply; the oracle's mean is sum / len in fp32)
-        const float rlen = div_rn(1.0f, (float)len);
+        // row totals: lane w < nw picks up wave w's partial sums, one DPP reduction each, results in SGPRs
+        const float tot1 = wave_sum_dpp(lane < nw ? wave_sum[lane] : 0.0f);
+        const float tot2 = wave_sum_dpp(lane < nw ? __uint_as_float(wave_thr[0][lane]) : 0.0f);
+        // (a power-of-two length divides exactly by a multiply with rlen = 1 / len from the host; the oracle's mean is
+        // sum / len in fp32)
         mean = ((len & (len - 1)) == 0) ? tot1 * rlen : tot1 / (float)len;
         bool use_hist = (k > 64) || (zthr <= 0.0f);
         bool payload_done = false;
@@ -1288,7 +1291,7 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     const int uwh = (768 > threads * 8 + 2 * nwh * wcaph) ? 768 : threads * 8 + 2 * nwh * wcaph;
     const size_t lds2 = ((size_t)uwh + 2 * (size_t)((len + 31) / 32)) * 4;
 #define GO2(B)                                                                                                         \
-    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
+    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, 1.0f / (float)len, \
                        (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,   \
                        (float*)omean)
     if (mode == 0) {
