@@ -152,7 +152,7 @@ __device__ __forceinline__ int quant_fast(float v, float mn, float scale, float 
         float t = v - mn;
         float c = t * inv;
         float r = rintf(c);
-        if (fabsf(fabsf(c - r) - 0.5f) < 1e-5f) {
+        if (fabsf(fabsf(c - r) - 0.5f) < (BITS == 8 ? 1e-3f : 1e-5f)) {   // (8-bit quotients reach 255: 1 ulp is 3e-5)
             c = div_rn(t, scale);
             r = rintf(c);
         }
