@@ -159,12 +159,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # GEAR_BENCH_ONE_GPU=1 (debug only): every rank uses cuda:0 and the gloo backend, to exercise the multi-rank control
+    # flow on a single-GPU box; the numbers it prints are meaningless
+    one_gpu = world > 1 and os.environ.get("GEAR_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from gear_amd import compress as C
     from gear_amd import _lib
