@@ -207,11 +207,11 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                 const uint32_t fv[8] = {cur.fv0.x, cur.fv0.y, cur.fv0.z, cur.fv0.w, cur.fv1.x, cur.fv1.y, cur.fv1.z, cur.fv1.w};
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    float acc = 0.0f;
+                    float acc = f[j];   // the dot-product chain starts from the dequantized value (no zero-fill, no final add)
 #pragma unroll
                     for (int c = 0; c < RV2; c++)
                         acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, fv[c]), __builtin_bit_cast(half2_t, gb[j][c]), acc, false);
-                    f[j] += acc;
+                    f[j] = acc;
                 }
             } else {
                 const int rin = (int)((row0 + ri) % g.rows_inner);
