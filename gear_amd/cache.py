@@ -24,44 +24,99 @@ from . import _lib as L
 from . import compress as C
 
 
+def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128):
+    bits, group, R = cc["quantize_bit"], cc["group_size"], cc["residual"]
+    m = cc["compress_method"]
+    lowrank = ("gearl" in m) or ("gearsl" in m)
+    rk = int(cc["rank"]) if lowrank else 0
+    rv = int(cc["rankv"]) if lowrank else 0
+    assert R % 64 == 0 and R % group == 0
+    fpi = 32 // bits
+    Tmax = (max_tokens + R - 1) // R * R
+    nseg = 1 + Tmax // R
+    B, H, D, T = batch, n_kv_heads, head_dim, Tmax
+    shapes = dict(kcode=((B, H, D, T // fpi), torch.int32), kscale=((B, H, D, T // group), torch.float16),
+                  kmn=((B, H, D, T // group), torch.float16), vcode=((B, H, T, D // fpi), torch.int32),
+                  vscale=((B, H, T, D // group), torch.float16), vmn=((B, H, T, D // group), torch.float16),
+                  kwin=((B, H, R, D), torch.float16), vwin=((B, H, R, D), torch.float16))
+    if lowrank:
+        shapes.update(kPseg=((nseg, B, H, D, rk), torch.float16), kQtok=((B, H, T, rk), torch.float16),
+                      vPseg=((nseg, B, H, D, rv), torch.float16), vQtok=((B, H, T, rv), torch.float16))
+    return shapes, dict(bits=bits, group=group, R=R, lowrank=lowrank, rk=rk, rv=rv, fpi=fpi, Tmax=Tmax, nseg=nseg)
+
+
+class GearKVCachePool:
+    """The buffers of ALL layers' caches as one tensor per field with a leading layer dimension.  Every layer's
+    GearKVCache takes its (contiguous) slice, so nothing changes for the kernels; what the pool buys is the block boundary:
+    all layers fill their fp16 windows on the same token, and with pooled storage the 32 per-layer compress + 10-copy
+    sequences (~800 launches) become ONE compress_key / compress_value over [layers * batch, H, residual, 128] and one
+    strided copy per field (compress_all)."""
+
+    def __init__(self, n_layers: int, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device,
+                 head_dim: int = 128, seed: int = 0):
+        shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim)
+        self.L, self.B, self.H, self.D = n_layers, batch, n_kv_heads, head_dim
+        self.loop = int(compress_config.get("loop", 3))
+        self.buf = {n: torch.zeros((n_layers,) + shp, dtype=dt, device=device) for n, (shp, dt) in shapes.items()}
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+        self.caches = []
+
+    def compress_all(self):
+        """Every layer's window holds `residual` tokens: compress all of them in one go and append behind the compressed
+        tokens (same arithmetic as GearKVCache._store_block, the layers ride in the batch dimension)."""
+        d, b, c0 = self.dims, self.buf, self.caches[0]
+        L_, B, H, D, R, g, fpi = self.L, self.B, self.H, self.D, d["R"], d["group"], d["fpi"]
+        assert all(c.n_win == R and c.n_comp == c0.n_comp for c in self.caches)
+        t0, seg = c0.n_comp, c0._segment_of(c0.n_comp)
+        assert t0 + R <= d["Tmax"], "cache capacity exceeded"
+        P0k = P0v = None
+        if d["lowrank"]:
+            P0k = torch.rand((L_ * B, H, D, d["rk"]), device=b["kwin"].device, generator=self.gen)
+            P0v = torch.rand((L_ * B, H, D, d["rv"]), device=b["kwin"].device, generator=self.gen)
+        pk = C.compress_key(b["kwin"].view(L_ * B, H, R, D), d["bits"], g, rank=d["rk"], loop=self.loop, mode="fp16", P0=P0k)
+        pv = C.compress_value(b["vwin"].view(L_ * B, H, R, D), d["bits"], g, rank=d["rv"], loop=self.loop, mode="fp16", P0=P0v)
+        b["kcode"][..., t0 // fpi:(t0 + R) // fpi] = pk.code.view(L_, B, H, D, R // fpi)
+        b["kscale"][..., t0 // g:(t0 + R) // g] = pk.scale.view(L_, B, H, D, R // g)
+        b["kmn"][..., t0 // g:(t0 + R) // g] = pk.mn.view(L_, B, H, D, R // g)
+        b["vcode"][:, :, :, t0:t0 + R] = pv.code.view(L_, B, H, R, D // fpi)
+        b["vscale"][:, :, :, t0:t0 + R] = pv.scale.view(L_, B, H, R, D // g)
+        b["vmn"][:, :, :, t0:t0 + R] = pv.mn.view(L_, B, H, R, D // g)
+        if d["lowrank"]:
+            b["kPseg"][:, seg] = pk.P.view(L_, B, H, D, d["rk"])
+            b["kQtok"][:, :, :, t0:t0 + R] = pk.Q.view(L_, B, H, R, d["rk"])
+            b["vPseg"][:, seg] = pv.P.view(L_, B, H, D, d["rv"])
+            b["vQtok"][:, :, :, t0:t0 + R] = pv.Q.view(L_, B, H, R, d["rv"])
+        for c in self.caches:
+            c.n_comp += R
+            c.n_win = 0
+
+
 class GearKVCache:
     def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device, head_dim: int = 128,
-                 seed: int = 0, state: torch.Tensor = None):
+                 seed: int = 0, state: torch.Tensor = None, pool: GearKVCachePool = None, layer: int = 0):
         assert head_dim == 128
         cc = compress_config
+        shapes, d = _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim)
         self.B, self.H, self.D = batch, n_kv_heads, head_dim
-        self.bits, self.group, self.R = cc["quantize_bit"], cc["group_size"], cc["residual"]
-        m = cc["compress_method"]
-        self.lowrank = ("gearl" in m) or ("gearsl" in m)
-        self.rk = int(cc["rank"]) if self.lowrank else 0
-        self.rv = int(cc["rankv"]) if self.lowrank else 0
+        self.bits, self.group, self.R = d["bits"], d["group"], d["R"]
+        self.lowrank, self.rk, self.rv = d["lowrank"], d["rk"], d["rv"]
         self.loop = int(cc.get("loop", 3))
-        assert self.R % 64 == 0 and self.R % self.group == 0
-        fpi = 32 // self.bits
-        self.fpi = fpi
-        self.Tmax = (max_tokens + self.R - 1) // self.R * self.R
-        nseg = 1 + self.Tmax // self.R
-        B, H, D, T = batch, n_kv_heads, head_dim, self.Tmax
-        dev, h16 = device, torch.float16
-        self.kcode = torch.zeros((B, H, D, T // fpi), dtype=torch.int32, device=dev)
-        self.kscale = torch.zeros((B, H, D, T // self.group), dtype=h16, device=dev)
-        self.kmn = torch.zeros_like(self.kscale)
-        self.vcode = torch.zeros((B, H, T, D // fpi), dtype=torch.int32, device=dev)
-        self.vscale = torch.zeros((B, H, T, D // self.group), dtype=h16, device=dev)
-        self.vmn = torch.zeros_like(self.vscale)
-        if self.lowrank:
-            self.kPseg = torch.zeros((nseg, B, H, D, self.rk), dtype=h16, device=dev)   # channel side, per segment
-            self.kQtok = torch.zeros((B, H, T, self.rk), dtype=h16, device=dev)         # token side
-            self.vPseg = torch.zeros((nseg, B, H, D, self.rv), dtype=h16, device=dev)
-            self.vQtok = torch.zeros((B, H, T, self.rv), dtype=h16, device=dev)
-        else:
-            self.kPseg = self.kQtok = self.vPseg = self.vQtok = None
-        self.kwin = torch.zeros((B, H, self.R, D), dtype=h16, device=dev)
-        self.vwin = torch.zeros_like(self.kwin)
+        self.fpi, self.Tmax = d["fpi"], d["Tmax"]
+        for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn", "kPseg", "kQtok", "vPseg", "vQtok", "kwin", "vwin"):
+            if name not in shapes:
+                setattr(self, name, None)
+            elif pool is not None:          # this layer's slice of the pooled storage (contiguous, same layout)
+                setattr(self, name, pool.buf[name][layer])
+            else:
+                shp, dt = shapes[name]
+                setattr(self, name, torch.zeros(shp, dtype=dt, device=device))
+        if pool is not None:
+            pool.caches.append(self)
         self.n_comp = 0      # compressed tokens
         self.n_win = 0       # tokens in the fp16 window
         self.seg0 = 0        # tokens of segment 0 (the compressed part of the prompt)
-        self.gen = torch.Generator(device=dev)
+        self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
         self._ws = None
         # optional device-side {pos, slot, T, W} shared by all layers (the _dyn methods read it: hipGraph replay)

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .cache import GearKVCache
+from .cache import GearKVCache, GearKVCachePool
 from .modeling_llamagear import apply_rotary_pos_emb
 
 
@@ -30,6 +30,9 @@ class FastGearDecoder:
         dev = model.lm_head.weight.device
         self.dev = dev
         self.layers = []
+        cc0 = model.model.layers[0].self_attn.compress_config
+        # pooled cache storage: block boundaries compress every layer's window in one launch sequence
+        self.pool = GearKVCachePool(len(model.model.layers), batch, self.Hkv, max_tokens, cc0, dev, self.D, seed=seed)
         for i, layer in enumerate(model.model.layers):
             at, mlp = layer.self_attn, layer.mlp
             assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
@@ -41,7 +44,8 @@ class FastGearDecoder:
             wgu = torch.stack([mlp.gate_proj.weight, mlp.up_proj.weight], 1).reshape(-1, n2.shape[0]) * n2[None, :]
             self.layers.append(dict(
                 wqkv=wqkv.contiguous(), wo=at.o_proj.weight, wgu=wgu.contiguous(), wd=mlp.down_proj.weight,
-                cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i),
+                cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i,
+                                  pool=self.pool, layer=i),
                 rotary=at.rotary_emb))
         self.w_head = (model.lm_head.weight * model.model.norm.weight[None, :]).contiguous()
         self.pos = 0
@@ -143,11 +147,12 @@ class FastGearDecoder:
             cache = lw["cache"]
             q = self._norm_qkv_rope(res, lw, dyn=False)
             a = cache.attend(q)
-            cache.maybe_compress()
             res = self._linear_add(a.view(a.shape[0], self.Hq * self.D), lw["wo"], res)
             act = self._norm_linear(res, lw["wgu"], swiglu=True)
             res = self._linear_add(act, lw["wd"], res)
         self.pos += 1
+        if self.layers[0]["cache"].n_win == self.layers[0]["cache"].R:
+            self.pool.compress_all()
         return self._norm_linear(res, self.w_head)
 
     # ------------------------------------------------------------------------------------------------ hipGraph decode
@@ -193,8 +198,7 @@ class FastGearDecoder:
             c.n_win += 1
             full = c.n_win == c.R
         if full:
-            for lw in self.layers:
-                lw["cache"].maybe_compress()
+            self.pool.compress_all()
             self._sync_state()
         return self.tok
 

@@ -271,3 +271,30 @@ def test_fused_qkv_rope_matches_gemv_plus_rope_append():
             assert float((got.float() - ref.float()).abs().max()) <= 6e-3 * float(ref.abs().max())
         # only the addressed slot is written
         assert float(kw1[:, :, :slot].abs().max()) == 0 and float(kw1[:, :, slot + 1:].abs().max()) == 0
+
+
+def test_pooled_block_compress_matches_per_layer():
+    """GearKVCachePool.compress_all (all layers' windows in one compress call) writes exactly what the per-layer
+    GearKVCache.maybe_compress path writes (quantization-only cache: no random bases involved)."""
+    from gear_amd.cache import GearKVCache, GearKVCachePool
+    torch.manual_seed(91)
+    cc = dict(compress_method="KIVI", group_size=64, residual=64, quantize_bit=2, rank=0, rankv=0, loop=0)
+    Lyr, B, H, D = 3, 2, 2, 128
+    pool = GearKVCachePool(Lyr, B, H, 256, cc, "cuda", D)
+    pooled = [GearKVCache(B, H, 256, cc, "cuda", D, pool=pool, layer=i) for i in range(Lyr)]
+    single = [GearKVCache(B, H, 256, cc, "cuda", D) for _ in range(Lyr)]
+    for blk in range(2):
+        for _ in range(64):
+            for cp, cs in zip(pooled, single):
+                k, v = torch.randn(B, H, 1, D).half().cuda(), torch.randn(B, H, 1, D).half().cuda()
+                cp.append(k, v)
+                cs.append(k, v)
+        pool.compress_all()
+        for cs in single:
+            cs.maybe_compress()
+        for cp, cs in zip(pooled, single):
+            assert cp.n_comp == cs.n_comp == 64 * (blk + 1) and cp.n_win == cs.n_win == 0
+            for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn"):
+                assert torch.equal(getattr(cp, name), getattr(cs, name)), name
+    q = torch.randn(B, 4, 1, D).half().cuda()
+    assert torch.equal(pooled[1].attend(q), single[1].attend(q))
