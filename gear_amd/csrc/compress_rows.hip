@@ -644,12 +644,11 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             const uint32_t excl = incl - cntp;
             if (lane == 63) wave_thr[1][wave] = incl;
             // smallest element index left in a mask (bit 15-w <-> element 2w, bit 31-w <-> element 2w+1), removed from it
-            auto next_j = [](uint32_t& msk) {
-                const uint32_t e16 = msk & 0xFFFFu, o16 = msk >> 16;
-                const int we = e16 ? __clz(e16) - 16 : 99, wo = o16 ? __clz(o16) - 16 : 99;   // w = 15 - msb
-                if (we <= wo) { msk &= ~(0x8000u >> we); return 2 * we; }
-                msk &= ~(0x80000000u >> wo);
-                return 2 * wo + 1;
+            auto next_j = [](uint32_t& msk) {   // (branch-free: __clz(0) = 32 makes an empty half lose the comparison)
+                const int we = __clz(msk & 0xFFFFu) - 16, wo = __clz(msk >> 16) - 16;   // w = 15 - msb; 16 when the half is empty
+                const bool ev = we <= wo;
+                msk &= ~(ev ? (0x8000u >> we) : (0x80000000u >> wo));
+                return ev ? 2 * we : 2 * wo + 1;
             };
             int slot = (int)(excl & 0xFFFFu);
             while (mh) {
