@@ -577,11 +577,19 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     const bool active = j0 < len;
     int seg = 0, pos = 0;
     if (active) seg_pos(gm, j0, seg, pos);
-    const int64_t off = row_base_of(gm, r) + (int64_t)seg * gm.seg_stride + pos;
+    // uniform row base (scalar registers) + a 32-bit lane offset: the loads and stores address as SGPR base + VGPR offset
+    // instead of carrying 64-bit vector arithmetic per pointer (the host checks that a row spans < 2^31 elements)
+    const int64_t row_base = row_base_of(gm, r);
+    const uint32_t loff = (uint32_t)seg * (uint32_t)gm.seg_stride + (uint32_t)pos;
+    const uint16_t* xrow = x + row_base;
+    uint32_t* code_row = code + row_base / CPW;                 // row_base is a multiple of the group size
+    ST* scale_row = scale + (row_base >> gm.group_shift);
+    ST* mn_row = mn + (row_base >> gm.group_shift);
+    uint16_t* err_row = err ? err + row_base : nullptr;
 
     uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
     if (active) {
-        const uint4* p = (const uint4*)(x + off);
+        const uint4* p = (const uint4*)(xrow + loff);
         ra = p[0];
         rb = p[1];
     }
@@ -903,12 +911,12 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
 #pragma unroll
         for (int w = 0; w < WPL; w++) words[w] = bfi32(spread_flags<BITS>(outl >> (w * CPW)), qrep, words[w]);
     }
-    uint32_t* cp = code + off / CPW;
+    uint32_t* cp = code_row + loff / CPW;
 #pragma unroll
     for (int w = 0; w < WPL; w++) cp[w] = words[w];
     if ((tid & (lanes_per_group - 1)) == 0) {
-        st_st<ST>(scale + (off >> gm.group_shift), qscale);
-        st_st<ST>(mn + (off >> gm.group_shift), qmn);
+        st_st<ST>(scale_row + (loff >> gm.group_shift), qscale);
+        st_st<ST>(mn_row + (loff >> gm.group_shift), qmn);
     }
     if (err) {
         // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
@@ -921,7 +929,7 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rw[w]), "v"(dw));
             ew[w] = vbfi(m[w], 0u, e2);
         }
-        uint4* ep = (uint4*)(err + off);
+        uint4* ep = (uint4*)(err_row + loff);
         ep[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]);
         ep[1] = make_uint4(ew[4], ew[5], ew[6], ew[7]);
     }
@@ -1244,6 +1252,8 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     GEAR_CHECK_ARG(outer_stride % group == 0 && inner_stride % group == 0 && (nseg == 1 || seg_stride % group == 0),
                    "gear_compress_rows: strides must be multiples of the group size");
     GEAR_CHECK_ARG(x && code && scale && mn, "gear_compress_rows: null pointer");
+    GEAR_CHECK_ARG((nseg - 1) * seg_stride + seglen < 0x7FFFFFFFLL && seg_stride >= 0,
+                   "gear_compress_rows: a row must span fewer than 2^31 elements");
     GEAR_CHECK_ARG(k == 0 || (oidx && oval), "gear_compress_rows: outlier buffers required when k > 0");
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
     RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride,
