@@ -428,8 +428,9 @@ __device__ __forceinline__ float reduce8_over_wave(float (&v)[8], int lane) {
     return r;
 }
 
-template <int BITS, typename ST>
+template <int BITS, typename ST, bool R16>
 __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
+    constexpr int RW = R16 ? 16 : 8;   // factor row width (a.rk / a.rv are 0 or RW)
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     constexpr int NWC = SC / CPW;    // K: packed words per channel in the chunk (8 | 16) = lanes along tokens
@@ -440,13 +441,13 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     constexpr int VIT = SC / NRS;    // V: tokens per thread (4 | 8)
     constexpr int XS = BITS == 2 ? 3 : 2;   // butterfly steps over the in-wave subset lanes (64 / NWC = 8 | 4 of them)
     __shared__ float qs[AD];
-    __shared__ float up[4][8];       // Pk[seg(slab)]^T q: waves 0,1 -> slab 0 (channels 0-63 / 64-127), waves 2,3 -> slab 1
+    __shared__ float up[4][RW];       // Pk[seg(slab)]^T q: waves 0,1 -> slab 0 (channels 0-63 / 64-127), waves 2,3 -> slab 1
     __shared__ float sp[4][SC];      // K side: per-wave partial scores
     __shared__ float s[SC];
     __shared__ float op[4][AD];      // V side: per-wave partial outputs
     __shared__ float ot[2][AD];      // Pv[seg(slab)] (Qv^T p)_slab
     __shared__ float oacc[AD];
-    __shared__ float wsl[2][8];      // Qv^T p of the two slabs
+    __shared__ float wsl[2][RW];      // Qv^T p of the two slabs
     __shared__ float red[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -504,13 +505,26 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         }
     }
     uint4 kq8 = {0, 0, 0, 0}, vq8 = {0, 0, 0, 0}, kp8 = {0, 0, 0, 0}, vp8 = {0, 0, 0, 0};
+    uint4 kq8b = {0, 0, 0, 0}, vq8b = {0, 0, 0, 0}, kp8b = {0, 0, 0, 0}, vp8b = {0, 0, 0, 0};   // columns 8..15 (rank 16)
     if (a.rk) {
-        kp8 = *(const uint4*)(a.kP + (int64_t)seg * a.kP_seg_stride + (bhk * AD + dq) * 8);
-        if (tid < tn) kq8 = *(const uint4*)(a.kQ + (bhk * a.tf_k + t0 + tid) * 8);
+        const uint4* pp = (const uint4*)(a.kP + (int64_t)seg * a.kP_seg_stride + (bhk * AD + dq) * RW);
+        kp8 = pp[0];
+        if (R16) kp8b = pp[1];
+        if (tid < tn) {
+            const uint4* qp = (const uint4*)(a.kQ + (bhk * a.tf_k + t0 + tid) * RW);
+            kq8 = qp[0];
+            if (R16) kq8b = qp[1];
+        }
     }
     if (a.rv) {
-        vp8 = *(const uint4*)(a.vP + (int64_t)seg * a.vP_seg_stride + (bhk * AD + dq) * 8);
-        if (tid < tn) vq8 = *(const uint4*)(a.vQ + (bhk * a.tf_v + t0 + tid) * 8);
+        const uint4* pp = (const uint4*)(a.vP + (int64_t)seg * a.vP_seg_stride + (bhk * AD + dq) * RW);
+        vp8 = pp[0];
+        if (R16) vp8b = pp[1];
+        if (tid < tn) {
+            const uint4* qp = (const uint4*)(a.vQ + (bhk * a.tf_v + t0 + tid) * RW);
+            vq8 = qp[0];
+            if (R16) vq8b = qp[1];
+        }
     }
 
     // ------------------------------------------------------------------ 1. scores
@@ -522,6 +536,13 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         for (int c = 0; c < 8; c++) pr[c] *= qv;
         const float r = reduce8_over_wave(pr, lane);
         if ((lane & 7) == 0) up[wave][lane >> 3] = r;
+        if (R16) {
+            unpack8(kp8b, pr);
+#pragma unroll
+            for (int c = 0; c < 8; c++) pr[c] *= qv;
+            const float r2 = reduce8_over_wave(pr, lane);
+            if ((lane & 7) == 0) up[wave][8 + (lane >> 3)] = r2;
+        }
     }
     __syncthreads();
     {
@@ -551,6 +572,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
             unpack8(kq8, tq);
 #pragma unroll
             for (int c = 0; c < 8; c++) acc = fmaf(tq[c], up[2 * wave][c] + up[2 * wave + 1][c], acc);
+            if (R16) {
+                unpack8(kq8b, tq);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc = fmaf(tq[c], up[2 * wave][8 + c] + up[2 * wave + 1][8 + c], acc);
+            }
             v += acc;
         }
         sv = v;
@@ -609,6 +635,13 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         for (int c = 0; c < 8; c++) wl[c] *= p;
         const float r = reduce8_over_wave(wl, lane);
         if ((lane & 7) == 0) wsl[wave][lane >> 3] = r;
+        if (R16) {
+            unpack8(vq8b, wl);
+#pragma unroll
+            for (int c = 0; c < 8; c++) wl[c] *= p;
+            const float r2 = reduce8_over_wave(wl, lane);
+            if ((lane & 7) == 0) wsl[wave][8 + (lane >> 3)] = r2;
+        }
     }
     __syncthreads();
     if (a.rv) {   // the unnormalised partial is linear in p: ot[slab][d] = Pv[seg(slab)][d][:] . wsl[slab]
@@ -616,6 +649,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         unpack8(vp8, t);
 #pragma unroll
         for (int c = 0; c < 8; c++) acc = fmaf(t[c], wsl[slab][c], acc);
+        if (R16) {
+            unpack8(vp8b, t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc = fmaf(t[c], wsl[slab][8 + c], acc);
+        }
         ot[slab][dq] = (slab * 64 < tn) ? acc : 0.0f;
         __syncthreads();
     }
@@ -798,7 +836,9 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
     a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
     a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
     bool small;
-    a.splits = plan_splits(T, bits, (int64_t)B * Hq, (a.rk == 0 || a.rk == 8) && (a.rv == 0 || a.rv == 8), &a.tc, &small);
+    const bool r8 = (a.rk == 0 || a.rk == 8) && (a.rv == 0 || a.rv == 8);
+    const bool r16 = !r8 && (a.rk == 0 || a.rk == 16) && (a.rv == 0 || a.rv == 16);
+    a.splits = plan_splits(T, bits, (int64_t)B * Hq, r8 || r16, &a.tc, &small);
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     a.part_o = ws;
     a.part_w = a.part_o + (size_t)B * Hq * a.splits * AD;
@@ -808,7 +848,8 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
         dim3 grid(a.splits, (unsigned)(B * Hq));
 #define GO(BI, STT)                                                                                             \
     do {                                                                                                        \
-        if (small) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT>), grid, dim3(256), 0, st, a);    \
+        if (small && r16) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, true>), grid, dim3(256), 0, st, a);  \
+        else if (small) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, false>), grid, dim3(256), 0, st, a);   \
         else hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a);              \
     } while (0)
         if (mode == 0) { if (bits == 2) GO(2, uint16_t); else GO(4, uint16_t); }

@@ -82,7 +82,8 @@ def attn_kernel(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("B,Hq,Hkv,T,W,bits,mode,rank,k_out", CASES + [(1, 2, 1, 8320, 3, 2, "fp32", 8, 20)])
+@pytest.mark.parametrize("B,Hq,Hkv,T,W,bits,mode,rank,k_out", CASES + [(1, 2, 1, 8320, 3, 2, "fp32", 8, 20),
+                                                                   (1, 8, 1, 8192, 5, 2, "fp32", 16, 20)])   # 70B-style GQA head, rank 16
 def test_fused_decode_attention(attn_kernel, B, Hq, Hkv, T, W, bits, mode, rank, k_out):
     from gear_amd import compress as C
     from gear_amd.attention import decode_attention
