@@ -5,10 +5,15 @@
 //   * V / token quantization : row = one token across ALL heads  (len = H*D, H segments of D contiguous fp16)
 //   * K / channel quantization: row = one channel across all tokens (len = T, contiguous in the K^T layout
 //                               [B,H,D,T] that the attention hook passes, modeling_llamagear.py:268)
-// Quantization groups are `group` consecutive elements inside a segment.  One workgroup owns one row: each
-// lane keeps 16 consecutive elements in registers; the k smallest / k largest are found with a two-level radix
-// select on the order-preserving 16-bit key of the fp16 value (LDS histograms, wave scans), ties broken by
-// LOWER INDEX FIRST (the oracle's rule); the survivors are quantized exactly like quant_pack.hip.
+// Quantization groups are `group` consecutive elements inside a segment.  One workgroup owns one row, each lane 16
+// consecutive elements in registers; ties are broken by LOWER INDEX FIRST (the oracle's rule); the survivors are quantized
+// exactly like quant_pack.hip.  Three kernels live here:
+//   compress_rows_fp32_kernel  fp32 arithmetic (mode 1, the simulated path): Gaussian-threshold candidates compacted in
+//                              index order + 17-step key bisection (two-level radix select as the exact fallback), dense
+//                              part on packed fp16 / packed fp32 -- the kernel the bench and the roofline are about
+//   compress_rows_kernel       first generation: fp16-stepwise arithmetic (mode 0, the fused path's block compress) and,
+//                              under GEAR_ROWS_V1, the fp32 mode for A/B runs
+//   compress_rows_wave_kernel  one wave per row (GEAR_ROWS_WAVE_KERNEL): an experiment that measured slower
 //
 // Outputs per row: packed codes, scale, mn, optional error (0 at outlier positions), and the sparse part
 // (column index within the row as uint16 + original fp16 value, sorted by index; first k = smallest side).

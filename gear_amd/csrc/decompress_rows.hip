@@ -9,10 +9,10 @@
 //   kind 1 (K^T): row = (bh, d), element j -> token j
 //
 // A workgroup owns RPB consecutive rows.  A lane keeps the same 16 columns for every row, so the 16 x r block of
-// the factor that varies along the row (P rows for V, Q rows for K^T) is loaded ONCE into registers and reused;
-// only the r-vector of the other factor changes per row.  Dense phase: one 32-byte store per lane per row.
-// Sparse phase (after a barrier): the few outlier positions of the block's rows are overwritten with
-// fp16(value + low-rank term).
+// the factor that varies along the row (P rows for V, Q rows for K^T) is loaded ONCE into registers (packed fp16 pairs,
+// consumed by v_dot2_f32_f16) and reused; only the r-vector of the other factor changes per row.  One 32-byte store per
+// lane per row.  Outliers: the block keeps an fp16 table of 4 rows in LDS (0xFFFF = no outlier), refilled every 4 rows
+// from entries prefetched one fill ahead; a lane reads its 32 bytes of the table row and selects half-words branch-free.
 #include <stdlib.h>
 
 #include "common.h"

@@ -7,10 +7,11 @@
 // accumulate), a tiny per-head solve that never leaves LDS, and ONE more pass Q' = E W with W = P' R^-1.
 // The reference makes 2*loop passes over E (new_pack.py:298-304); same mathematics, fp32-level differences.
 //
-// Kernel 1 (one workgroup per head): stream E through LDS, v_mfma_f32_32x32x16_f16 on the 10 upper-triangular
-//   32x32 blocks of G (contraction over tokens), then the solve (CholeskyQR2 in fp64 for orth(P), one Cholesky for Q).
-// Kernel 2: Q' = E W -- lanes own 8 tokens and stream the 128 channels (K^T layout) or 16 lanes share a token row
-//   (token-major layout); plain fp32 FMAs, HBM-bound.
+// Kernel 1 (one workgroup per head): stream E through LDS (3 tiles of loads in flight), v_mfma_f32_32x32x16_f16 on the 10
+//   upper-triangular 32x32 blocks of G (contraction over tokens), then the solve: strip matmuls on the symmetric G,
+//   CholeskyQR2 in fp64 for orth(P) and one Cholesky for Q, both column-parallel on one wave.
+// Kernel 2: Q' = E W -- token-major layout on the matrix cores (MFMA B operands straight from global memory, W split into
+//   fp16 head + remainder); K^T layout: lanes own 8 tokens and stream the 128 channels with fp32 FMAs.
 #include <stdlib.h>
 
 #include "common.h"
