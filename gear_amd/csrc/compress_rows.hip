@@ -464,10 +464,13 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
 
 
 // =====================================================================================================
-// fp32-arithmetic rows (MODE 1), second generation of the workgroup kernel above.  Same selection (tier-0 Gaussian
-// thresholds -> candidates -> ballot bisection -> bitonic sort, histogram radix select as the exact fallback), but the
-// dense part was rebuilt around what the PMC counters showed (VALU-issue-bound, ~1000 VALU instructions per wave and
-// row of which ~100 were per-element compare/select chains and ~32 branches):
+// fp32-arithmetic rows (MODE 1), second generation of the workgroup kernel above.  Selection: tier-0 Gaussian thresholds
+// from the row's sum / sum of squares -> candidates compacted IN INDEX ORDER into one LDS region per wave (DPP prefix sum of
+// the lane counts) -> one wave per side finds the threshold value by 17 rounds of ballot bisection on the 16-bit order key,
+// ties at the threshold resolve "lower index first" by position, outputs come out sorted by index without a sort; the
+// two-level histogram radix select stays as the exact fallback.  The dense part was rebuilt around what the PMC counters
+// showed (VALU-issue-bound, ~1000 VALU instructions per wave and row of which ~100 were per-element compare/select chains
+// and ~32 branches):
 //   * the lane's 16 elements stay PACKED (8 words of 2 x fp16) wherever the arithmetic is exact in fp16: row sum and
 //     sum of squares by v_dot2_f32_f16, group min/max by v_pk_min/max_f16 with the outlier halves masked to +-inf,
 //     error = x - dequant by v_pk_add_f16 (a single rounding of an exact difference, identical to rounding the fp32
