@@ -38,6 +38,8 @@ SIGNATURES = {
     "gear_attn_decode_dyn": (_i, [_vp] * 17 + [_i] * 21 + [_vp, C.c_float, _vp, _vp, _vp, _sz, _vp]),
     "gear_rope_append_dyn": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp, _i, _vp]),
     "gear_decode_state_advance": (_i, [_vp, _vp]),
+    "gear_outlier_chunk_index": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
+    "gear_attn_decode_idx": (_i, [_vp] * 19 + [_i] * 18 + [C.c_float, _vp, _vp, _vp, _sz, _vp]),
     "gear_gemv_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "gear_gemv_f16_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gear_gemv_f16_norm": (_i, [_vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -35,9 +35,12 @@ def decode_attention(q: torch.Tensor, pk: Optional[Payload], pv: Optional[Payloa
         ldk, lsk = T // fpi, T // pk.group
         bits, group, mode = pk.bits, pk.group, pk.mode
         rk, rv, kk, kv = pk.rank, pv.rank, pk.k_out, pv.k_out
+        # chunk index of the outlier lists (contexts the 128-token-chunk kernel handles)
+        args["kochunk"] = pk.chunk_index() if T <= 8192 else None
+        args["vochunk"] = pv.chunk_index() if T <= 8192 else None
     else:
         Hkv, T = k_window.shape[1], 0
-        args = {n: None for n in ("kcode kscale kmn kP kQ koidx koval vcode vscale vmn vP vQ voidx voval").split()}
+        args = {n: None for n in ("kcode kscale kmn kP kQ koidx koval vcode vscale vmn vP vQ voidx voval kochunk vochunk").split()}
         ldk = lsk = 0
         bits, group, mode, rk, rv, kk, kv = 2, 64, 0, 0, 0, 0, 0
     out = torch.empty((B, Hq, 1, D), dtype=torch.float16, device=q.device)
@@ -45,10 +48,11 @@ def decode_attention(q: torch.Tensor, pk: Optional[Payload], pv: Optional[Payloa
     wsb = lib.gear_attn_decode_workspace(B, Hq, T, bits)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
     p = L.ptr
-    rc = lib.gear_attn_decode(p(q), p(args["kcode"]), p(args["kscale"]), p(args["kmn"]), p(args["kP"]), p(args["kQ"]),
-                              p(args["koidx"]), p(args["koval"]), p(args["vcode"]), p(args["vscale"]), p(args["vmn"]),
-                              p(args["vP"]), p(args["vQ"]), p(args["voidx"]), p(args["voval"]), p(k_window), p(v_window),
-                              B, Hq, Hkv, D, T, W, ldk, lsk, T, T, T, group, bits, mode, rk, rv, kk, kv,
-                              1.0 / math.sqrt(D), p(out), p(lse), p(ws), wsb, L.stream_ptr())
+    rc = lib.gear_attn_decode_idx(p(q), p(args["kcode"]), p(args["kscale"]), p(args["kmn"]), p(args["kP"]), p(args["kQ"]),
+                                  p(args["koidx"]), p(args["koval"]), p(args["kochunk"]), p(args["vcode"]), p(args["vscale"]),
+                                  p(args["vmn"]), p(args["vP"]), p(args["vQ"]), p(args["voidx"]), p(args["voval"]),
+                                  p(args["vochunk"]), p(k_window), p(v_window),
+                                  B, Hq, Hkv, D, T, W, ldk, lsk, T, T, T, group, bits, mode, rk, rv, kk, kv,
+                                  1.0 / math.sqrt(D), p(out), p(lse), p(ws), wsb, L.stream_ptr())
     L.check(rc, "gear_attn_decode")
     return (out, lse) if return_lse else out

@@ -49,9 +49,25 @@ class Payload:
     def rank(self):
         return 0 if self.P is None else self.P.shape[-1]
 
+    def chunk_index(self) -> Optional[torch.Tensor]:
+        """uint8 chunk index of the sorted outlier lists (built once, cached): K lists (b, h, d, side) x (T/128 + 1) token
+        bounds, V lists (b, t, side) x (H + 1) head bounds -- what gear_attn_decode_idx uses to find a chunk's outliers
+        without a binary search.  None without outliers or when a list is longer than 255."""
+        if self.oidx is None or self.k_out == 0 or self.k_out > 255:
+            return None
+        if getattr(self, "_ochunk", None) is None:
+            B, H, T, D = self.shape
+            nb = (T + 127) // 128 + 1 if self.kind == "k" else H + 1
+            n_lists = self.oidx.numel() // self.k_out
+            out = torch.empty((n_lists, nb), dtype=torch.uint8, device=self.oidx.device)
+            rc = L.load().gear_outlier_chunk_index(L.ptr(self.oidx), n_lists, self.k_out, 128, nb, L.ptr(out), L.stream_ptr())
+            L.check(rc, "gear_outlier_chunk_index")
+            self._ochunk = out
+        return self._ochunk
+
     def nbytes(self) -> int:
         n = 0
-        for t in (self.code, self.scale, self.mn, self.P, self.Q, self.oidx, self.oval):
+        for t in (self.code, self.scale, self.mn, self.P, self.Q, self.oidx, self.oval, getattr(self, "_ochunk", None)):
             if t is not None:
                 n += t.numel() * t.element_size()
         return n

@@ -56,6 +56,12 @@ struct AttnArgs {
     float* part_o;           // [B*Hq, splits, 128]
     float* part_w;           // [B*Hq, splits, 16]
     float* part_ml;          // [B*Hq, splits, 2]
+    // optional chunk index of the sorted outlier lists (gear_outlier_chunk_index): entry [list][b] = first position in
+    // the list whose index is >= b * 128.  K lists (bhk, d, side) x (T / 128 + 1) token bounds; V lists (b, t, side) x
+    // (Hkv + 1) column bounds.  Lets a 128-token chunk find its outliers without a binary search per list.
+    const uint8_t* kochunk;
+    const uint8_t* vochunk;
+    int nbk, nbv;
 };
 
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
@@ -527,6 +533,20 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         }
     }
 
+    // outlier list ranges of this chunk (chunk index present): K list (channel dq, side tid >> 7), V list (token tid & 127,
+    // side tid >> 7) -- two byte loads each, issued with everything else
+    int ki0 = 0, ki1 = 0, vi0 = 0, vi1 = 0;
+    if (a.kochunk) {
+        const int64_t list = (bhk * AD + dq) * 2 + (tid >> 7);
+        ki0 = a.kochunk[list * a.nbk + split];
+        ki1 = a.kochunk[list * a.nbk + split + 1];
+    }
+    if (a.vochunk && (tid & (SC - 1)) < tn) {
+        const int64_t list = ((int64_t)b * a.tcap_v + t0 + (tid & (SC - 1))) * 2 + (tid >> 7);
+        vi0 = a.vochunk[list * a.nbv + hkv];
+        vi1 = a.vochunk[list * a.nbv + hkv + 1];
+    }
+
     // ------------------------------------------------------------------ 1. scores
     if (tid < AD) qs[tid] = qv;
     if (a.rk) {   // up[wave][:] = sum over this wave's 64 channels of q[d] Pk[seg(slab)][d][:]
@@ -584,21 +604,43 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     if (a.kk > 0) {   // K outliers inside the chunk: s[t] += q[d] (val - dequant(t, d))
         if (tid < SC) s[tid] = sv;
         __syncthreads();
-        if (tid < AD) {
-            const int d = tid;
-            for (int side = 0; side < 2; side++) {
-                const uint16_t* oi = a.koidx + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
-                const uint16_t* ov = a.koval + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
-                for (int i = lower_bound_u16(oi, a.kk, t0); i < a.kk; i++) {
-                    const int t = oi[i];
-                    if (t >= t0 + tn) break;
-                    const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + t / CPW];
-                    const int g = t / a.group;
-                    const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
-                    const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
-                    const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & MASK), mnv);
-                    atomicAdd(&s[t - t0], qv * (h2f_bits(ov[i]) - deq));
+        {   // one sorted list per (channel, side) = per thread; its entries inside the chunk are [i0, i1)
+            const int side = tid >> 7;
+            const int64_t list = (bhk * AD + dq) * 2 + side;
+            const uint16_t* oi = a.koidx + list * (int64_t)a.kk;
+            const uint16_t* ov = a.koval + list * (int64_t)a.kk;
+            int i0, i1 = a.kk;
+            if (a.kochunk) { i0 = ki0; i1 = ki1; }
+            else i0 = lower_bound_u16(oi, a.kk, t0);
+            const int64_t ch = bhk * AD + dq;
+            for (int base = i0; base < i1; base += 4) {   // 4 entries per trip: their loads fly together
+                int tt[4];
+                float val[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool ok = base + j < i1;
+                    tt[j] = ok ? (int)oi[base + j] : 0x7FFFFFFF;
+                    val[j] = ok ? h2f_bits(ov[base + j]) : 0.0f;
                 }
+                uint32_t word[4];
+                float sc[4], mnv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool ok = tt[j] < t0 + tn;
+                    const int t = ok ? tt[j] : t0;
+                    word[j] = a.kcode[ch * (int64_t)a.ldk + t / CPW];
+                    sc[j] = ld_st<ST>(kscale + ch * (int64_t)a.lsk + t / a.group);
+                    mnv[j] = ld_st<ST>(kmn + ch * (int64_t)a.lsk + t / a.group);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (tt[j] < t0 + tn) {
+                        const int t = tt[j];
+                        const float deq = fmaf(sc[j], (float)((word[j] >> (BITS * (t % CPW))) & MASK), mnv[j]);
+                        atomicAdd(&s[t - t0], qv * (val[j] - deq));
+                    }
+                }
+                if (tt[3] >= t0 + tn) break;   // (without the chunk index i1 = kk: stop at the first entry past the chunk)
             }
         }
         __syncthreads();
@@ -665,24 +707,46 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     if (a.kv > 0) {   // V outliers of the chunk's tokens that fall into this head's 128 columns
         if (tid < AD) oacc[tid] = o;
         __syncthreads();
-        if (tid < tn) {
+        const int tok = tid & (SC - 1), side = tid >> 7;   // one sorted list per (token, side) = per thread
+        if (tok < tn) {
             const int c_lo = hkv * AD, c_hi = c_lo + AD;
             const int ngv = AD / a.group;
-            const int64_t orow = (int64_t)b * a.tcap_v + t0 + tid;
-            const int64_t row = bhk * a.tcap_v + t0 + tid;
-            for (int side = 0; side < 2; side++) {
-                const uint16_t* oi = a.voidx + (orow * 2 + side) * a.kv;
-                const uint16_t* ov = a.voval + (orow * 2 + side) * a.kv;
-                for (int i = lower_bound_u16(oi, a.kv, c_lo); i < a.kv; i++) {
-                    const int col = oi[i];
-                    if (col >= c_hi) break;
-                    const int d = col - c_lo;
-                    const uint32_t word = a.vcode[row * NWV + d / CPW];
-                    const float sc = ld_st<ST>(vscale + row * ngv + d / a.group);
-                    const float mnv = ld_st<ST>(vmn + row * ngv + d / a.group);
-                    const float deq = fmaf(sc, (float)((word >> (BITS * (d % CPW))) & MASK), mnv);
-                    atomicAdd(&oacc[d], p * (h2f_bits(ov[i]) - deq));
+            const int64_t orow = (int64_t)b * a.tcap_v + t0 + tok;
+            const int64_t row = bhk * a.tcap_v + t0 + tok;
+            const int64_t list = orow * 2 + side;
+            const uint16_t* oi = a.voidx + list * a.kv;
+            const uint16_t* ov = a.voval + list * a.kv;
+            const float pt = s[tok];
+            int i0, i1 = a.kv;
+            if (a.vochunk) { i0 = vi0; i1 = vi1; }
+            else i0 = lower_bound_u16(oi, a.kv, c_lo);
+            for (int base = i0; base < i1; base += 4) {
+                int cc[4];
+                float val[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool ok = base + j < i1;
+                    cc[j] = ok ? (int)oi[base + j] : 0x7FFFFFFF;
+                    val[j] = ok ? h2f_bits(ov[base + j]) : 0.0f;
                 }
+                uint32_t word[4];
+                float sc[4], mnv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int d = cc[j] < c_hi ? cc[j] - c_lo : 0;
+                    word[j] = a.vcode[row * NWV + d / CPW];
+                    sc[j] = ld_st<ST>(vscale + row * ngv + d / a.group);
+                    mnv[j] = ld_st<ST>(vmn + row * ngv + d / a.group);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (cc[j] < c_hi) {
+                        const int d = cc[j] - c_lo;
+                        const float deq = fmaf(sc[j], (float)((word[j] >> (BITS * (d % CPW))) & MASK), mnv[j]);
+                        atomicAdd(&oacc[d], pt * (val[j] - deq));
+                    }
+                }
+                if (cc[3] >= c_hi) break;
             }
         }
         __syncthreads();
@@ -794,13 +858,42 @@ extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
     return (size_t)B * Hq * 64 * (AD + 16 + 2) * sizeof(float) + 256;
 }
 
-extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+namespace {
+
+// sorted uint16 lists [n_lists][k] -> out[list][b] = first position whose value is >= b * step, b = 0 .. n_bounds - 1
+__global__ __launch_bounds__(256) void outlier_chunk_index_kernel(const uint16_t* __restrict__ oidx, int64_t n_lists, int k,
+                                                                  int step, int n_bounds, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_lists * n_bounds) return;
+    const int64_t list = i / n_bounds;
+    const int bnd = (int)(i % n_bounds);
+    out[i] = (uint8_t)lower_bound_u16(oidx + list * k, k, bnd * step);
+}
+
+}  // namespace
+
+extern "C" int gear_outlier_chunk_index(const void* oidx, int64_t n_lists, int k, int step, int n_bounds, void* out,
+                                        void* stream) {
+    GEAR_CHECK_ARG(oidx && out && n_lists > 0 && n_bounds > 0 && step > 0, "gear_outlier_chunk_index: bad arguments");
+    GEAR_CHECK_ARG(k > 0 && k <= 255, "gear_outlier_chunk_index: list length %d must be in [1,255] (positions are stored as bytes)", k);
+    GEAR_CHECK_ARG((int64_t)(n_bounds - 1) * step <= 65536, "gear_outlier_chunk_index: bounds exceed the uint16 index range");
+    const int64_t n = n_lists * n_bounds;
+    hipLaunchKernelGGL(outlier_chunk_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)oidx, n_lists, k, step, n_bounds, (uint8_t*)out);
+    GEAR_CHECK_LAUNCH("gear_outlier_chunk_index");
+    return 0;
+}
+
+namespace {
+
+int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
                                 const void* kQ, const void* koidx, const void* koval, const void* vcode,
                                 const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
                                 const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T,
                                 int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
                                 int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, const void* dyn_state,
-                                float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream) {
+                                float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream,
+                     const void* kochunk, const void* vochunk) {
     GEAR_CHECK_ARG(wcap >= W, "gear_attn_decode: window pitch %d smaller than the window %d", wcap, W);
     GEAR_CHECK_ARG(seglen == 0 || (seglen % 64 == 0 && seg0 % 64 == 0 && seg0 >= 0),
                    "gear_attn_decode: factor segments must be multiples of 64 tokens (seg0=%d seglen=%d)", seg0, seglen);
@@ -833,6 +926,11 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
     a.qscale = qscale;
     a.seg0 = seg0; a.seglen = seglen;
     a.dyn = (const int*)dyn_state;
+    // chunk index of the outlier lists: only with 128-token bounds (K) / one bound per KV head (V), the small kernel's chunks
+    a.kochunk = a.kk ? (const uint8_t*)kochunk : nullptr;
+    a.vochunk = a.kv ? (const uint8_t*)vochunk : nullptr;
+    a.nbk = (T + SC - 1) / SC + 1;
+    a.nbv = Hkv + 1;
     a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
     a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
     bool small;
@@ -861,6 +959,33 @@ extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void
                        (const uint16_t*)vwin, W, wcap, (uint16_t*)out, (float*)lse);
     GEAR_CHECK_LAUNCH("gear_attn_decode(reduce)");
     return 0;
+}
+
+}  // namespace
+
+extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                                const void* kQ, const void* koidx, const void* koval, const void* vcode,
+                                const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
+                                const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T,
+                                int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
+                                int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, const void* dyn_state,
+                                float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream) {
+    return attn_decode_impl(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin, vwin,
+                            B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv, kk, kv, seg0, seglen,
+                            wcap, dyn_state, qscale, out, lse, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int gear_attn_decode_idx(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                                    const void* kQ, const void* koidx, const void* koval, const void* kochunk,
+                                    const void* vcode, const void* vscale, const void* vmn, const void* vP, const void* vQ,
+                                    const void* voidx, const void* voval, const void* vochunk, const void* kwin,
+                                    const void* vwin, int B, int Hq, int Hkv, int D, int T, int W, int ldk, int lsk,
+                                    int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv, int kk,
+                                    int kv, float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    return attn_decode_impl(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin, vwin,
+                            B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv, kk, kv, 0, 0, W,
+                            nullptr, qscale, out, lse, workspace, workspace_bytes, stream, kochunk, vochunk);
 }
 
 extern "C" int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,

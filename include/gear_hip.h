@@ -202,6 +202,21 @@ int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, c
                          int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv, int kk, int kv,
                          int seg0, int seglen, int wcap, const void* dyn_state, float qscale, void* out, void* lse,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Chunk index of sorted outlier lists (the build's own addition to the sparse payload; the reference's fused path stores no
+ * outliers at all, modeling_llamagear.py cache slots 11-12 / 15-16 are None).  oidx: uint16 [n_lists][k], every list
+ * ascending; out: uint8 [n_lists][n_bounds], out[l][b] = first position of list l whose index is >= b * step.
+ *   K payload: lists = (b, h, d, side), step 128 (tokens), n_bounds = ceil(T / 128) + 1
+ *   V payload: lists = (b, t, side),    step 128 (columns = one KV head), n_bounds = Hkv + 1
+ * gear_attn_decode_idx = gear_attn_decode with the two index tables (either may be NULL): a 128-token chunk then finds its
+ * outliers with two byte loads per list instead of a binary search (contexts <= 8192 tokens; ignored otherwise). */
+int gear_outlier_chunk_index(const void* oidx, int64_t n_lists, int k, int step, int n_bounds, void* out, void* stream);
+int gear_attn_decode_idx(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP, const void* kQ,
+                         const void* koidx, const void* koval, const void* kochunk, const void* vcode, const void* vscale,
+                         const void* vmn, const void* vP, const void* vQ, const void* voidx, const void* voval,
+                         const void* vochunk, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T, int W,
+                         int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv,
+                         int kk, int kv, float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes,
+                         void* stream);
 int gear_rope_append_dyn(const void* qkv, int B, int Hq, int Hkv, int D, const void* dyn_state, float theta, void* q_out,
                          void* kwin, void* vwin, int W, void* stream);
 int gear_decode_state_advance(void* state, void* stream);

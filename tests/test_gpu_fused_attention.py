@@ -112,3 +112,21 @@ def test_window_only_and_matches_module_semantics():
     out = decode_attention(q, None, None, kw, vw)
     ref = ref_attention(host(q), np.zeros((2, 2, 0, 128)), np.zeros((2, 2, 0, 128)), host(kw), host(vw), 2)
     assert rel_fro(host(out).astype(np.float64), ref) < 2e-3
+
+
+def test_outlier_chunk_index_matches_searchsorted():
+    """gear_outlier_chunk_index (through Payload.chunk_index) == numpy searchsorted on every sorted outlier list."""
+    from gear_amd import compress as C
+    torch.manual_seed(63)
+    B, H, T, D, k = 1, 4, 512, 128, 6
+    x = torch.randn(B, H, T, D).half().cuda()
+    pk = C.compress_key(x, 2, 64, k_out=k)
+    pv = C.compress_value(x, 2, 64, k_out=k)
+    for p, nb in ((pk, T // 128 + 1), (pv, H + 1)):
+        idx = host(p.oidx).astype(np.int64).reshape(-1, k) & 0xFFFF
+        tab = host(p.chunk_index())
+        assert tab.shape == (idx.shape[0], nb) and tab.dtype == np.uint8
+        bounds = np.arange(nb) * 128
+        ref = np.stack([np.searchsorted(row, bounds, side="left") for row in idx])
+        assert np.array_equal(tab, ref)
+    assert p.chunk_index() is p.chunk_index()          # cached
