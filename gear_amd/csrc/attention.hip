@@ -483,31 +483,42 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     const float qv = h2f_bits(a.q[bhq * AD + dq]) * a.qscale;
     const int lw = tid & (NWC - 1), dsub = tid / NWC;
     const bool kval = lw * CPW < tn;
+    // Addresses = uniform 64-bit base (head / chunk, scalar registers) + a 32-bit lane offset; lanes past the end of a partial
+    // last chunk load a valid clamped address and get scale = mn = 0 instead of branching around each load.
     uint32_t kw[KIT];
     float ksc[KIT], kmv[KIT];
     {
-        const int gk = (t0 + lw * CPW) / a.group;
+        const uint32_t* kc_b = a.kcode + bhk * AD * (int64_t)a.ldk + t0 / CPW;
+        const ST* ks_b = kscale + bhk * AD * (int64_t)a.lsk;
+        const ST* km_b = kmn + bhk * AD * (int64_t)a.lsk;
+        const uint32_t lwc = kval ? (uint32_t)lw : 0u;
+        const uint32_t gk = (uint32_t)(t0 + (int)lwc * CPW) / (uint32_t)a.group;
 #pragma unroll
         for (int i = 0; i < KIT; i++) {
-            const int64_t ch = bhk * AD + dsub + NDS * i;
-            kw[i] = kval ? a.kcode[ch * a.ldk + t0 / CPW + lw] : 0u;
-            ksc[i] = kval ? ld_st<ST>(kscale + ch * a.lsk + gk) : 0.0f;
-            kmv[i] = kval ? ld_st<ST>(kmn + ch * a.lsk + gk) : 0.0f;
+            const uint32_t ch = (uint32_t)(dsub + NDS * i);
+            kw[i] = kc_b[ch * (uint32_t)a.ldk + lwc];
+            const float sc = ld_st<ST>(ks_b + ch * (uint32_t)a.lsk + gk), mv = ld_st<ST>(km_b + ch * (uint32_t)a.lsk + gk);
+            ksc[i] = kval ? sc : 0.0f;
+            kmv[i] = kval ? mv : 0.0f;
         }
     }
     const int wv = tid & (NWV - 1), rsub = tid / NWV;
     uint32_t vw[VIT];
     float vsc[VIT], vmv[VIT];
     {
-        const int gv = (wv * CPW) / a.group, ngv = AD / a.group;
+        const uint32_t gv = (uint32_t)(wv * CPW) / (uint32_t)a.group, ngv = (uint32_t)(AD / a.group);
+        const uint32_t* vc_b = a.vcode + (bhk * a.tcap_v + t0) * (int64_t)NWV;
+        const ST* vs_b = vscale + (bhk * a.tcap_v + t0) * (int64_t)ngv;
+        const ST* vm_b = vmn + (bhk * a.tcap_v + t0) * (int64_t)ngv;
 #pragma unroll
         for (int i = 0; i < VIT; i++) {
             const int t = rsub + NRS * i;
-            const int64_t row = bhk * a.tcap_v + t0 + t;
             const bool ok = t < tn;
-            vw[i] = ok ? a.vcode[row * NWV + wv] : 0u;
-            vsc[i] = ok ? ld_st<ST>(vscale + row * ngv + gv) : 0.0f;
-            vmv[i] = ok ? ld_st<ST>(vmn + row * ngv + gv) : 0.0f;
+            const uint32_t tc = ok ? (uint32_t)t : 0u;
+            vw[i] = vc_b[tc * NWV + wv];
+            const float sc = ld_st<ST>(vs_b + tc * ngv + gv), mv = ld_st<ST>(vm_b + tc * ngv + gv);
+            vsc[i] = ok ? sc : 0.0f;
+            vmv[i] = ok ? mv : 0.0f;
         }
     }
     uint4 kq8 = {0, 0, 0, 0}, vq8 = {0, 0, 0, 0}, kp8 = {0, 0, 0, 0}, vp8 = {0, 0, 0, 0};
