@@ -478,8 +478,9 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
 
     // ------------------------------------------------------------------ every load of the chunk
     const int dq = tid & (AD - 1), slab = tid >> 7;   // factor rows: one (slab, channel) per thread
-    const int tslab = min(t0 + 64 * slab, t0 + tn - 1);
-    const int seg = (a.seglen == 0 || tslab < a.seg0) ? 0 : 1 + (tslab - a.seg0) / a.seglen;
+    // factor segment of each 64-token slab: block-uniform (scalar) arithmetic, then a select by slab
+    auto seg_at = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
+    const int seg_s0 = seg_at(t0), seg_s1 = seg_at(min(t0 + 64, t0 + tn - 1));
     const float qv = h2f_bits(a.q[bhq * AD + dq]) * a.qscale;
     const int lw = tid & (NWC - 1), dsub = tid / NWC;
     const bool kval = lw * CPW < tn;
@@ -524,21 +525,23 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     uint4 kq8 = {0, 0, 0, 0}, vq8 = {0, 0, 0, 0}, kp8 = {0, 0, 0, 0}, vp8 = {0, 0, 0, 0};
     uint4 kq8b = {0, 0, 0, 0}, vq8b = {0, 0, 0, 0}, kp8b = {0, 0, 0, 0}, vp8b = {0, 0, 0, 0};   // columns 8..15 (rank 16)
     if (a.rk) {
-        const uint4* pp = (const uint4*)(a.kP + (int64_t)seg * a.kP_seg_stride + (bhk * AD + dq) * RW);
+        const uint16_t* kp_b = a.kP + (slab ? (int64_t)seg_s1 : (int64_t)seg_s0) * a.kP_seg_stride + bhk * AD * RW;
+        const uint4* pp = (const uint4*)(kp_b + (uint32_t)dq * RW);
         kp8 = pp[0];
         if (R16) kp8b = pp[1];
         if (tid < tn) {
-            const uint4* qp = (const uint4*)(a.kQ + (bhk * a.tf_k + t0 + tid) * RW);
+            const uint4* qp = (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RW + (uint32_t)tid * RW);
             kq8 = qp[0];
             if (R16) kq8b = qp[1];
         }
     }
     if (a.rv) {
-        const uint4* pp = (const uint4*)(a.vP + (int64_t)seg * a.vP_seg_stride + (bhk * AD + dq) * RW);
+        const uint16_t* vp_b = a.vP + (slab ? (int64_t)seg_s1 : (int64_t)seg_s0) * a.vP_seg_stride + bhk * AD * RW;
+        const uint4* pp = (const uint4*)(vp_b + (uint32_t)dq * RW);
         vp8 = pp[0];
         if (R16) vp8b = pp[1];
         if (tid < tn) {
-            const uint4* qp = (const uint4*)(a.vQ + (bhk * a.tf_v + t0 + tid) * RW);
+            const uint4* qp = (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RW + (uint32_t)tid * RW);
             vq8 = qp[0];
             if (R16) vq8b = qp[1];
         }
