@@ -67,7 +67,7 @@ struct GemvArgs {
     uint16_t *q_out, *kwin, *vwin;
 };
 
-template <int NB, int SK, bool NORM, int EPI>
+template <int NB, int SK, int NORM, int EPI>
 __global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_kernel(GemvArgs a) {
     constexpr int WPB = EPI == EPI_ROPE ? 4 * SK : 4;   // waves per block (RoPE blocks always hold 4 rows)
     constexpr int RPB = WPB / SK;                       // rows per block
@@ -92,17 +92,21 @@ __global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_ker
     const uint4* dv = (const uint4*)a.delta;
     const uint4* nv = (const uint4*)a.nw;
     uint4* rv = (uint4*)a.res_out;
-    const bool writer = NORM && a.res_out && blockIdx.x == 0 && rsub == 0;   // this row's K parts cover every chunk once
+    // NORM 1: the residual stream as it is (norm weight folded into W) -- a loop without run-time branches, so that it
+    // unrolls with four weight loads in flight like the plain GEMV; NORM 2: optional addend / norm weight / residual write
+    const bool writer = NORM == 2 && a.res_out && blockIdx.x == 0 && rsub == 0;   // this row's K parts cover every chunk once
 #pragma unroll 4
     for (int c = lane + 64 * kp; c < nchunk; c += 64 * SK) {
         const uint4 w = Wv[c];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             uint4 xa = xv[(int64_t)b * nchunk + c];
-            if (NORM) {
+            if (NORM == 2) {
                 if (a.delta) xa = hadd8(xa, dv[(int64_t)b * nchunk + c]);
                 if (writer) rv[(int64_t)b * nchunk + c] = xa;
-                ss[b] = dot8(xa, xa, ss[b]);
+            }
+            if (NORM) ss[b] = dot8(xa, xa, ss[b]);
+            if (NORM == 2) {
                 if (a.nw) xa = hmul8(xa, nv[c]);
             }
             acc[b] = dot8(w, xa, acc[b]);
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_ker
     }
 }
 
-template <int SK, bool NORM, int EPI>
+template <int SK, int NORM, int EPI>
 void launch_nb(int B, unsigned blocks, hipStream_t st, const GemvArgs& a) {
     dim3 grid(blocks), block(EPI == EPI_ROPE ? 256 * SK : 256);
     if (B == 1) hipLaunchKernelGGL((gemv_tok_kernel<1, SK, NORM, EPI>), grid, block, 0, st, a);
@@ -190,7 +194,7 @@ int pick_sk(int K, int N, int max_sk) {
     return sk > max_sk ? max_sk : sk;
 }
 
-template <bool NORM, int EPI>
+template <int NORM, int EPI>
 void launch_sk(int sk, int B, int N, hipStream_t st, const GemvArgs& a) {
     if constexpr (EPI != EPI_SWIGLU) {
         if (sk == 4) return launch_nb<4, NORM, EPI>(B, (unsigned)N, st, a);
@@ -209,7 +213,7 @@ extern "C" int gear_gemv_f16_add(const void* x, const void* W, int B, int K, int
     GemvArgs a = {};
     a.x = (const uint16_t*)x; a.W = (const uint16_t*)W; a.y = (uint16_t*)y; a.K = K; a.N = N;
     a.res_in = (const uint16_t*)res_in;
-    launch_sk<false, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
+    launch_sk<0, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
     GEAR_CHECK_LAUNCH("gear_gemv_f16");
     return 0;
 }
@@ -230,8 +234,14 @@ extern "C" int gear_gemv_f16_norm(const void* x, const void* delta, const void* 
     a.x = (const uint16_t*)x; a.delta = (const uint16_t*)delta; a.nw = (const uint16_t*)norm_w;
     a.res_out = delta ? (uint16_t*)res_out : nullptr;
     a.eps = eps; a.W = (const uint16_t*)W; a.y = (uint16_t*)y; a.K = K; a.N = N;
-    if (swiglu) launch_sk<true, EPI_SWIGLU>(pick_sk(K, N, 2), B, N, (hipStream_t)stream, a);
-    else launch_sk<true, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
+    const bool folded = !delta && !norm_w;
+    if (swiglu) {
+        if (folded) launch_sk<1, EPI_SWIGLU>(pick_sk(K, N, 2), B, N, (hipStream_t)stream, a);
+        else launch_sk<2, EPI_SWIGLU>(pick_sk(K, N, 2), B, N, (hipStream_t)stream, a);
+    } else {
+        if (folded) launch_sk<1, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
+        else launch_sk<2, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
+    }
     GEAR_CHECK_LAUNCH("gear_gemv_f16_norm");
     return 0;
 }
@@ -252,8 +262,15 @@ extern "C" int gear_gemv_qkv_rope(const void* x, const void* delta, const void* 
     a.eps = eps; a.W = (const uint16_t*)Wqkv; a.K = K; a.N = (Hq + 2 * Hkv) * 128;
     a.Hq = Hq; a.Hkv = Hkv; a.pos = pos; a.slot = slot; a.wcap = wcap; a.log2_theta = log2f(theta);
     a.dyn = (const int*)dyn_state; a.q_out = (uint16_t*)q_out; a.kwin = (uint16_t*)kwin; a.vwin = (uint16_t*)vwin;
-    if (pick_sk(K, a.N, 2) == 2) launch_nb<2, true, EPI_ROPE>(B, (unsigned)((Hq + 2 * Hkv) * 32), (hipStream_t)stream, a);
-    else launch_nb<1, true, EPI_ROPE>(B, (unsigned)((Hq + 2 * Hkv) * 32), (hipStream_t)stream, a);
+    const unsigned blocks = (unsigned)((Hq + 2 * Hkv) * 32);
+    const bool folded = !delta && !norm_w;
+    if (pick_sk(K, a.N, 2) == 2) {
+        if (folded) launch_nb<2, 1, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
+        else launch_nb<2, 2, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
+    } else {
+        if (folded) launch_nb<1, 1, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
+        else launch_nb<1, 2, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
+    }
     GEAR_CHECK_LAUNCH("gear_gemv_qkv_rope");
     return 0;
 }
