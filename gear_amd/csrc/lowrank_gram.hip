@@ -337,16 +337,34 @@ __global__ __launch_bounds__(256) void lr_qpass_kt_kernel(const uint16_t* __rest
     for (int j = 0; j < 8; j++)
 #pragma unroll
         for (int c = 0; c < RP; c++) acc[j][c] = 0.0f;
-#pragma unroll 8
-    for (int d = 0; d < GD; d++) {
-        float m[8];
-        unpack8(*(const uint4*)(p + (int64_t)d * S), m);
+    // two register sets of 4 channel rows: the loads of the next 4 rows are in flight while the current 4 are consumed (a
+    // plain unrolled loop waited for all of its loads before the first FMA)
+    uint4 ra[4], rb[4];
 #pragma unroll
-        for (int c = 0; c < RP; c++) {
-            float w = Ws[d * RP + c];
+    for (int i = 0; i < 4; i++) ra[i] = *(const uint4*)(p + (int64_t)i * S);
+    auto consume = [&](const uint4 (&rr)[4], int d0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) acc[j][c] = fmaf(m[j], w, acc[j][c]);
+        for (int i = 0; i < 4; i++) {
+            float m[8];
+            unpack8(rr[i], m);
+#pragma unroll
+            for (int c = 0; c < RP; c++) {
+                const float w = Ws[(d0 + i) * RP + c];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j][c] = fmaf(m[j], w, acc[j][c]);
+            }
         }
+    };
+#pragma unroll 1
+    for (int d = 0; d < GD; d += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[i] = *(const uint4*)(p + (int64_t)(d + 4 + i) * S);
+        consume(ra, d);
+        if (d + 8 < GD) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) ra[i] = *(const uint4*)(p + (int64_t)(d + 8 + i) * S);
+        }
+        consume(rb, d + 4);
     }
     if (out_f16 && r == RP && t0 + 8 <= S) {   // 8 tokens x RP halfs = one contiguous run per lane
         uint16_t* qo = (uint16_t*)Q_out + (bh * S + t0) * (int64_t)RP;
