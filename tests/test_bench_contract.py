@@ -1,0 +1,34 @@
+"""The bench.py output contract, checked on the bench line committed with the profiles (no GPU needed): the fields the
+driver reads, the roofline and cpu_baseline objects, and internal consistency of the numbers."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r1_final_bench_line.json")))
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["unit"] == "GB/s" and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["alg_bytes_per_launch"]   # HBM bytes >= ~algorithmic bytes
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    # value = fp16 KV bytes through compress + decompress per second, whole job
+    n = 32 * 32 * 4096 * 128
+    assert abs(d["value"] - 2 * (2 * n * 2) / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+
+
+def test_bench_parses_and_defaults_to_one_gpu():
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ast.parse(src)
+    assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
