@@ -233,12 +233,14 @@ def main():
             sk, sv = pool[2 * i], pool[2 * i + 1]
             sk.wait_stream(cur)
             sv.wait_stream(cur)
-            with torch.cuda.stream(sk):
-                pk = C.compress_key(K[l0:l1], bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k[l0:l1])
-                kr = C.decompress(pk, transposed_out=True)
+            # (the V chain is enqueued first: it starts with the VALU-bound row compressor, which then overlaps the K chain's
+            # HBM-bound re-layout; measured 1250 vs 1205 GB/s the other way round)
             with torch.cuda.stream(sv):
                 pv = C.compress_value(V[l0:l1], bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v[l0:l1])
                 vr = C.decompress(pv)
+            with torch.cuda.stream(sk):
+                pk = C.compress_key(K[l0:l1], bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k[l0:l1])
+                kr = C.decompress(pk, transposed_out=True)
             outs.append((pk, pv, kr, vr))
         for st in pool:
             cur.wait_stream(st)
