@@ -22,6 +22,10 @@ _vp, _i64, _i, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 SIGNATURES = {
     "gear_last_error": (C.c_char_p, []),
     "gear_abi_version": (_i, []),
+    "gear_set_option": (_i, [C.c_char_p, _i]),
+    "gear_compress_key_fused_workspace": (_sz, [_i64, _i, _i, _i]),
+    "gear_compress_key_fused": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _i64,
+                                     _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "gear_quant_pack_lastdim": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_quant_pack_k": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_unpack_dequant_lastdim": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
@@ -90,8 +94,18 @@ def check(rc: int, what: str):
         raise GearError(f"{what}: status {rc}: {msg.decode() if msg else ''}")
 
 
-def stream_ptr() -> int:
+def stream_ptr(t=None) -> int:
+    """hipStream_t of the current stream of `t`'s device (the current device when t is None).  The library never calls
+    hipSetDevice: launches go to the stream that is passed, so the stream must belong to the device that holds the
+    tensors -- require_gpu() checks that all tensors of a call share one device."""
+    if t is not None:
+        return torch.cuda.current_stream(t.device).cuda_stream
     return torch.cuda.current_stream().cuda_stream
+
+
+def set_option(name: str, value: int):
+    """gear_set_option(): select an alternative (equally exact) code path -- used by the tests."""
+    check(load().gear_set_option(name.encode(), int(value)), "gear_set_option")
 
 
 def ptr(t):
@@ -99,6 +113,7 @@ def ptr(t):
 
 
 def require_gpu(*tensors):
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -106,3 +121,10 @@ def require_gpu(*tensors):
             raise GearError("gear_amd operators run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
         if not t.is_contiguous():
             raise GearError("gear_amd operators need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GearError(f"gear_amd operators need all tensors on one device (got {dev} and {t.device})")
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        raise GearError(f"tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
+                        "torch.cuda.device(tensor.device) (kernels are enqueued on the current device's stream)")

@@ -190,6 +190,64 @@ def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank:
     return Payload("v", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
 
 
+def key_fused_supported(T: int, D: int, group: int, bits: int, k_out: int) -> bool:
+    """Shapes the fused token-major K path (gear_compress_key_fused) covers; everything else takes the row compressor."""
+    return D == 128 and T % 64 == 0 and 64 <= T <= 16384 and group in (32, 64) and bits in (2, 4) and 2 * k_out <= T
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, dev) -> torch.Tensor:
+    """One grow-only scratch buffer per device and stream for the fused compress calls (the work in it is stream-ordered)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _ws_cache[key] = None
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = ws
+    return ws
+
+
+def compress_key_fused(k: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3, mode="fp32",
+                       P0: Optional[torch.Tensor] = None, variant: int = 0) -> Payload:
+    """K [B,H,T,128] fp16 token-major -> Payload through the fused path (csrc/kfused.hip): select -> fused quantize + pack +
+    error + Gram -> per-head solve -> Q pass.  No K^T, no transpose kernel."""
+    assert k.dim() == 4 and k.dtype == torch.float16
+    k = k.contiguous()
+    L.require_gpu(k)
+    B, H, T, D = k.shape
+    if not key_fused_supported(T, D, group, bits, k_out):
+        raise L.GearError(f"compress_key_fused: unsupported shape T={T} D={D} group={group} bits={bits} k={k_out}")
+    m = _MODES[mode]
+    dev = k.device
+    fpi = 32 // bits
+    sdt = torch.float16 if m == 0 else torch.float32
+    code = torch.empty((B, H, D, T // fpi), dtype=torch.int32, device=dev)
+    scale = torch.empty((B, H, D, T // group), dtype=sdt, device=dev)
+    mn = torch.empty_like(scale)
+    oidx = torch.empty((B, H, D, 2 * k_out), dtype=torch.int16, device=dev) if k_out > 0 else None
+    oval = torch.empty((B, H, D, 2 * k_out), dtype=torch.float16, device=dev) if k_out > 0 else None
+    P = Q = None
+    if rank > 0:
+        if P0 is None:
+            P0 = draw_p0(B, H, T, D, rank, dev)
+        P0 = P0.to(device=dev, dtype=torch.float32).contiguous()
+        assert tuple(P0.shape) == (B, H, D, rank)
+        P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
+        Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
+    lib = L.load()
+    wsb = lib.gear_compress_key_fused_workspace(B * H, T, k_out, rank)
+    ws = _workspace(wsb, dev)
+    rc = lib.gear_compress_key_fused(L.ptr(k), B * H, T, group, bits, m, k_out, L.ptr(code), L.ptr(scale), L.ptr(mn),
+                                     T // fpi, T // group, 0, rank, loop, L.ptr(P0) if rank > 0 else None, L.ptr(P), B * H, 0,
+                                     L.ptr(Q), T, 0, L.ptr(oidx), L.ptr(oval), k_out, 0, variant, L.ptr(ws), ws.numel(),
+                                     L.stream_ptr(k))
+    L.check(rc, "gear_compress_key_fused")
+    return Payload("k", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
+
+
 def _compress_key_impl(src: torch.Tensor, src_is_transposed: bool, bits, group, k_out, rank, loop, mode, P0) -> Payload:
     assert src.dim() == 4 and src.dtype == torch.float16
     src = src.contiguous()
@@ -253,9 +311,14 @@ def transpose_last2(x: torch.Tensor) -> torch.Tensor:
 
 
 def compress_key(k: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
-                 mode="fp32", P0: Optional[torch.Tensor] = None) -> Payload:
-    """K [B,H,T,D] fp16 (token-major) -> Payload.  The K^T re-layout (HIP transpose kernel) runs chunk by chunk into a
-    reused buffer right before the chunk is compressed, so K^T never makes a round trip through HBM."""
+                 mode="fp32", P0: Optional[torch.Tensor] = None, path: str = "auto") -> Payload:
+    """K [B,H,T,D] fp16 (token-major) -> Payload.  path "auto": the fused token-major path (compress_key_fused) when the
+    shape allows it (head_dim 128, T % 64 == 0, group 32 / 64), otherwise -- or with path "rows" -- the round-1 chain
+    K^T re-layout -> row compressor -> Gram -> Q pass; "fused" insists on the fused path."""
+    assert path in ("auto", "rows", "fused")
+    B, H, T, D = k.shape
+    if path == "fused" or (path == "auto" and key_fused_supported(T, D, group, bits, k_out)):
+        return compress_key_fused(k, bits, group, k_out, rank, loop, mode, P0)
     return _compress_key_impl(k, False, bits, group, k_out, rank, loop, mode, P0)
 
 

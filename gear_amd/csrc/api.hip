@@ -1,5 +1,7 @@
 // api.hip -- error plumbing and library identification for libgear_hip.so
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -13,4 +15,35 @@ void gear_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gear_last_error(void) { return g_err; }
-extern "C" int gear_abi_version(void) { return 1; }
+extern "C" int gear_abi_version(void) { return 2; }
+
+// ---- run-time options ------------------------------------------------------------------------------------------
+// A handful of switches select an alternative (always exact) code path; the tests use them to cover the paths a normal
+// input does not reach.  They are read from the environment ONCE, when the library is first used, and can be set through
+// gear_set_option(); the launch paths read the cached table (no getenv() per call).
+GearOptions& gear_options() {
+    static GearOptions o = [] {
+        GearOptions v{};
+        auto flag = [](const char* n) { const char* e = getenv(n); return e && *e && *e != '0'; };
+        v.attn_generic = flag("GEAR_ATTN_GENERIC");
+        v.lowrank_generic = flag("GEAR_LOWRANK_GENERIC");
+        v.rows_hist_only = flag("GEAR_ROWS_HIST_ONLY");
+        v.rows_v1 = flag("GEAR_ROWS_V1");
+        v.kfused_generic = flag("GEAR_KFUSED_GENERIC");
+        v.kselect_slow = flag("GEAR_KSELECT_SLOW");
+        return v;
+    }();
+    return o;
+}
+
+extern "C" int gear_set_option(const char* name, int value) {
+    GearOptions& o = gear_options();
+    const struct { const char* n; int* p; } tab[] = {
+        {"attn_generic", &o.attn_generic},     {"lowrank_generic", &o.lowrank_generic}, {"rows_hist_only", &o.rows_hist_only},
+        {"rows_v1", &o.rows_v1},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
+    };
+    for (const auto& t : tab)
+        if (name && !strcmp(name, t.n)) { *t.p = value; return 0; }
+    gear_set_error("gear_set_option: unknown option '%s'", name ? name : "(null)");
+    return -1;
+}

@@ -852,7 +852,7 @@ int plan_splits(int T, int bits, int64_t bhq, bool fast_ranks, int* tc_out, bool
     *small = false;
     if (T <= 0) { *tc_out = 64; return 1; }
     // contexts up to 8k (ranks 0 / 8): 128-token chunks (<= 64 splits for the reduce kernel) -> attn_decode_partial_small
-    if (T <= 64 * SC && fast_ranks && !getenv("GEAR_ATTN_GENERIC")) { *tc_out = SC; *small = true; return (T + SC - 1) / SC; }
+    if (T <= 64 * SC && fast_ranks && !gear_options().attn_generic) { *tc_out = SC; *small = true; return (T + SC - 1) / SC; }
     // enough workgroups to cover the chip a few times over, chunks a multiple of 64 tokens
     int splits = 1;
     while (splits < 64 && (int64_t)splits * bhq < 1024 && T / (splits * 2) >= 128) splits *= 2;

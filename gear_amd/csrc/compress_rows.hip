@@ -7,13 +7,12 @@
 //                               [B,H,D,T] that the attention hook passes, modeling_llamagear.py:268)
 // Quantization groups are `group` consecutive elements inside a segment.  One workgroup owns one row, each lane 16
 // consecutive elements in registers; ties are broken by LOWER INDEX FIRST (the oracle's rule); the survivors are quantized
-// exactly like quant_pack.hip.  Three kernels live here:
+// exactly like quant_pack.hip.  Two kernels live here:
 //   compress_rows_fp32_kernel  fp32 arithmetic (mode 1, the simulated path): Gaussian-threshold candidates compacted in
 //                              index order + 17-step key bisection (two-level radix select as the exact fallback), dense
 //                              part on packed fp16 / packed fp32 -- the kernel the bench and the roofline are about
 //   compress_rows_kernel       first generation: fp16-stepwise arithmetic (mode 0, the fused path's block compress) and,
-//                              under GEAR_ROWS_V1, the fp32 mode for A/B runs
-//   compress_rows_wave_kernel  one wave per row (GEAR_ROWS_WAVE_KERNEL): an experiment that measured slower
+//                              with the option rows_v1, the fp32 mode as a cross-check
 //
 // Outputs per row: packed codes, scale, mn, optional error (0 at outlier positions), and the sparse part
 // (column index within the row as uint16 + original fp16 value, sorted by index; first k = smallest side).
@@ -943,290 +942,8 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     }
 }
 
-
-// =====================================================================================================
-// Wave-per-row variant (the fast path): ONE wave owns the whole row.  Lane l holds CPL chunks of 16 consecutive
-// elements (chunk c = elements [1024 c + 16 l, +16)), so global accesses stay fully coalesced, every reduction is a
-// DPP / shuffle butterfly, and there is no workgroup barrier on the critical path (the block IS the wave): far more
-// rows are in flight per CU than with the 4-wave workgroup kernel, whose chain of barriers made it latency-bound.
-// Selection: tau_hi = k-th largest of the 64 per-lane maxima (one bitonic sort in registers) -- at least k elements
-// are >= tau_hi; the few elements passing the threshold are ranked exactly in LDS ((value desc, index asc) for the
-// large side, (value asc, index asc) for the small side) and written out sorted by index.
-// =====================================================================================================
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    return x;
-}
-__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t x, uint32_t* total) {
-    const int lane = threadIdx.x & 63;
-    uint32_t inc = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    *total = __shfl(inc, 63, 64);
-    return inc - x;
-}
-
-// Exact selection without the survivor buffer (rows where more than CAND_CAP elements tie with / exceed the
-// threshold, e.g. constant rows): bisection on the 16-bit key for the k-th largest (LARGE) / smallest value, then
-// ties in index order.  Returns per-chunk 16-bit flags and writes the (index-sorted) payload.  Slow, rare, exact.
-template <int CPL, bool LARGE>
-__device__ __forceinline__ void select_bisect(const float (&v)[CPL][16], const bool (&act)[CPL], int k, uint32_t* flags,
-                                               uint16_t* oi, uint16_t* ov) {
-    const int lane = threadIdx.x & 63;
-    auto count = [&](uint32_t thr, bool strict) {
-        uint32_t n = 0;
-#pragma unroll
-        for (int c = 0; c < CPL; c++)
-            if (act[c]) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    uint32_t key = sort_key(f2h_bits(v[c][j]));
-                    bool hit = LARGE ? (strict ? key > thr : key >= thr) : (strict ? key < thr : key <= thr);
-                    n += hit ? 1u : 0u;
-                }
-            }
-        return wave_sum_u32(n);
-    };
-    uint32_t lo_b = 0u, hi_b = 0xFFFFu;
-    for (int it = 0; it < 16; it++) {
-        if (LARGE) {   // largest thr with count(key >= thr) >= k
-            uint32_t mid = (lo_b + hi_b + 1u) >> 1;
-            if (count(mid, false) >= (uint32_t)k) lo_b = mid; else hi_b = mid - 1u;
-        } else {       // smallest thr with count(key <= thr) >= k
-            uint32_t mid = (lo_b + hi_b) >> 1;
-            if (count(mid, false) >= (uint32_t)k) hi_b = mid; else lo_b = mid + 1u;
-        }
-    }
-    const uint32_t thr = LARGE ? lo_b : hi_b;
-    const int take = k - (int)count(thr, true);
-    uint32_t eq_base = 0u, slot_base = 0u;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        uint32_t key[16], neq = 0u;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            key[j] = sort_key(f2h_bits(v[c][j]));
-            neq += (act[c] && key[j] == thr) ? 1u : 0u;
-        }
-        uint32_t tot_eq;
-        int rank = (int)(eq_base + wave_excl_scan_u32(neq, &tot_eq));
-        eq_base += tot_eq;
-        uint32_t f = 0u;
-        if (act[c]) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                bool beyond = LARGE ? key[j] > thr : key[j] < thr;
-                if (beyond) f |= 1u << j;
-                else if (key[j] == thr) { if (rank < take) f |= 1u << j; rank++; }
-            }
-        }
-        flags[c] = f;
-        uint32_t tot_f;
-        int slot = (int)(slot_base + wave_excl_scan_u32((uint32_t)__popc(f), &tot_f));
-        slot_base += tot_f;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (f & (1u << j)) {
-                if (slot < k) { oi[slot] = (uint16_t)(c * 1024 + lane * 16 + j); ov[slot] = f2h_bits(v[c][j]); }
-                slot++;
-            }
-    }
-}
-
-template <int BITS, int MODE, typename ST, int CPL>
-__global__ __launch_bounds__(64) void compress_rows_wave_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len,
-                                                                 int group, int k, uint32_t* __restrict__ code,
-                                                                 ST* __restrict__ scale, ST* __restrict__ mn,
-                                                                 uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
-                                                                 uint16_t* __restrict__ oval, float* __restrict__ omean) {
-    constexpr int LEVELS = (1 << BITS) - 1;
-    constexpr int WPL = BITS / 2;
-    constexpr int CPW = 32 / BITS;
-    __shared__ uint32_t cand[2][CAND_CAP];
-    __shared__ uint32_t sel[2][CAND_CAP];
-    __shared__ uint32_t omask[2][32 * CPL];   // 1024 * CPL bits per side
-    __shared__ uint32_t ncand[2];
-
-    const int64_t r = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int64_t row_base = row_base_of(gm, r);
-    float v[CPL][16];
-    int64_t off[CPL];
-    bool act[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const int j0 = c * 1024 + lane * 16;
-        act[c] = j0 < len;
-        const int jj = act[c] ? j0 : 0;
-        int sg, ps;
-        seg_pos(gm, jj, sg, ps);
-        off[c] = row_base + (int64_t)sg * gm.seg_stride + ps;
-    }
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        uint4 a = make_uint4(0, 0, 0, 0), b = a;
-        if (act[c]) {
-            const uint4* p = (const uint4*)(x + off[c]);
-            a = p[0];
-            b = p[1];
-        }
-        unpack8(a, v[c]);
-        unpack8(b, v[c] + 8);
-    }
-    uint32_t fl[CPL];   // bits 0-15: large-side outlier flags of chunk c, bits 16-31: small side
-#pragma unroll
-    for (int c = 0; c < CPL; c++) fl[c] = 0u;
-
-    if (k > 0) {
-        float s = 0.0f, lmax = -INFINITY, lmin = INFINITY;
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            if (act[c]) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    s += v[c][j];
-                    lmax = fmaxf(lmax, v[c][j]);
-                    lmin = fminf(lmin, v[c][j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        const float mean = s / (float)len;
-        const uint32_t kmax = act[0] ? sort_key(f2h_bits(lmax)) : 0u;
-        const uint32_t kmin = act[0] ? sort_key(f2h_bits(lmin)) : 0xFFFFu;
-        const uint32_t smax = wave_bitonic_sort<true>(kmax);
-        const uint32_t smin = wave_bitonic_sort<false>(kmin);
-        const uint32_t tau_hi = __shfl(smax, k - 1, 64), tau_lo = __shfl(smin, k - 1, 64);
-        const float thi = h2f_bits((uint16_t)key_to_bits(tau_hi)), tlo = h2f_bits((uint16_t)key_to_bits(tau_lo));
-        if (lane < 2) ncand[lane] = 0u;
-        for (int i = lane; i < 2 * 32 * CPL; i += 64) (&omask[0][0])[i] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            if (act[c]) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const float vv = v[c][j];
-                    if (vv >= thi) {
-                        uint32_t sl = atomicAdd(&ncand[0], 1u);
-                        if (sl < CAND_CAP) cand[0][sl] = (sort_key(f2h_bits(vv)) << 16) | (0xFFFFu - (uint32_t)(c * 1024 + lane * 16 + j));
-                    }
-                    if (vv <= tlo) {
-                        uint32_t sl = atomicAdd(&ncand[1], 1u);
-                        if (sl < CAND_CAP) cand[1][sl] = (sort_key(f2h_bits(vv)) << 16) | (uint32_t)(c * 1024 + lane * 16 + j);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t nh = min(ncand[0], (uint32_t)CAND_CAP), nl = min(ncand[1], (uint32_t)CAND_CAP);
-        const bool overflow = (ncand[0] > CAND_CAP) || (ncand[1] > CAND_CAP);
-        uint16_t* oi = oidx + r * (int64_t)(2 * k);
-        uint16_t* ov = oval + r * (int64_t)(2 * k);
-        uint32_t fhi[CPL], flo[CPL];
-        if (overflow) {
-            // more than CAND_CAP elements reach the threshold (massive duplicates): exact bisection path
-            select_bisect<CPL, true>(v, act, k, fhi, oi + k, ov + k);
-            select_bisect<CPL, false>(v, act, k, flo, oi, ov);
-        } else {
-            // pass 1: exact rank inside the survivor set
-            for (uint32_t ci = lane; ci < nh; ci += 64) {
-                const uint32_t me = cand[0][ci];
-                int rk = 0;
-                for (uint32_t o = 0; o < nh; o++) rk += (cand[0][o] > me) ? 1 : 0;
-                sel[0][ci] = (rk < k) ? 1u : 0u;
-                if (rk < k) { uint32_t idx = 0xFFFFu - (me & 0xFFFFu); atomicOr(&omask[0][idx >> 5], 1u << (idx & 31)); }
-            }
-            for (uint32_t ci = lane; ci < nl; ci += 64) {
-                const uint32_t me = cand[1][ci];
-                int rk = 0;
-                for (uint32_t o = 0; o < nl; o++) rk += (cand[1][o] < me) ? 1 : 0;
-                sel[1][ci] = (rk < k) ? 1u : 0u;
-                if (rk < k) { uint32_t idx = me & 0xFFFFu; atomicOr(&omask[1][idx >> 5], 1u << (idx & 31)); }
-            }
-            __syncthreads();
-            // pass 2: output slot = number of selected survivors with a smaller index; payload sorted by index
-            for (uint32_t ci = lane; ci < nh; ci += 64) {
-                if (!sel[0][ci]) continue;
-                const uint32_t me = cand[0][ci], idx = 0xFFFFu - (me & 0xFFFFu);
-                int sl = 0;
-                for (uint32_t o = 0; o < nh; o++) sl += (sel[0][o] && (0xFFFFu - (cand[0][o] & 0xFFFFu)) < idx) ? 1 : 0;
-                if (sl < k) { oi[k + sl] = (uint16_t)idx; ov[k + sl] = (uint16_t)key_to_bits(me >> 16); }
-            }
-            for (uint32_t ci = lane; ci < nl; ci += 64) {
-                if (!sel[1][ci]) continue;
-                const uint32_t me = cand[1][ci], idx = me & 0xFFFFu;
-                int sl = 0;
-                for (uint32_t o = 0; o < nl; o++) sl += (sel[1][o] && (cand[1][o] & 0xFFFFu) < idx) ? 1 : 0;
-                if (sl < k) { oi[sl] = (uint16_t)idx; ov[sl] = (uint16_t)key_to_bits(me >> 16); }
-            }
-        }
-        if (lane == 0 && omean) omean[r] = mean;
-        const float fill = (MODE == 0) ? hround(mean) : mean;
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int j0 = c * 1024 + lane * 16;
-            const uint32_t fh = overflow ? fhi[c] : ((omask[0][j0 >> 5] >> (j0 & 31)) & 0xFFFFu);
-            const uint32_t fw = overflow ? flo[c] : ((omask[1][j0 >> 5] >> (j0 & 31)) & 0xFFFFu);
-            fl[c] = act[c] ? (fh | (fw << 16)) : 0u;
-            const uint32_t any = (fl[c] | (fl[c] >> 16)) & 0xFFFFu;
-#pragma unroll
-            for (int j = 0; j < 16; j++)
-                if (any & (1u << j)) v[c][j] = fill;
-        }
-    }
-
-    const int lanes_per_group = group / 16;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        float lo = v[c][0], hi = v[c][0];
-#pragma unroll
-        for (int j = 1; j < 16; j++) {
-            lo = fminf(lo, v[c][j]);
-            hi = fmaxf(hi, v[c][j]);
-        }
-        for (int m = 1; m < lanes_per_group; m <<= 1) {
-            lo = fminf(lo, __shfl_xor(lo, m, 64));
-            hi = fmaxf(hi, __shfl_xor(hi, m, 64));
-        }
-        if (!act[c]) continue;
-        QuantParams<MODE> qp = make_qparams<MODE>(lo, hi, LEVELS);
-        const float inv = (qp.scale != 0.0f) ? div_rn(1.0f, qp.scale) : 0.0f;
-        uint32_t words[WPL];
-#pragma unroll
-        for (int w = 0; w < WPL; w++) words[w] = 0u;
-        float e[16];
-        const uint32_t outl = (fl[c] | (fl[c] >> 16)) & 0xFFFFu;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            int q = quant_fast<BITS, MODE>(v[c][j], qp.mn, qp.scale, inv, LEVELS);
-            words[j / CPW] |= (uint32_t)q << (BITS * (j % CPW));
-            float d = (MODE == 0) ? dequant_one<0>(q, qp.scale, qp.mn) : hround(dequant_one<1>(q, qp.scale, qp.mn));
-            e[j] = (outl & (1u << j)) ? 0.0f : (v[c][j] - d);
-        }
-        uint32_t* cp = code + off[c] / CPW;
-#pragma unroll
-        for (int w = 0; w < WPL; w++) cp[w] = words[w];
-        if ((lane & (lanes_per_group - 1)) == 0) {
-            st_st<ST>(scale + (off[c] >> gm.group_shift), qp.scale);
-            st_st<ST>(mn + (off[c] >> gm.group_shift), qp.mn);
-        }
-        if (err) {
-            uint4* ep = (uint4*)(err + off[c]);
-            ep[0] = pack8(e);
-            ep[1] = pack8(e + 8);
-        }
-    }
-}
-
 }  // namespace
 
-// inverse of the standard normal CDF (Acklam's rational approximation, |error| < 1.2e-9) -- host side only
 static double inv_norm_cdf(double p) {
     static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
                                1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
@@ -1269,36 +986,11 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     int threads = (int)((len / 16 + 63) / 64 * 64);
     // tier-0 threshold: let about 2.2 k of a normal row's elements pass on each side (at most 128 may)
     float zthr = 0.0f;
-    if (k > 0 && k <= 58 && !getenv("GEAR_ROWS_HIST_ONLY")) {
+    if (k > 0 && k <= 58 && !gear_options().rows_hist_only) {
         double frac = 2.2 * (double)k / (double)len;
         if (frac < 0.45) zthr = (float)(-inv_norm_cdf(frac));
     }
     hipStream_t st = (hipStream_t)stream;
-    if (k <= 64 && len <= 8192 && len >= 16 * (int64_t)k && getenv("GEAR_ROWS_WAVE_KERNEL")) {
-        // experimental: one wave per row (fewer instructions per element, but 3 waves/SIMD; measured slower than the
-        // workgroup kernel on MI355X -- both are VALU-issue-bound)
-        const int cpl = len <= 1024 ? 1 : (len <= 2048 ? 2 : (len <= 4096 ? 4 : 8));
-        dim3 wb(64), wg((unsigned)n_rows);
-#define GOW(B, M, STT, CP)                                                                                                \
-    hipLaunchKernelGGL((compress_rows_wave_kernel<B, M, STT, CP>), wg, wb, 0, st, (const uint16_t*)x, gm, (int)len, group, \
-                       k, (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
-                       (float*)omean)
-#define GOC(B, M, STT) do { if (cpl == 1) GOW(B, M, STT, 1); else if (cpl == 2) GOW(B, M, STT, 2); \
-                            else if (cpl == 4) GOW(B, M, STT, 4); else GOW(B, M, STT, 8); } while (0)
-        if (mode == 0) {
-            if (bits == 2) GOC(2, 0, uint16_t);
-            else if (bits == 4) GOC(4, 0, uint16_t);
-            else GOC(8, 0, uint16_t);
-        } else {
-            if (bits == 2) GOC(2, 1, float);
-            else if (bits == 4) GOC(4, 1, float);
-            else GOC(8, 1, float);
-        }
-#undef GOC
-#undef GOW
-        GEAR_CHECK_LAUNCH("gear_compress_rows(wave)");
-        return 0;
-    }
     dim3 block(threads), grid((unsigned)n_rows);
 #define GO(B, M, STT)                                                                                                  \
     hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \
@@ -1315,7 +1007,7 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
         if (bits == 2) GO(2, 0, uint16_t);
         else if (bits == 4) GO(4, 0, uint16_t);
         else GO(8, 0, uint16_t);
-    } else if (getenv("GEAR_ROWS_V1")) {   // first-generation workgroup kernel (kept for A/B runs and as a cross-check)
+    } else if (gear_options().rows_v1) {   // first-generation workgroup kernel (kept for A/B runs and as a cross-check)
         if (bits == 2) GO(2, 1, float);
         else if (bits == 4) GO(4, 1, float);
         else GO(8, 1, float);

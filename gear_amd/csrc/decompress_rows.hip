@@ -334,17 +334,14 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
-    const char* pe = getenv("GEAR_DECOMP_PATCH");
-    const int patch = pe ? atoi(pe) : 0;   // measured: 0.81 ms (patch) vs 0.72 ms (table) on the 7B / 4k V tensor
+    const int patch = 0;   // (an in-kernel global patch pass measured 0.81 ms vs 0.72 ms for the LDS table: not used)
     // rows per block, measured on the 7B / 4k tensors (V / K^T ms): factors only: 16 rows 0.48 / 0.42, 8 rows 0.51 / 0.47
     // (fewer reloads of the lane's factor block).  The LDS outlier table covers 4 rows (35 KB) and is refilled inside the
     // block: outliers + factors 0.58 / 0.54 with 16 rows per block (0.64 / 0.62 when the block itself was 4 rows, 0.70 /
     // 0.75 with an 8-row table = 70 KB = half the resident blocks)
     int rpb = patch ? 8 : (r > 0 ? 16 : 8);
-    if (const char* re = getenv("GEAR_DECOMP_RPB")) rpb = atoi(re);
     while (rpb > 1 && rows_inner % rpb != 0) rpb >>= 1;
     int trows = rpb < 4 ? rpb : 4;            // rows per fill of the LDS outlier table (35 KB at 4096 columns)
-    if (const char* te = getenv("GEAR_DECOMP_TROWS")) trows = atoi(te);
     if (trows > rpb) trows = rpb;
     while (trows > 1 && (rpb % trows != 0 || (size_t)trows * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024)) trows >>= 1;
     const size_t shmem = (k > 0 && !patch) ? (size_t)trows * len * 2 : 0;

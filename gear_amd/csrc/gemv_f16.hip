@@ -188,8 +188,7 @@ void launch_nb(int B, unsigned blocks, hipStream_t st, const GemvArgs& a) {
 //   SK=1  5696 4473 6156 4784 6338     SK=2  5907 4608 6376 4788 6581     SK=4  5497 4188 6224 5015 6488
 int pick_sk(int K, int N, int max_sk) {
     int sk = 2;
-    if (const char* e = getenv("GEAR_GEMV_SK")) sk = atoi(e);
-    else if ((int64_t)N <= 8192 && K >= 8192) sk = 4;
+    if ((int64_t)N <= 8192 && K >= 8192) sk = 4;
     if (sk != 1 && sk != 2 && sk != 4) sk = 1;
     return sk > max_sk ? max_sk : sk;
 }

@@ -1,0 +1,930 @@
+// kfused.hip -- the K side of GEAR compress, fused, reading token-major K [BH][T][128] exactly as the model produces it.
+//
+// Reference semantics: gears_channelQ + fake_poweriteration_group
+// (GenerationBench/GenerationTest/GEARLM/Simulated/compress_function.py:261-296, :69-98, :204-220) and, in fp16-stepwise
+// mode, key_compression (cuda_supported_gear/modeling_llamagear.py:23-38 with new_pack.py:253-311).  The reference does
+// `key.transpose(2, 3).contiguous()` first (modeling_llamagear.py:268, :403) and then makes 2 + 2*loop passes over the
+// data; round 1 of this build did transpose -> row compressor -> Gram -> Q pass with the fp16 error matrix making a round
+// trip through HBM in the K^T layout.  Here:
+//
+//   k_select_kernel   one sweep: per-channel outlier selection over all T tokens (exact top-k / bottom-k, ties "lower
+//                     index first").  Lanes own channel pairs and stream tokens; thresholds guessed from a token
+//                     sample, validated by the candidate counts, exact slow path otherwise.  Out: the sparse payload
+//                     (sorted lists), the row means (fill value) and a bitmap [BH][T/64][128] x 64 bit.
+//   k_main_kernel     one sweep, everything dense: a wave owns a 64-token x 128-channel tile with lane = channel pair, so a
+//                     quantization group (64 or 32 tokens of one channel) lives in ONE lane's registers: min/max, scale,
+//                     quantize, bit-pack along T (straight into the channel-major K^T payload layout the decode
+//                     attention streams, with a row pitch / token offset so that the streaming cache is written in
+//                     place) and the fp16 error, which goes into the wave's LDS tile and from there into
+//                     v_mfma_f32_32x32x16_f16 for the per-head Gram matrix G = E^T E.  The error matrix is additionally
+//                     written ONCE token-major for the Q pass (no E^T, no transpose kernel, no Gram pass over HBM).
+//   k_solve_kernel    per head: sum the slabs' partial Gram matrices, power iteration + CholeskyQR2 in LDS
+//                     (lowrank_solve.h) -> W, P.
+//   Q pass            Q' = E W, lowrank_gram.hip's token-major MFMA kernel.
+//
+// HBM traffic per K tensor of n elements: read 2n (select) + read 2n, write n*b/8 + 8n/g + 2n (main) + read 2n (Q pass)
+// = 8.3n bytes against 12.6n for the round-1 chain (transpose r+w 4n, rows r 2n + w 2.3n, Gram 2n, Q 2n + ...).
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "lowrank_solve.h"
+
+int gear_qpass_tm(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_dtype, int q_tcap, int q_toff,
+                  hipStream_t st);
+
+namespace {
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+constexpr int KD = 128;          // head_dim
+constexpr int KS_CAP = 160;      // candidate slots per (channel, side) list
+constexpr int KS_B = 8;          // words per candidate batch
+constexpr int ET_PITCH = 136;    // halfs per LDS row of a wave's error tile [64 tokens][128 channels (+8 pad)]
+
+__device__ __forceinline__ uint32_t sort_key16(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit); -0 == +0
+    if (hbits == 0x8000u) hbits = 0u;
+    return (hbits & 0x8000u) ? (~hbits & 0xFFFFu) : (hbits | 0x8000u);
+}
+// "larger = selected first": side 0 = the k largest values, side 1 = the k smallest
+__device__ __forceinline__ uint32_t order_key(uint32_t hbits, int side) {
+    const uint32_t kx = sort_key16(hbits);
+    return side == 0 ? kx : 0xFFFFu - kx;
+}
+
+// ================================================================================================ select
+// block L of the 1-D grid -> (quarter q of the 128 channels, head bh).  With BH % 8 == 0 the four quarters of a head are
+// blocks L, L+8, L+16, L+24: the same XCD (block b runs on XCD b % 8), dispatched together, so the two 64-byte halves of
+// every 128-byte line of K meet in one L2.
+__device__ __forceinline__ void select_block_map(int L, int64_t BH, int& q, int64_t& bh) {
+    if ((BH & 7) == 0) {
+        const int xcd = L & 7, i = L >> 3;
+        q = i & 3;
+        bh = xcd + 8 * (int64_t)(i >> 2);
+    } else {
+        q = L & 3;
+        bh = L >> 2;
+    }
+}
+
+struct SelArgs {
+    const uint16_t* x;      // [BH][T][128]
+    int64_t BH;
+    int T, k;
+    float zthr;             // candidate threshold = mean +- zthr * sd of the token sample
+    int sstride;            // phase A samples every sstride-th token of a stream
+    float rlen;             // 1 / T
+    uint32_t* obits;        // [BH][T/64][128][2] words: bit t%64 of (tile t/64, channel) = outlier (either side)
+    float* omean;           // [BH][128]
+    uint16_t* oidx;         // [BH][128][2][kcap]: side slot 0 = the k smallest, 1 = the k largest, each ascending by token
+    uint16_t* oval;
+    int kcap, o_off, tok_base;
+};
+
+__global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
+    // dynamic LDS: cand [64 lists][KS_CAP] | cnt [64] | scratch (phase A: stat [16][16][4] floats; phase B: stash
+    // [256][KS_B]; phase C: per wave 2 bitmaps + 1 prefix array of T/32 words)
+    extern __shared__ __attribute__((aligned(16))) uint32_t sl[];
+    uint32_t* cand = sl;
+    uint32_t* cnt = sl + 64 * KS_CAP;
+    uint32_t* scr = cnt + 64;
+    __shared__ uint32_t thr_lds[32];
+    __shared__ float sum_lds[16][32];
+
+    int q;
+    int64_t bh;
+    select_block_map((int)blockIdx.x, a.BH, q, bh);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c2 = lane & 15, ts = lane >> 4, s = wave * 4 + ts;      // channel pair in the quarter, stream id (16 streams)
+    const int T = a.T, k = a.k;
+    const uint16_t* xq = a.x + bh * (int64_t)T * KD + 32 * q;         // this quarter's first channel of token 0
+    const uint32_t* xw = (const uint32_t*)xq + c2;                    // + t * 64 words
+    const int per_stream = (T + 15) >> 4;                             // tokens of a stream: t = s + 16 i
+
+    // ---------------------------------------------------------------- phase A: sample statistics -> threshold guess
+    {
+        float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+        int ns = 0;
+        for (int i = 0; i < per_stream; i += a.sstride) {
+            const int t = s + 16 * i;
+            if (t < T) {
+                const uint32_t w = xw[(int64_t)t * 64];
+                const float f0 = h2f_bits((uint16_t)(w & 0xFFFFu)), f1 = h2f_bits((uint16_t)(w >> 16));
+                s1a += f0; s2a = fmaf(f0, f0, s2a);
+                s1b += f1; s2b = fmaf(f1, f1, s2b);
+                ns++;
+            }
+        }
+        float* stat = (float*)scr;                                   // [16 streams][16 pairs][4]
+        *(float4*)&stat[(s * 16 + c2) * 4] = make_float4(s1a, s2a, s1b, s2b);
+        if (tid < 64) cnt[tid] = 0u;
+        if (tid == 0) sum_lds[0][0] = 0.f;
+        __syncthreads();
+        if (tid < 32) {
+            const int pr = tid >> 1, h = tid & 1;
+            float t1 = 0.f, t2 = 0.f;
+            for (int st = 0; st < 16; st++) {
+                t1 += stat[(st * 16 + pr) * 4 + 2 * h];
+                t2 += stat[(st * 16 + pr) * 4 + 2 * h + 1];
+            }
+            // number of sampled tokens (all streams): streams s < T % 16 ... every stream sees ceil((T - s) / 16) tokens
+            int n = 0;
+            for (int st = 0; st < 16; st++) {
+                const int cntst = (T > st) ? ((T - st + 15) >> 4) : 0;
+                n += (cntst + a.sstride - 1) / a.sstride;
+            }
+            const float rn = 1.0f / (float)max(n, 1);
+            const float mean = t1 * rn;
+            const float sd = sqrtf(fmaxf(t2 * rn - mean * mean, 0.0f));
+            const uint32_t th = f2h_bits(mean + a.zthr * sd), tl = f2h_bits(mean - a.zthr * sd);
+            thr_lds[tid] = th | (tl << 16);
+        }
+        (void)ns;
+        __syncthreads();
+    }
+    const uint32_t tw0 = thr_lds[2 * c2], tw1 = thr_lds[2 * c2 + 1];
+    const half2v thi2 = __builtin_bit_cast(half2v, (tw0 & 0xFFFFu) | (tw1 << 16));
+    const half2v tlo2 = __builtin_bit_cast(half2v, (tw0 >> 16) | (tw1 & 0xFFFF0000u));
+
+    // ---------------------------------------------------------------- phase B: stream every token once
+    float suma = 0.f, sumb = 0.f;
+    {
+        const half2v sel_a = {(_Float16)1.0f, (_Float16)0.0f}, sel_b = {(_Float16)0.0f, (_Float16)1.0f};
+        uint32_t* stash = scr + tid * KS_B;
+        const int nb = (per_stream + KS_B - 1) / KS_B;
+        uint32_t cur[KS_B], nxt[KS_B];
+        auto load_batch = [&](int b, uint32_t (&dst)[KS_B]) {
+#pragma unroll
+            for (int j = 0; j < KS_B; j++) {
+                const int t = s + 16 * (b * KS_B + j);
+                dst[j] = (t < T) ? xw[(int64_t)t * 64] : 0u;
+            }
+        };
+        load_batch(0, cur);
+        for (int b = 0; b < nb; b++) {
+            if (b + 1 < nb) load_batch(b + 1, nxt);
+            uint32_t sg_hi = 0u, sg_lo = 0u;
+#pragma unroll
+            for (int j = 0; j < KS_B; j++) {
+                const half2v xv = __builtin_bit_cast(half2v, cur[j]);
+                suma = __builtin_amdgcn_fdot2(xv, sel_a, suma, false);
+                sumb = __builtin_amdgcn_fdot2(xv, sel_b, sumb, false);
+                const uint32_t dh = __builtin_bit_cast(uint32_t, (half2v)(xv - thi2));   // sign clear: x >= thi
+                const uint32_t dl = __builtin_bit_cast(uint32_t, (half2v)(tlo2 - xv));   // sign clear: x <= tlo
+                sg_hi |= (dh & 0x80008000u) >> j;
+                sg_lo |= (dl & 0x80008000u) >> j;
+                stash[j] = cur[j];
+            }
+            // bit 15-j <-> (word j, low half = even channel), bit 31-j <-> (word j, high half); words past T are masked
+            uint32_t valid = 0u;
+#pragma unroll
+            for (int j = 0; j < KS_B; j++)
+                if (s + 16 * (b * KS_B + j) < T) valid |= 0x80008000u >> j;
+            uint32_t mh = ~sg_hi & valid, ml = ~sg_lo & valid;
+            for (int side = 0; side < 2; side++) {
+                uint32_t msk = side == 0 ? mh : ml;
+                while (msk) {
+                    const int p = 31 - __clz(msk);                  // highest set bit first
+                    msk &= ~(1u << p);
+                    const int half = p >> 4, j = 15 - (p & 15);
+                    const uint32_t bits = (stash[j] >> (16 * half)) & 0xFFFFu;
+                    const int t = s + 16 * (b * KS_B + j);
+                    const int list = (2 * c2 + half) * 2 + side;
+                    const uint32_t slot = atomicAdd(&cnt[list], 1u);
+                    if (slot < (uint32_t)KS_CAP) cand[list * KS_CAP + slot] = (bits << 16) | (uint32_t)t;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KS_B; j++) cur[j] = nxt[j];
+        }
+    }
+    sum_lds[s][2 * c2] = suma;
+    sum_lds[s][2 * c2 + 1] = sumb;
+    __syncthreads();
+    if (tid < 32) {
+        float tot = 0.f;
+        for (int st = 0; st < 16; st++) tot += sum_lds[st][tid];
+        const float mean = ((T & (T - 1)) == 0) ? tot * a.rlen : tot / (float)T;
+        a.omean[bh * KD + 32 * q + tid] = mean;
+    }
+    if (k <= 0) return;
+
+    // ---------------------------------------------------------------- phase C: exact selection, one wave per channel
+    const int nwords = (T + 31) >> 5;
+    uint32_t* bmA = scr + wave * 3 * nwords;       // side 0 (large) bitmap of the current channel
+    uint32_t* bmB = bmA + nwords;                  // side 1 (small)
+    uint32_t* pfx = bmB + nwords;                  // exclusive prefix popcount per word (one side at a time)
+    const int wpl = (nwords + 63) >> 6;            // bitmap words per lane
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int lch = wave; lch < 32; lch += 4) {
+        const int ch = 32 * q + lch;
+        const uint16_t* xc = a.x + bh * (int64_t)T * KD + ch;       // + t * 128
+        for (int i = 0; i < wpl; i++) {
+            const int w = lane * wpl + i;
+            if (w < nwords) { bmA[w] = 0u; bmB[w] = 0u; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int side = 0; side < 2; side++) {
+            uint32_t* bm = side == 0 ? bmA : bmB;
+            const int list = lch * 2 + side;
+            const int n = __builtin_amdgcn_readfirstlane((int)cnt[list]);
+            const bool fast = n >= k && n <= KS_CAP;
+            uint32_t cv[3] = {0u, 0u, 0u}, kx[3] = {0u, 0u, 0u};    // candidate (bits << 16 | t), order key + 1 (0 = none)
+            bool sel[3] = {false, false, false};
+            uint32_t vstar = 0u;
+            int need = 0;
+            if (fast) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int g = lane + 64 * i;
+                    if (g < n) {
+                        cv[i] = cand[list * KS_CAP + g];
+                        kx[i] = order_key(cv[i] >> 16, side) + 1u;
+                    }
+                }
+                uint32_t lo_b = 1u, hi_b = 0x10000u;               // largest V with count(key >= V) >= k (count(>= 1) = n >= k)
+                for (int it = 0; it < 17; it++) {
+                    const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                    const int c = __popcll(__ballot(kx[0] >= mid)) + __popcll(__ballot(kx[1] >= mid)) + __popcll(__ballot(kx[2] >= mid));
+                    if (c >= k) lo_b = mid; else hi_b = mid - 1u;
+                }
+                vstar = lo_b;
+                const int above = __popcll(__ballot(kx[0] > vstar)) + __popcll(__ballot(kx[1] > vstar)) + __popcll(__ballot(kx[2] > vstar));
+                need = k - above;
+                const bool e0 = kx[0] == vstar, e1 = kx[1] == vstar, e2 = kx[2] == vstar;
+                const int neq = __popcll(__ballot(e0)) + __popcll(__ballot(e1)) + __popcll(__ballot(e2));
+                uint32_t tmax = 0xFFFFu;                           // ties: the `need` lowest tokens
+                if (neq > need) {
+                    const uint32_t t0 = e0 ? (cv[0] & 0xFFFFu) : 0xFFFFFFFFu, t1 = e1 ? (cv[1] & 0xFFFFu) : 0xFFFFFFFFu,
+                                   t2 = e2 ? (cv[2] & 0xFFFFu) : 0xFFFFFFFFu;
+                    uint32_t lo_t = 0u, hi_t = 0xFFFFu;            // smallest Tt with count(tie && t <= Tt) >= need
+                    for (int it = 0; it < 16; it++) {
+                        const uint32_t mid = (lo_t + hi_t) >> 1;
+                        const int c = __popcll(__ballot(t0 <= mid)) + __popcll(__ballot(t1 <= mid)) + __popcll(__ballot(t2 <= mid));
+                        if (c >= need) hi_t = mid; else lo_t = mid + 1u;
+                    }
+                    tmax = hi_t;
+                }
+                sel[0] = kx[0] > vstar || (e0 && (cv[0] & 0xFFFFu) <= tmax);
+                sel[1] = kx[1] > vstar || (e1 && (cv[1] & 0xFFFFu) <= tmax);
+                sel[2] = kx[2] > vstar || (e2 && (cv[2] & 0xFFFFu) <= tmax);
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if (sel[i]) atomicOr(&bm[(cv[i] & 0xFFFFu) >> 5], 1u << (cv[i] & 31u));
+            } else {
+                // exact slow path (threshold guess missed, list overflow, k > what the candidate lists hold): bisection on
+                // the value key with one pass over the channel's column per round
+                uint32_t lo_b = 1u, hi_b = 0x10000u;
+                for (int it = 0; it < 17; it++) {
+                    const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                    int c = 0;
+                    for (int tb = 0; tb < T; tb += 64) {
+                        const int t = tb + lane;
+                        const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+                        c += __popcll(__ballot(kk >= mid));
+                    }
+                    if (c >= k) lo_b = mid; else hi_b = mid - 1u;
+                }
+                vstar = lo_b;
+                int above = 0;
+                for (int tb = 0; tb < T; tb += 64) {
+                    const int t = tb + lane;
+                    const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+                    above += __popcll(__ballot(kk > vstar));
+                }
+                need = k - above;
+                int taken = 0;                                      // ties taken so far, in token order
+                for (int tb = 0; tb < T; tb += 64) {
+                    const int t = tb + lane;
+                    const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+                    const bool eq = kk == vstar;
+                    const unsigned long long be = __ballot(eq);
+                    const bool sl_ = kk > vstar || (eq && taken + __popcll(be & lt) < need);
+                    const unsigned long long bs = __ballot(sl_);
+                    if (lane == 0) { bm[tb >> 5] = (uint32_t)bs; if (tb + 32 < T) bm[(tb >> 5) + 1] = (uint32_t)(bs >> 32); }
+                    taken += __popcll(be);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // exclusive prefix popcount per bitmap word -> rank of a selected token = its position in the sorted list
+            uint32_t c = 0u;
+            for (int i = 0; i < wpl; i++) {
+                const int w = lane * wpl + i;
+                if (w < nwords) c += (uint32_t)__popc(bm[w]);
+            }
+            uint32_t base = wave_incl_scan_u32(c) - c;
+            for (int i = 0; i < wpl; i++) {
+                const int w = lane * wpl + i;
+                if (w < nwords) { pfx[w] = base; base += (uint32_t)__popc(bm[w]); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int64_t lbase = ((bh * KD + ch) * 2 + (side == 0 ? 1 : 0)) * (int64_t)a.kcap + a.o_off;
+            if (fast) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    if (sel[i]) {
+                        const uint32_t t = cv[i] & 0xFFFFu;
+                        const uint32_t r = pfx[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
+                        a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
+                        a.oval[lbase + r] = (uint16_t)(cv[i] >> 16);
+                    }
+                }
+            } else {
+                for (int tb = 0; tb < T; tb += 64) {
+                    const uint32_t t = tb + lane;
+                    if ((int)t < T && ((bm[t >> 5] >> (t & 31u)) & 1u)) {
+                        const uint32_t r = pfx[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
+                        a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
+                        a.oval[lbase + r] = xc[(int64_t)t * KD];
+                    }
+                }
+            }
+        }
+        // the channel's outlier bitmap (both sides), tile-major for the main kernel: [bh][tile][channel] x 2 words
+        const int ntiles = (T + 63) >> 6;
+        for (int tile = lane; tile < ntiles; tile += 64) {
+            const uint32_t w0 = bmA[2 * tile] | bmB[2 * tile];
+            const uint32_t w1 = (2 * tile + 1 < nwords) ? (bmA[2 * tile + 1] | bmB[2 * tile + 1]) : 0u;
+            *(uint2*)&a.obits[((bh * ntiles + tile) * KD + ch) * 2] = make_uint2(w0, w1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ================================================================================================ main
+__device__ __forceinline__ uint32_t vbfi(uint32_t m, uint32_t a, uint32_t bb) {   // (a & m) | (bb & ~m)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmin16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmax16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ float fmin_raw(float a, float bb) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ float fmax_raw(float a, float bb) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+// float(half HI ? high : low of w) + addend (the convert is exact: one rounding)
+template <int HI>
+__device__ __forceinline__ float add_mix(uint32_t w, float one, float addend) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(one), "v"(addend));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(one), "v"(addend));
+    return r;
+}
+// half-word masks of token j (0..15) from D = (16 outlier bits of the even channel) | (16 bits of the odd channel) << 16
+__device__ __forceinline__ uint32_t mask_of(uint32_t D, int j) {
+    const short2v d = __builtin_bit_cast(short2v, D);
+    const short sh = (short)(15 - j);
+    short2v t = d << (short2v){sh, sh};
+    t = t >> (short2v){15, 15};
+    return __builtin_bit_cast(uint32_t, t);
+}
+// flag bits (one per code) -> BITS bits per code, 16 / BITS codes -> 16 bits
+template <int BITS>
+__device__ __forceinline__ uint32_t spread_half(uint32_t f) {
+    if (BITS == 2) {
+        uint32_t x = f & 0xFFu;
+        x = (x | (x << 4)) & 0x0F0Fu;
+        x = (x | (x << 2)) & 0x3333u;
+        x = (x | (x << 1)) & 0x5555u;
+        return x * 3u;
+    } else {
+        uint32_t x = f & 0xFu;
+        x = (x | (x << 6)) & 0x0303u;
+        x = (x | (x << 3)) & 0x1111u;
+        return x * 15u;
+    }
+}
+
+struct MainArgs {
+    const uint16_t* x;       // [BH][T][128]
+    const uint32_t* obits;   // [BH][T/64][128][2] or null (no outliers)
+    const float* omean;      // [BH][128] (only with obits)
+    int T, tiles_per_slab, nslab;
+    uint32_t* code;          // [BH][128][ldc] words
+    void* scale;             // [BH][128][lds]
+    void* mn;
+    int64_t ldc, lds;
+    int t_off;               // token offset of this call inside the payload rows (multiple of 64)
+    uint16_t* err;           // [BH][T][128] fp16 error, token-major (null: not needed)
+    float* gpart;            // [BH][nslab][128][128] partial Gram matrices (blocks on / above the block diagonal), or null
+};
+
+// One 64-token tile of one wave.  xr[i] = (channel 2*lane, channel 2*lane+1) of token i.
+// Generic arithmetic (both modes): element by element, as compress_rows_kernel / quant_pack.hip do it.
+template <int BITS, int MODE, int G, typename ST>
+__device__ __forceinline__ void tile_generic(const uint32_t (&xr)[64], uint32_t mA0, uint32_t mA1, uint32_t mB0, uint32_t mB1,
+                                             float meanA, float meanB, uint32_t (&ew)[64], uint32_t (&cwA)[64 * BITS / 32],
+                                             uint32_t (&cwB)[64 * BITS / 32], float (&scA)[64 / G], float (&mnA)[64 / G],
+                                             float (&scB)[64 / G], float (&mnB)[64 / G]) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int CPW = 32 / BITS;
+    constexpr int NW = 64 / CPW;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { cwA[w] = 0u; cwB[w] = 0u; }
+#pragma unroll
+    for (int i = 0; i < 64; i++) ew[i] = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t m0 = h ? mB0 : mA0, m1 = h ? mB1 : mA1;
+        const float mean = h ? meanB : meanA;
+        const float fill = (MODE == 0) ? hround(mean) : mean;
+#pragma unroll
+        for (int gi = 0; gi < 64 / G; gi++) {
+            float v[G];
+            float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const int tk = gi * G + i;
+                const bool o = ((tk < 32 ? m0 >> tk : m1 >> (tk - 32)) & 1u) != 0u;
+                const float xv = h2f_bits((uint16_t)((xr[tk] >> (16 * h)) & 0xFFFFu));
+                v[i] = o ? fill : xv;
+                lo = fminf(lo, v[i]);
+                hi = fmaxf(hi, v[i]);
+            }
+            QuantParams<MODE> qp = make_qparams<MODE>(lo, hi, LEVELS);
+            const float inv = (qp.scale != 0.0f) ? div_rn(1.0f, qp.scale) : 0.0f;
+            (h ? scB : scA)[gi] = qp.scale;
+            (h ? mnB : mnA)[gi] = qp.mn;
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const int tk = gi * G + i;
+                const bool o = ((tk < 32 ? m0 >> tk : m1 >> (tk - 32)) & 1u) != 0u;
+                int qv;
+                if (qp.scale == 0.0f) qv = 0;
+                else if (MODE == 0) {
+                    const float t1 = hround(v[i] - qp.mn);
+                    float c = hround(div_rn(t1, qp.scale));
+                    c = fminf(fmaxf(c, 0.0f), (float)LEVELS);
+                    qv = (int)rintf(c);
+                } else {
+                    const float t = v[i] - qp.mn;
+                    float c = t * inv;
+                    float r = rintf(c);
+                    if (fabsf(fabsf(c - r) - 0.5f) < 1e-5f) r = rintf(div_rn(t, qp.scale));
+                    qv = (int)fminf(fmaxf(r, 0.0f), (float)LEVELS);
+                }
+                (h ? cwB : cwA)[tk / CPW] |= (uint32_t)qv << (BITS * (tk % CPW));
+                const float d = (MODE == 0) ? dequant_one<0>(qv, qp.scale, qp.mn) : hround(dequant_one<1>(qv, qp.scale, qp.mn));
+                const float e = o ? 0.0f : (v[i] - d);
+                ew[tk] |= (uint32_t)f2h_bits(e) << (16 * h);
+            }
+        }
+    }
+}
+
+// Mode-1 (fp32 simulated arithmetic) tile on packed registers: everything that is exact in fp16 stays packed (min / max
+// with the outlier halves masked to +-inf, error = x - dequant), the quotient is a reciprocal multiply with a 1e-5 tie
+// guard (exact division redone for the block of a lane that raises it), codes are packed by an fp32 Horner chain along T.
+template <int BITS, int G, typename ST>
+__device__ __forceinline__ void tile_fast(const uint32_t (&xr)[64], uint32_t mA0, uint32_t mA1, uint32_t mB0, uint32_t mB1,
+                                          float meanA, float meanB, uint32_t (&ew)[64], uint32_t (&cwA)[64 * BITS / 32],
+                                          uint32_t (&cwB)[64 * BITS / 32], float (&scA)[64 / G], float (&mnA)[64 / G],
+                                          float (&scB)[64 / G], float (&mnB)[64 / G]) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int HC = 16 / BITS;            // codes per 16-bit half word: one Horner chain
+    constexpr float TIE = 0.49999f;
+    const uint32_t PINF = 0x7C007C00u, NINF = 0xFC00FC00u;
+    // D[w]: outlier bits of tokens 16w .. 16w+15, even channel in the low half, odd channel in the high half
+    const uint32_t D[4] = {(mA0 & 0xFFFFu) | (mB0 << 16), (mA0 >> 16) | (mB0 & 0xFFFF0000u),
+                           (mA1 & 0xFFFFu) | (mB1 << 16), (mA1 >> 16) | (mB1 & 0xFFFF0000u)};
+#pragma unroll
+    for (int gi = 0; gi < 64 / G; gi++) {
+        // ---- group min / max over the non-outliers (packed, exact)
+        uint32_t lo2 = PINF, hi2 = NINF;
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int tk = gi * G + i;
+            const uint32_t m = mask_of(D[tk >> 4], tk & 15);
+            lo2 = pkmin16(lo2, vbfi(m, PINF, xr[tk]));
+            hi2 = pkmax16(hi2, vbfi(m, NINF, xr[tk]));
+        }
+        float loA = h2f_bits((uint16_t)(lo2 & 0xFFFFu)), loB = h2f_bits((uint16_t)(lo2 >> 16));
+        float hiA = h2f_bits((uint16_t)(hi2 & 0xFFFFu)), hiB = h2f_bits((uint16_t)(hi2 >> 16));
+        uint32_t gA, gB;                     // the group's outlier bits, per channel
+        if (G == 64) { gA = mA0 | mA1; gB = mB0 | mB1; }
+        else { gA = gi == 0 ? mA0 : mA1; gB = gi == 0 ? mB0 : mB1; }
+        // the fill value (fp32 row mean, compress_function.py:279-283) takes part in min / max when the group holds an outlier
+        loA = fmin_raw(loA, gA ? meanA : INFINITY); hiA = fmax_raw(hiA, gA ? meanA : -INFINITY);
+        loB = fmin_raw(loB, gB ? meanB : INFINITY); hiB = fmax_raw(hiB, gB ? meanB : -INFINITY);
+        const float qsA = div_rn(hiA - loA, (float)LEVELS), qsB = div_rn(hiB - loB, (float)LEVELS);
+        const float invA = (qsA != 0.0f) ? __builtin_amdgcn_rcpf(qsA) : 0.0f, invB = (qsB != 0.0f) ? __builtin_amdgcn_rcpf(qsB) : 0.0f;
+        scA[gi] = qsA; mnA[gi] = loA; scB[gi] = qsB; mnB[gi] = loB;
+        const float2v inv2 = {invA, invB}, qs2 = {qsA, qsB}, mn2 = {loA, loB};
+        // code of a filled position: quant(mean)
+        float cmA = 0.f, cmB = 0.f;
+        if (gA | gB) {
+            const float ca = (meanA - loA) * invA, cb = (meanB - loB) * invB;
+            cmA = rintf(ca); cmB = rintf(cb);
+            if (fabsf(ca - cmA) > TIE) cmA = (qsA != 0.0f) ? rintf(div_rn(meanA - loA, qsA)) : 0.0f;
+            if (fabsf(cb - cmB) > TIE) cmB = (qsB != 0.0f) ? rintf(div_rn(meanB - loB, qsB)) : 0.0f;
+            cmA = __builtin_amdgcn_fmed3f(cmA, 0.0f, (float)LEVELS);
+            cmB = __builtin_amdgcn_fmed3f(cmB, 0.0f, (float)LEVELS);
+        }
+        const uint32_t repA = (uint32_t)cmA * (0xFFFFu / (uint32_t)LEVELS), repB = (uint32_t)cmB * (0xFFFFu / (uint32_t)LEVELS);
+        // ---- quantize / pack / error, one 16-bit half word (HC tokens) at a time
+#pragma unroll
+        for (int hb = 0; hb < G / HC; hb++) {
+            const int tb = gi * G + hb * HC;                 // first token of the block
+            float2v rq[HC];
+            float dmax = 0.0f;
+#pragma unroll
+            for (int j = 0; j < HC; j++) {
+                const float2v t = {add_mix<0>(xr[tb + j], 1.0f, -loA), add_mix<1>(xr[tb + j], 1.0f, -loB)};
+                const float2v c = t * inv2;
+                const float2v rr = {rintf(c.x), rintf(c.y)};
+                const float2v d = c - rr;
+                rq[j] = rr;
+                asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
+            }
+            if (dmax > TIE) {                                // within 1e-5 of a rounding tie: redo by exact division
+#pragma unroll
+                for (int j = 0; j < HC; j++) {
+                    const float xa = h2f_bits((uint16_t)(xr[tb + j] & 0xFFFFu)), xb = h2f_bits((uint16_t)(xr[tb + j] >> 16));
+                    rq[j].x = (qsA != 0.0f) ? rintf(div_rn(xa - loA, qsA)) : 0.0f;
+                    rq[j].y = (qsB != 0.0f) ? rintf(div_rn(xb - loB, qsB)) : 0.0f;
+                }
+            }
+            float2v hn = {0.0f, 0.0f};
+#pragma unroll
+            for (int j = HC - 1; j >= 0; j--) {
+                rq[j].x = __builtin_amdgcn_fmed3f(rq[j].x, 0.0f, (float)LEVELS);
+                rq[j].y = __builtin_amdgcn_fmed3f(rq[j].y, 0.0f, (float)LEVELS);
+                hn = hn * (float)(1 << BITS) + rq[j];        // exact: < 2^16
+            }
+            uint32_t hwA = (uint32_t)hn.x, hwB = (uint32_t)hn.y;
+            const uint32_t fA = ((tb < 32 ? mA0 >> tb : mA1 >> (tb - 32))) & ((1u << HC) - 1u);
+            const uint32_t fB = ((tb < 32 ? mB0 >> tb : mB1 >> (tb - 32))) & ((1u << HC) - 1u);
+            if (fA) { const uint32_t sm = spread_half<BITS>(fA); hwA = (repA & sm) | (hwA & ~sm); }
+            if (fB) { const uint32_t sm = spread_half<BITS>(fB); hwB = (repB & sm) | (hwB & ~sm); }
+            const int hw = tb / HC;                          // half-word index inside the tile
+            if ((hw & 1) == 0) { cwA[hw >> 1] = hwA; cwB[hw >> 1] = hwB; }
+            else { cwA[hw >> 1] |= hwA << 16; cwB[hw >> 1] |= hwB << 16; }
+            // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
+#pragma unroll
+            for (int j = 0; j < HC; j++) {
+                const float2v dq = rq[j] * qs2 + mn2;        // -ffp-contract=off: v_pk_mul_f32, v_pk_add_f32
+                const uint32_t dw = (uint32_t)f2h_bits(dq.x) | ((uint32_t)f2h_bits(dq.y) << 16);
+                uint32_t e2;
+                asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tb + j]), "v"(dw));
+                ew[tb + j] = vbfi(mask_of(D[(tb + j) >> 4], (tb + j) & 15), 0u, e2);
+            }
+        }
+    }
+}
+
+__host__ __device__ constexpr int blk_index(int I, int J) {  // upper-triangular block (I <= J) -> 0..9
+    return I * 4 - (I * (I - 1)) / 2 + (J - I);
+}
+
+// grid (nslab, BH), 256 threads = 4 waves, each wave walks its own tiles of the slab.
+template <int BITS, int MODE, int G, typename ST, bool FAST, bool LR>
+__global__ __launch_bounds__(256, 1) void k_main_kernel(MainArgs a) {
+    constexpr int CPW = 32 / BITS;
+    constexpr int NW = 64 / CPW;             // code words per channel and tile
+    constexpr int NG = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slab = blockIdx.x;
+    const int64_t bh = blockIdx.y;
+    const int T = a.T, ntiles = T >> 6;
+    uint16_t* etile = (uint16_t*)smem + wave * 64 * ET_PITCH;   // this wave's error tile [64][ET_PITCH]
+    const int x31 = lane & 31, kg = lane >> 5;
+
+    float16_t acc[10];
+    if (LR) {
+#pragma unroll
+        for (int b = 0; b < 10; b++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
+    }
+    float meanA = 0.f, meanB = 0.f;
+    if (a.obits) {
+        const float2 mm = *(const float2*)&a.omean[bh * KD + 2 * lane];
+        meanA = mm.x; meanB = mm.y;
+    }
+    const int tile_lo = slab * a.tiles_per_slab, tile_hi = min(ntiles, tile_lo + a.tiles_per_slab);
+
+    auto load_tile = [&](int tile, uint32_t (&dst)[64], uint4& mk) {
+        const uint32_t* xw = (const uint32_t*)(a.x + (bh * T + (int64_t)tile * 64) * KD) + lane;
+#pragma unroll
+        for (int i = 0; i < 64; i++) dst[i] = xw[i * 64];
+        mk = make_uint4(0, 0, 0, 0);
+        if (a.obits) mk = *(const uint4*)&a.obits[((bh * ntiles + tile) * KD + 2 * lane) * 2];
+    };
+    auto process = [&](int tile, const uint32_t (&xr)[64], const uint4& mk) {
+        uint32_t ew[64], cwA[NW], cwB[NW];
+        float scA[NG], mnA[NG], scB[NG], mnB[NG];
+        if (FAST) tile_fast<BITS, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
+        else tile_generic<BITS, MODE, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
+        // ---- payload stores: channel-major rows, this tile's words / groups at the token offset
+        const int tok = a.t_off + tile * 64;
+        uint32_t* cA = a.code + (bh * KD + 2 * lane) * a.ldc + tok / CPW;
+        uint32_t* cB = cA + a.ldc;
+        if (NW == 4) {
+            *(uint4*)cA = make_uint4(cwA[0], cwA[1], cwA[2], cwA[3]);
+            *(uint4*)cB = make_uint4(cwB[0], cwB[1], cwB[2], cwB[3]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; w += 4) {
+                *(uint4*)(cA + w) = make_uint4(cwA[w], cwA[w + 1], cwA[w + 2], cwA[w + 3]);
+                *(uint4*)(cB + w) = make_uint4(cwB[w], cwB[w + 1], cwB[w + 2], cwB[w + 3]);
+            }
+        }
+        ST* sA = (ST*)a.scale + (bh * KD + 2 * lane) * a.lds + tok / G;
+        ST* nA = (ST*)a.mn + (bh * KD + 2 * lane) * a.lds + tok / G;
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) {
+            st_st<ST>(sA + gi, scA[gi]);
+            st_st<ST>(nA + gi, mnA[gi]);
+            st_st<ST>(sA + a.lds + gi, scB[gi]);
+            st_st<ST>(nA + a.lds + gi, mnB[gi]);
+        }
+        if (a.err) {
+            uint32_t* ep = (uint32_t*)(a.err + (bh * T + (int64_t)tile * 64) * KD) + lane;
+#pragma unroll
+            for (int i = 0; i < 64; i++) ep[i * 64] = ew[i];
+        }
+        if (LR) {
+            // ---- error tile -> LDS (row = token, conflict-free 4-byte stores) -> MFMA operands (lane (x31, kg) holds channel
+            // 32 I + x31 of tokens 16 ks + 8 kg .. +7) -> the 10 upper-triangular 32x32 blocks of G += E^T E
+#pragma unroll
+            for (int i = 0; i < 64; i++) ((uint32_t*)(etile + i * ET_PITCH))[lane] = ew[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                half8_t f[4];
+#pragma unroll
+                for (int I = 0; I < 4; I++) {
+                    union { half8_t h; uint16_t u[8]; } cv;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) cv.u[j] = etile[(16 * ks + 8 * kg + j) * ET_PITCH + 32 * I + x31];
+                    f[I] = cv.h;
+                }
+#pragma unroll
+                for (int I = 0; I < 4; I++)
+#pragma unroll
+                    for (int J = I; J < 4; J++)
+                        acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    // two register sets: the loads of the wave's next tile are in flight while the current one is processed (one copy of the
+    // tile body in the instruction stream: 64 register moves per tile are cheaper than 17 KB more code)
+    uint32_t xa[64], xb[64];
+    uint4 ma, mb = make_uint4(0, 0, 0, 0);
+    int tile = tile_lo + wave;
+    if (tile < tile_hi) load_tile(tile, xa, ma);
+#pragma unroll 1
+    while (tile < tile_hi) {
+        const bool more = tile + 4 < tile_hi;
+        if (more) load_tile(tile + 4, xb, mb);
+        process(tile, xa, ma);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) xa[i] = xb[i];
+            ma = mb;
+        }
+        tile += 4;
+    }
+    if (!LR) return;
+    // ---- the four waves' partial Gram matrices -> LDS, one wave at a time (deterministic), then one coalesced write of
+    // the blocks on / above the block diagonal.  C layout of the 32x32 MFMA: lane l, reg q -> row (q&3) + 8 (q>>2) + 4 (l>>5), col l&31
+    float* Gs = (float*)smem;                                  // [128][GS_GP], aliases the error tiles
+    __syncthreads();
+    for (int i = tid; i < GS_GD * GS_GP; i += 256) Gs[i] = 0.0f;
+    for (int turn = 0; turn < 4; turn++) {
+        __syncthreads();
+        if (wave == turn) {
+#pragma unroll
+            for (int I = 0; I < 4; I++)
+#pragma unroll
+                for (int J = I; J < 4; J++) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int row = 32 * I + (q & 3) + 8 * (q >> 2) + 4 * kg, col = 32 * J + x31;
+                        Gs[row * GS_GP + col] += acc[blk_index(I, J)][q];
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    float* gp = a.gpart + (bh * a.nslab + slab) * (int64_t)(KD * KD);
+    for (int idx = tid; idx < KD * KD; idx += 256) {
+        const int row = idx >> 7, col = idx & 127;
+        if ((col >> 5) >= (row >> 5)) gp[idx] = Gs[row * GS_GP + col];
+    }
+}
+
+// ================================================================================================ solve
+// grid (BH): G = sum of the slabs' partial Gram matrices, then the solve of lowrank_solve.h.
+// P_out head bh lives at (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * r elements.
+template <int RP>
+__global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict__ gpart, int nslab, int loop,
+                                                         const float* __restrict__ P0, int r, float* __restrict__ Wout,
+                                                         void* __restrict__ P_out, int out_f16, int64_t p_inner,
+                                                         int64_t p_outer_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* G = (float*)smem;
+    float* Pa = (float*)(smem + GS_GD * GS_GP * 4);
+    float* Pb = Pa + GS_GD * RP;
+    double* Md = (double*)(Pb + GS_GD * RP);
+    double* Rinv = Md + RP * RP;
+    const int64_t bh = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* gp = gpart + bh * nslab * (int64_t)(KD * KD);
+    for (int idx = tid; idx < KD * KD; idx += 256) {
+        const int row = idx >> 7, col = idx & 127;
+        if ((col >> 5) >= (row >> 5)) {
+            float v = 0.0f;
+            for (int s = 0; s < nslab; s++) v += gp[s * (int64_t)(KD * KD) + idx];
+            G[row * GS_GP + col] = v;
+        }
+    }
+    __syncthreads();
+    const int64_t po = (bh / p_inner) * p_outer_stride + (bh % p_inner) * (int64_t)(KD * r);
+    gram_solve_phase2<RP>(G, Pa, Pb, Md, Rinv, P0 + bh * KD * r, r, loop, Wout + bh * KD * RP,
+                          out_f16 ? (void*)((uint16_t*)P_out + po) : (void*)((float*)P_out + po), out_f16);
+}
+
+double inv_norm_cdf(double p) {  // Acklam's rational approximation (relative error 1.2e-9), 0 < p < 1
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                               1.383577518672690e+02,  -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                               6.680131188771972e+01,  -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                               -2.549732539343734e+00, 4.374664141464968e+00,  2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    const double plow = 0.02425;
+    if (p < plow) {
+        double q = sqrt(-2 * log(p));
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    if (p > 1 - plow) {
+        double q = sqrt(-2 * log(1 - p));
+        return -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    double q = p - 0.5, rr = q * q;
+    return (((((a[0] * rr + a[1]) * rr + a[2]) * rr + a[3]) * rr + a[4]) * rr + a[5]) * q /
+           (((((b[0] * rr + b[1]) * rr + b[2]) * rr + b[3]) * rr + b[4]) * rr + 1);
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct KfWs {       // workspace carve-up
+    size_t obits, omean, err, gpart, W, total;
+    int nslab, tiles_per_slab;
+};
+KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
+    KfWs w;
+    const int ntiles = T / 64;
+    // slabs: enough workgroups to fill the chip (>= ~2 per CU) without drowning the solve in partial Gram traffic
+    int nslab = 1;
+    while (nslab < 4 && BH * nslab < 2048 && ntiles / (nslab * 2) >= 8) nslab *= 2;
+    w.nslab = nslab;
+    w.tiles_per_slab = (ntiles + nslab - 1) / nslab;
+    const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
+    size_t off = 0;
+    w.obits = off; off += align256(k > 0 ? (size_t)BH * ntiles * KD * 8 : 0);
+    w.omean = off; off += align256(k > 0 ? (size_t)BH * KD * 4 : 0);
+    w.err = off;   off += align256(rank > 0 ? (size_t)BH * T * KD * 2 : 0);
+    w.gpart = off; off += align256(rank > 0 ? (size_t)BH * nslab * KD * KD * 4 : 0);
+    w.W = off;     off += align256(rank > 0 ? (size_t)BH * KD * RP * 4 : 0);
+    w.total = off + 256;
+    return w;
+}
+
+template <int BITS, int MODE, int G, typename ST>
+void launch_main(const MainArgs& a, int64_t BH, bool fast, bool lr, hipStream_t st) {
+    const size_t shmem = lr ? (size_t)max(4 * 64 * ET_PITCH * 2, GS_GD * GS_GP * 4) : 0;
+    const dim3 grid((unsigned)a.nslab, (unsigned)BH);
+#define KF_GO(FASTV, LRV)                                                                                              \
+    do {                                                                                                               \
+        auto kfn = k_main_kernel<BITS, MODE, G, ST, FASTV, LRV>;                                                       \
+        if (shmem > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), shmem, st, a);                                                        \
+    } while (0)
+    if constexpr (MODE == 1) {
+        if (fast) { if (lr) KF_GO(true, true); else KF_GO(true, false); return; }
+    }
+    if (lr) KF_GO(false, true); else KF_GO(false, false);
+#undef KF_GO
+}
+
+}  // namespace
+
+extern "C" size_t gear_compress_key_fused_workspace(int64_t BH, int T, int k, int rank) {
+    if (BH <= 0 || T <= 0 || T % 64) return 0;
+    return kf_workspace(BH, T, k, rank).total;
+}
+
+extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int group, int bits, int mode, int k, void* code,
+                                       void* scale, void* mn, int64_t ldc, int64_t lds, int t_off, int rank, int loop,
+                                       const void* P0, void* P_out, int64_t p_inner, int64_t p_outer_stride, void* Q_out,
+                                       int q_tcap, int q_toff, void* oidx, void* oval, int kcap, int o_off, int variant,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    GEAR_CHECK_ARG(x && code && scale && mn && workspace, "gear_compress_key_fused: null pointer");
+    GEAR_CHECK_ARG(BH > 0 && BH <= 65535, "gear_compress_key_fused: BH must be in [1, 65535] (got %lld)", (long long)BH);
+    GEAR_CHECK_ARG(T >= 64 && T % 64 == 0 && T <= 16384, "gear_compress_key_fused: T must be a multiple of 64 in [64, 16384] (got %d)", T);
+    GEAR_CHECK_ARG(group == 64 || group == 32, "gear_compress_key_fused: group must be 32 or 64 (got %d)", group);
+    GEAR_CHECK_ARG(bits == 2 || bits == 4, "gear_compress_key_fused: bits must be 2 or 4 (got %d)", bits);
+    GEAR_CHECK_ARG(mode == GEAR_MODE_FP16_STEPWISE || mode == GEAR_MODE_FP32, "gear_compress_key_fused: bad mode");
+    GEAR_CHECK_ARG(k >= 0 && 2 * k <= T, "gear_compress_key_fused: need 0 <= 2k <= T (k = %d, T = %d)", k, T);
+    GEAR_CHECK_ARG(t_off >= 0 && t_off % 64 == 0, "gear_compress_key_fused: t_off must be a multiple of 64");
+    GEAR_CHECK_ARG(ldc * (32 / bits) >= t_off + T && lds * group >= t_off + T, "gear_compress_key_fused: row pitch too small");
+    GEAR_CHECK_ARG((ldc * 4) % 16 == 0, "gear_compress_key_fused: code row pitch must be a multiple of 16 bytes");
+    GEAR_CHECK_ARG(rank >= 0 && rank <= 16, "gear_compress_key_fused: rank must be in [0, 16]");
+    if (rank > 0) {
+        GEAR_CHECK_ARG(loop >= 1 && P0 && P_out && Q_out, "gear_compress_key_fused: low-rank needs loop >= 1, P0, P_out, Q_out");
+        GEAR_CHECK_ARG(p_inner >= 1 && q_tcap >= q_toff + T, "gear_compress_key_fused: bad factor geometry");
+    }
+    if (k > 0) GEAR_CHECK_ARG(oidx && oval && kcap >= o_off + k && t_off + T <= 65536, "gear_compress_key_fused: bad outlier geometry");
+    const KfWs ws = kf_workspace(BH, T, k, rank);
+    GEAR_CHECK_ARG(workspace_bytes >= ws.total, "gear_compress_key_fused: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    uint32_t* obits = k > 0 ? (uint32_t*)(base + ws.obits) : nullptr;
+    float* omean = k > 0 ? (float*)(base + ws.omean) : nullptr;
+    uint16_t* err = rank > 0 ? (uint16_t*)(base + ws.err) : nullptr;
+    float* gpart = rank > 0 ? (float*)(base + ws.gpart) : nullptr;
+    float* Wws = rank > 0 ? (float*)(base + ws.W) : nullptr;
+
+    if (k > 0) {
+        SelArgs sa;
+        sa.x = (const uint16_t*)x; sa.BH = BH; sa.T = T; sa.k = k;
+        // candidates per side and row: k + 5 sqrt(k) + 8 expected (the guess is validated by the counts; lists hold KS_CAP)
+        const double target = k + 5.0 * sqrt((double)k) + 8.0;
+        double p = target / (double)T;
+        if (p > 0.5) p = 0.5;
+        sa.zthr = (target > 0.6 * KS_CAP || (variant & 2) || gear_options().kselect_slow) ? 1e30f : (float)(-inv_norm_cdf(p));   // huge z: no candidates -> slow exact path
+        sa.sstride = max(1, T / 1024);
+        sa.rlen = 1.0f / (float)T;
+        sa.obits = obits; sa.omean = omean; sa.oidx = (uint16_t*)oidx; sa.oval = (uint16_t*)oval;
+        sa.kcap = kcap; sa.o_off = o_off; sa.tok_base = t_off;
+        const int nwords = (T + 31) / 32;
+        const size_t scr_words = (size_t)max(max(16 * 16 * 4, 256 * KS_B), 4 * 3 * nwords);
+        const size_t shmem = ((size_t)64 * KS_CAP + 64 + scr_words) * 4;
+        hipLaunchKernelGGL(k_select_kernel, dim3((unsigned)(4 * BH)), dim3(256), shmem, st, sa);
+        GEAR_CHECK_LAUNCH("gear_compress_key_fused(select)");
+    }
+    MainArgs ma;
+    ma.x = (const uint16_t*)x; ma.obits = obits; ma.omean = omean; ma.T = T;
+    ma.tiles_per_slab = ws.tiles_per_slab; ma.nslab = ws.nslab;
+    ma.code = (uint32_t*)code; ma.scale = scale; ma.mn = mn; ma.ldc = ldc; ma.lds = lds; ma.t_off = t_off;
+    ma.err = err; ma.gpart = gpart;
+    const bool fast = (variant & 1) == 0 && !gear_options().kfused_generic, lr = rank > 0;
+#define KF_DISPATCH(B, M, GG, STT) launch_main<B, M, GG, STT>(ma, BH, fast, lr, st)
+    if (mode == GEAR_MODE_FP32) {
+        if (bits == 2) { if (group == 64) KF_DISPATCH(2, 1, 64, float); else KF_DISPATCH(2, 1, 32, float); }
+        else { if (group == 64) KF_DISPATCH(4, 1, 64, float); else KF_DISPATCH(4, 1, 32, float); }
+    } else {
+        if (bits == 2) { if (group == 64) KF_DISPATCH(2, 0, 64, uint16_t); else KF_DISPATCH(2, 0, 32, uint16_t); }
+        else { if (group == 64) KF_DISPATCH(4, 0, 64, uint16_t); else KF_DISPATCH(4, 0, 32, uint16_t); }
+    }
+#undef KF_DISPATCH
+    GEAR_CHECK_LAUNCH("gear_compress_key_fused(main)");
+    if (rank > 0) {
+        const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
+        const int of16 = 1;
+        const size_t shmem = gram_solve_lds_bytes(RP);
+#define KF_SOLVE(RPV)                                                                                                    \
+        do {                                                                                                             \
+            auto kfn = k_solve_kernel<RPV>;                                                                              \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
+            hipLaunchKernelGGL(kfn, dim3((unsigned)BH), dim3(256), shmem, st, gpart, ws.nslab, loop, (const float*)P0,   \
+                               rank, Wws, P_out, of16, p_inner, p_outer_stride);                                         \
+        } while (0)
+        if (RP == 4) KF_SOLVE(4); else if (RP == 8) KF_SOLVE(8); else KF_SOLVE(16);
+#undef KF_SOLVE
+        GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
+        return gear_qpass_tm(err, Wws, BH, T, rank, Q_out, GEAR_DTYPE_F16, q_tcap, q_toff, st);
+    }
+    return 0;
+}

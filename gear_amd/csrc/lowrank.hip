@@ -329,7 +329,7 @@ extern "C" int gear_lowrank(const void* E, int e_dtype, int transposed, int64_t 
     GEAR_CHECK_ARG(E && P0 && P_out && Q_out && workspace, "gear_lowrank: null pointer");
     GEAR_CHECK_ARG(workspace_bytes >= gear_lowrank_workspace(bh, S, Dm, r), "gear_lowrank: workspace too small");
     // fast path: fp16 error, head_dim 128 -> Gram-matrix formulation on the matrix cores (lowrank_gram.hip)
-    if (e_dtype == GEAR_DTYPE_F16 && Dm == 128 && (!transposed || S % 8 == 0) && !getenv("GEAR_LOWRANK_GENERIC"))
+    if (e_dtype == GEAR_DTYPE_F16 && Dm == 128 && (!transposed || S % 8 == 0) && !gear_options().lowrank_generic)
         return gear_lowrank_gram(E, transposed, bh, S, r, loop, P0, P_out, Q_out, out_dtype, workspace, (hipStream_t)stream);
     const int RP = pad_rank(r);
     LrWs ws;

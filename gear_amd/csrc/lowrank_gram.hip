@@ -15,16 +15,17 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "lowrank_solve.h"
 
 namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
-constexpr int GD = 128;          // head_dim (the Gram trick is built for 128)
+constexpr int GD = GS_GD;        // head_dim (the Gram trick is built for 128)
 constexpr int KT_PITCH = 72;     // halfs per LDS row of the K^T staging tile [128][64 (+8 pad)]
 constexpr int TM_PITCH = 136;    // halfs per LDS row of the token-major staging tile [64][128 (+8 pad)]
-constexpr int GP = 129;          // float pitch of G in LDS: rows AND columns are bank-conflict-free
+constexpr int GP = GS_GP;        // float pitch of G in LDS: rows AND columns are bank-conflict-free
 
 __host__ __device__ constexpr int blk_index(int I, int J) {  // upper-triangular block (I <= J) -> 0..9
     return I * 4 - (I * (I - 1)) / 2 + (J - I);
@@ -157,154 +158,10 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
                 }
         }
     }
-    // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS
-    for (int i = tid; i < GD * RP; i += 256) {
-        int d = i / RP, c = i % RP;
-        Pa[i] = (c < r) ? P0[(bh * GD + d) * r + c] : 0.0f;
-    }
+    // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS (lowrank_solve.h)
     __syncthreads();
-    // Y = G X ([128][RP]).  Thread (d = tid / 2, h = tid & 1) accumulates the RP outputs of row d over half of the e range
-    // (e = (i & 31) + 64 (i >> 5) + 32 h: with the pitch of 129 floats the 64 lanes of a wave hit 64 different banks, for
-    // the direct access G[d][e] and for the mirrored one G[e][d] alike), then the two halves meet through DPP.
-    // One G read feeds RP FMAs (the first version spent two LDS reads per FMA and was LDS-bound).
-    auto matmulG = [&](const float* X, float* Y) {
-        const int d = tid >> 1, h = tid & 1;
-        const int dlow = d & ~31;        // e < dlow lies below the diagonal blocks
-        float acc[RP];
-#pragma unroll
-        for (int c = 0; c < RP; c++) acc[c] = 0.0f;
-#pragma unroll 4
-        for (int i = 0; i < 64; i++) {
-            const int e = (i & 31) + 64 * (i >> 5) + 32 * h;
-            const float g = (e < dlow) ? G[e * GP + d] : G[d * GP + e];
-#pragma unroll
-            for (int c4 = 0; c4 < RP; c4 += 4) {
-                const float4 xv = *(const float4*)&X[e * RP + c4];
-                acc[c4] = fmaf(g, xv.x, acc[c4]);
-                acc[c4 + 1] = fmaf(g, xv.y, acc[c4 + 1]);
-                acc[c4 + 2] = fmaf(g, xv.z, acc[c4 + 2]);
-                acc[c4 + 3] = fmaf(g, xv.w, acc[c4 + 3]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < RP; c++) acc[c] = GEAR_DPP_ADD(acc[c], 0xB1);   // + the partner lane (quad_perm xor 1)
-        if (h == 0) {
-#pragma unroll
-            for (int c4 = 0; c4 < RP; c4 += 4) *(float4*)&Y[d * RP + c4] = make_float4(acc[c4], acc[c4 + 1], acc[c4 + 2], acc[c4 + 3]);
-        }
-        __syncthreads();
-    };
-    // Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0.  Lane m of wave 0 owns column m of R and of
-    // R^-1 (the first version ran the whole factorisation on ONE thread: ~2500 dependent fp64 instructions with 44
-    // divisions / square roots, three times per head); the pivots' reciprocal square roots come from v_rsq_f64 + Newton.
-    auto chol_inverse = [&]() {
-        double* Rl = Rinv + RP * RP;   // R staged for the back substitution
-        if (tid < 64) {
-            const int m = lane;
-            double col[RP], rin[RP], rinvd[RP];
-            bool dead[RP];
-#pragma unroll
-            for (int j = 0; j < RP; j++) {
-                double sacc = (m < RP) ? Md[j * RP + m] : 0.0;
-#pragma unroll
-                for (int kk = 0; kk < RP; kk++) {
-                    if (kk < j) {
-                        const double rkj = __shfl(col[kk], j, 64);    // R[kk][j]
-                        sacc -= rkj * col[kk];
-                    }
-                }
-                const double dj = __shfl(sacc, j, 64), dg = Md[j * RP + j];
-                dead[j] = !(dj > 1e-12 * dg) || !(dg > 0.0);
-                double rs = 1.0;
-                if (!dead[j]) {
-                    rs = __builtin_amdgcn_rsq(dj);
-                    rs = rs * (1.5 - 0.5 * dj * rs * rs);
-                    rs = rs * (1.5 - 0.5 * dj * rs * rs);
-                }
-                rinvd[j] = dead[j] ? 0.0 : rs;
-                col[j] = (m == j) ? (dead[j] ? 1.0 : dj * rs) : ((m > j && !dead[j]) ? sacc * rs : 0.0);
-            }
-            if (m < RP) {
-#pragma unroll
-                for (int kk = 0; kk < RP; kk++) Rl[kk * RP + m] = col[kk];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            bool deadm = false;
-#pragma unroll
-            for (int j = 0; j < RP; j++) deadm = (m == j) ? dead[j] : deadm;
-            // column m of R^-1 by back substitution: Rinv[m][m] = 1 / R[m][m]; Rinv[i][m] = -(sum_{i<kk<=m} R[i][kk] Rinv[kk][m]) / R[i][i]
-#pragma unroll
-            for (int i = RP - 1; i >= 0; i--) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < RP; kk++)
-                    if (kk > i) sacc += Rl[i * RP + kk] * ((kk <= m) ? rin[kk] : 0.0);
-                rin[i] = (i == m) ? rinvd[i] : ((i < m && !deadm) ? -sacc * rinvd[i] : 0.0);
-            }
-            if (m < RP) {
-#pragma unroll
-                for (int i = 0; i < RP; i++) Rinv[i * RP + m] = rin[i];
-            }
-        }
-        __syncthreads();
-    };
-    auto gram_small = [&](const float* A, const float* B) {  // Md = A^T B  (fp64 accumulate), 4 lanes per output
-        for (int o = tid >> 2; o < RP * RP; o += 64) {
-            const int a = o / RP, b = o % RP, part = tid & 3;
-            double sacc = 0.0;
-#pragma unroll 8
-            for (int i = 0; i < GD / 4; i++) {
-                const int d = 4 * i + part;
-                sacc += (double)A[d * RP + a] * (double)B[d * RP + b];
-            }
-            sacc += __shfl_xor(sacc, 1, 64);
-            sacc += __shfl_xor(sacc, 2, 64);
-            if (part == 0) Md[o] = sacc;
-        }
-        __syncthreads();
-    };
-    auto apply_rinv = [&](const float* X, float* Y) {  // Y = X Rinv
-        for (int i = tid; i < GD * RP; i += 256) {
-            int d = i / RP, c = i % RP;
-            double s = 0.0;
-            for (int a = 0; a <= c; a++) s += (double)X[d * RP + a] * Rinv[a * RP + c];
-            Y[i] = (float)s;
-        }
-        __syncthreads();
-    };
-    float* cur = Pa;
-    float* oth = Pb;
-    for (int it = 0; it + 1 < loop; it++) {  // P <- G P, loop-1 times
-        matmulG(cur, oth);
-        float* t = cur; cur = oth; oth = t;
-    }
-    // P' = orth(P): CholeskyQR twice (fp64 Gram) -- stable for the column scaling power iteration produces
-    for (int rep = 0; rep < 2; rep++) {
-        gram_small(cur, cur);
-        chol_inverse();
-        apply_rinv(cur, oth);
-        float* t = cur; cur = oth; oth = t;
-    }
-    // T1 = G P' ; Q^T Q = P'^T T1 ; W = P' R^-1 ; P_out = T1 R^-1
-    matmulG(cur, oth);            // oth = T1
-    gram_small(cur, oth);
-    chol_inverse();
-    // write W (fp32, padded) and P_out
-    for (int i = tid; i < GD * RP; i += 256) {
-        int d = i / RP, c = i % RP;
-        double sw = 0.0, sp = 0.0;
-        for (int a = 0; a <= c; a++) {
-            sw += (double)cur[d * RP + a] * Rinv[a * RP + c];
-            sp += (double)oth[d * RP + a] * Rinv[a * RP + c];
-        }
-        Wout[(bh * GD + d) * RP + c] = (float)sw;
-        if (c < r) {
-            if (out_f16) ((uint16_t*)P_out)[(bh * GD + d) * r + c] = f2h_bits((float)sp);
-            else ((float*)P_out)[(bh * GD + d) * r + c] = (float)sp;
-        }
-    }
+    gram_solve_phase2<RP>(G, Pa, Pb, Md, Rinv, P0 + bh * GD * r, r, loop, Wout + bh * GD * RP,
+                          out_f16 ? (void*)((uint16_t*)P_out + bh * GD * r) : (void*)((float*)P_out + bh * GD * r), out_f16);
 }
 
 template <int N>
@@ -385,66 +242,17 @@ __global__ __launch_bounds__(256) void lr_qpass_kt_kernel(const uint16_t* __rest
     }
 }
 
-// token-major layout: E [bh][S][128].  16 lanes share a token row (8 channels per lane), W in registers.
-template <int RP>
-__global__ __launch_bounds__(256) void lr_qpass_tm_kernel(const uint16_t* __restrict__ E, const float* __restrict__ W,
-                                                          int S, int r, void* __restrict__ Q_out, int out_f16) {
-    const int64_t bh = blockIdx.y;
-    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const float* Wb = W + bh * GD * RP;
-    float wr[8][RP];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int c = 0; c < RP; c++) wr[i][c] = Wb[(l16 * 8 + i) * RP + c];
-    // all 8 row loads are issued up front; the 16-lane reductions run on DPP (no LDS crossbar)
-    uint4 raw[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = blockIdx.x * 128 + grp + 16 * i;
-        raw[i] = make_uint4(0, 0, 0, 0);
-        if (row < S) raw[i] = *(const uint4*)(E + (bh * S + row) * (int64_t)GD + l16 * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = blockIdx.x * 128 + grp + 16 * i;
-        float acc[RP], m[8];
-#pragma unroll
-        for (int c = 0; c < RP; c++) acc[c] = 0.0f;
-        unpack8(raw[i], m);
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int c = 0; c < RP; c++) acc[c] = fmaf(m[j], wr[j][c], acc[c]);
-#pragma unroll
-        for (int c = 0; c < RP; c++) acc[c] = row16_sum(acc[c]);
-        if (l16 == 0 && row < S) {
-            if (out_f16 && r == RP) {
-                store_halfs<RP>((uint16_t*)Q_out + (bh * S + row) * (int64_t)RP, acc);
-                continue;
-            }
-#pragma unroll
-            for (int c = 0; c < RP; c++) {
-                if (c < r) {
-                    int64_t o = (bh * S + row) * r + c;
-                    if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[c]);
-                    else ((float*)Q_out)[o] = acc[c];
-                }
-            }
-        }
-    }
-}
-
 // token-major layout on the matrix cores: Q'^T [c][token] = W^T [c][channel] . E^T [channel][token], one
 // v_mfma_f32_32x32x16_f16 tile = 32 tokens x (RP of 32 rows used).  The B operand of lane (token n, k-half) is 8
-// consecutive channels of ONE token row = one 16-byte global load (no LDS staging, no transpose); the 16-lane DPP
-// reductions and the 64 fp32 FMAs per row of the VALU kernel above (~110 VALU per 16 bytes) disappear.  W (fp32) is split
+// consecutive channels of ONE token row = one 16-byte global load (no LDS staging, no transpose); no 16-lane DPP
+// reductions, no fp32 FMAs on the vector ALU (a VALU version of this pass cost ~110 VALU per 16 bytes).  W (fp32) is split
 // into an fp16 head and an fp16 remainder (two MFMAs per k-step), which keeps ~22 bits of it.
 // C layout (lane l, register q): row (q & 3) + 8 (q >> 2) + 4 (l >> 5), column l & 31: a lane ends up with 4 consecutive
 // rank columns of its token = one 8-byte store.
 template <int RP>
 __global__ __launch_bounds__(256) void lr_qpass_tm_mfma_kernel(const uint16_t* __restrict__ E, const float* __restrict__ W,
-                                                               int S, int r, void* __restrict__ Q_out, int out_f16) {
+                                                               int S, int r, void* __restrict__ Q_out, int out_f16,
+                                                               int q_tcap, int q_toff) {
     constexpr int NT = 4;   // 32-token tiles per wave
     __shared__ __attribute__((aligned(16))) uint16_t Ah[16 * RP * 8], Al[16 * RP * 8];   // [k / 8][m][k % 8]
     const int64_t bh = blockIdx.y;
@@ -501,12 +309,12 @@ __global__ __launch_bounds__(256) void lr_qpass_tm_mfma_kernel(const uint16_t* _
                 uint2 v;
                 v.x = (uint32_t)f2h_bits(acc[4 * qb]) | ((uint32_t)f2h_bits(acc[4 * qb + 1]) << 16);
                 v.y = (uint32_t)f2h_bits(acc[4 * qb + 2]) | ((uint32_t)f2h_bits(acc[4 * qb + 3]) << 16);
-                *(uint2*)((uint16_t*)Q_out + (bh * S + token) * (int64_t)RP + c0) = v;
+                *(uint2*)((uint16_t*)Q_out + (bh * q_tcap + q_toff + token) * (int64_t)RP + c0) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     if (c0 + i < r) {
-                        const int64_t o = (bh * S + token) * r + c0 + i;
+                        const int64_t o = (bh * (int64_t)q_tcap + q_toff + token) * r + c0 + i;
                         if (out_f16) ((uint16_t*)Q_out)[o] = f2h_bits(acc[4 * qb + i]);
                         else ((float*)Q_out)[o] = acc[4 * qb + i];
                     }
@@ -531,12 +339,8 @@ int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int lo
         auto kfn = lr_gram_solve_kernel<RP, true>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16);
-        if (getenv("GEAR_QPASS_VALU"))
-            hipLaunchKernelGGL((lr_qpass_tm_kernel<RP>), dim3((S + 127) / 128, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
-                               Q_out, of16);
-        else
-            hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<RP>), dim3((S + 511) / 512, (unsigned)bh), dim3(256), 0, st, E, Wws, S,
-                               r, Q_out, of16);
+        hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<RP>), dim3((S + 511) / 512, (unsigned)bh), dim3(256), 0, st, E, Wws, S,
+                               r, Q_out, of16, S, 0);
     }
     GEAR_CHECK_LAUNCH("gear_lowrank(gram)");
     return 0;
@@ -552,4 +356,18 @@ int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, i
     if (RP == 4) return run_gram<4>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
     if (RP == 8) return run_gram<8>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
     return run_gram<16>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
+}
+
+// Q' = E W for a token-major fp16 error E [bh][S][128] with the token-side factor written at row q_toff of a [bh][q_tcap][r]
+// tensor (the streaming cache's layout); W fp32 [bh][128][RP] as gram_solve_phase2 leaves it.  Used by kfused.hip.
+int gear_qpass_tm(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_dtype, int q_tcap, int q_toff,
+                  hipStream_t st) {
+    const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
+    const int of16 = out_dtype == GEAR_DTYPE_F16;
+    const dim3 grid((S + 511) / 512, (unsigned)bh);
+    if (RP == 4) hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<4>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, of16, q_tcap, q_toff);
+    else if (RP == 8) hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<8>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, of16, q_tcap, q_toff);
+    else hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<16>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, of16, q_tcap, q_toff);
+    GEAR_CHECK_LAUNCH("gear_qpass_tm");
+    return 0;
 }

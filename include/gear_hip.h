@@ -42,6 +42,11 @@ extern "C" {
 /* Library / build identification. */
 const char* gear_last_error(void);
 int gear_abi_version(void);
+/* Run-time options: switches that select an alternative, equally exact code path (used by the tests to reach the
+ * paths ordinary inputs do not).  Names: "attn_generic", "lowrank_generic", "rows_hist_only", "rows_v1",
+ * "kfused_generic", "kselect_slow".  Each is also read once from the environment (GEAR_<NAME>) when the library is
+ * first used.  Returns 0, or -1 for an unknown name. */
+int gear_set_option(const char* name, int value);
 
 /* ---- a1 / a2 / a3(V): group quantize + bit-pack along the last dim ------------------------------------
  * Replaces triton_quantize_and_pack_along_last_dim (cuda_supported_gear/quant/new_pack.py:217-250),
@@ -107,6 +112,32 @@ int gear_gemv_outer(const void* a, const void* qB, const void* scale, const void
 int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride,
                        int nseg, int seglen, int64_t seg_stride, int group, int bits, int mode, int k, void* code,
                        void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, void* stream);
+
+/* ---- a5 / a11 (K side) fused: token-major K -> complete K payload, no transpose, no K^T intermediates ------------------
+ * Replaces, for head_dim 128, the chain  key.transpose(2, 3).contiguous()  (cuda_supported_gear/modeling_llamagear.py:268,
+ * :403) -> gears_channelQ (GenerationBench/.../Simulated/compress_function.py:261-296) -> fake_poweriteration_group
+ * (:69-98) / key_compression (modeling_llamagear.py:23-38):  per-channel outlier selection over the T tokens, mean fill,
+ * group quantization along T, bit-packing into the channel-major K^T payload layout, the fp16 error and its rank-r
+ * power iteration -- in four launches (select, fused quantize + pack + error + Gram on the matrix cores, per-head solve,
+ * Q pass) that read x three times and write the error once (the round-1 chain moved 12.6 bytes per element, this 8.3).
+ *   x     fp16 [BH, T, 128] token-major                       T % 64 == 0, 64 <= T <= 16384; group in {32, 64}; bits in {2, 4}
+ *   code  int32 [BH, 128, ldc]   words  t_off / fpi ..  of every channel row are written (ldc = row pitch in words)
+ *   scale, mn [BH, 128, lds]     fp16 (mode 0) / float (mode 1), groups t_off / group ..
+ *   k     outliers per side per channel row (0: none).  oidx / oval uint16 / fp16 [BH, 128, 2, kcap]: side slot 0 = the k
+ *         smallest, slot 1 = the k largest, each ascending by token, written at list position o_off ..; the stored token
+ *         index is t_off + t.  Ties at the selection boundary: lower token first (as gear_compress_rows).
+ *   rank  0: no low-rank part.  P0 float [BH, 128, rank]; P_out fp16, head bh at element offset
+ *         (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * rank;  Q_out fp16 [BH, q_tcap, rank], rows q_toff ..
+ *   variant: bit 0 = element-by-element tile arithmetic, bit 1 = always the exact slow selection (cross-checks)
+ *   workspace: gear_compress_key_fused_workspace(BH, T, k, rank) bytes of device scratch.
+ * With t_off / ldc / lds / q_tcap / kcap the call appends a block to a pre-allocated streaming cache in place.
+ */
+size_t gear_compress_key_fused_workspace(int64_t BH, int T, int k, int rank);
+int gear_compress_key_fused(const void* x, int64_t BH, int T, int group, int bits, int mode, int k, void* code, void* scale,
+                            void* mn, int64_t ldc, int64_t lds, int t_off, int rank, int loop, const void* P0, void* P_out,
+                            int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, void* oidx,
+                            void* oval, int kcap, int o_off, int variant, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* ---- a4 / a10: low-rank power iteration ---------------------------------------------------------------------
  * Replaces headwise_lrap (cuda_supported_gear/quant/new_pack.py:291-311) and fake_poweriteration_group

@@ -47,13 +47,23 @@ def _ref_attn(q, K, V, kw, vw, n_rep):
     return np.einsum("bht,bhtd->bhd", a, V)[:, :, None]
 
 
+@pytest.fixture
+def attn_option():
+    """Select the generic (variable-chunk) decode-attention kernel for one test; always restored."""
+    from gear_amd import _lib as L
+
+    def setter(on):
+        L.set_option("attn_generic", 1 if on else 0)
+    yield setter
+    L.set_option("attn_generic", 0)
+
+
 @pytest.mark.parametrize("method,bits,Hq,Hkv,T0", [("gearlKIVI", 2, 4, 4, 200), ("gearlKIVI", 4, 4, 2, 64), ("KIVI", 2, 2, 2, 30),
                                                    ("gearlKIVI", 2, 2, 2, 2304)])
 @pytest.mark.parametrize("kernel", ["planned", "generic"])
-def test_cache_attend_matches_reconstruction(monkeypatch, kernel, method, bits, Hq, Hkv, T0):
+def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, Hq, Hkv, T0):
     from gear_amd.cache import GearKVCache
-    if kernel == "generic":
-        monkeypatch.setenv("GEAR_ATTN_GENERIC", "1")
+    attn_option(kernel == "generic")
     torch.manual_seed(71)
     cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
     B, D, steps = 2, 128, 150

@@ -74,12 +74,13 @@ CASES = [
 
 
 @pytest.fixture(params=["planned", "generic"])
-def attn_kernel(request, monkeypatch):
+def attn_kernel(request):
     """planned: contexts <= 8k run the 128-token-chunk kernel (every load issued up front); generic: force the
     variable-chunk kernel that longer contexts use, on the same cases."""
-    if request.param == "generic":
-        monkeypatch.setenv("GEAR_ATTN_GENERIC", "1")
-    return request.param
+    from gear_amd import _lib as L
+    L.set_option("attn_generic", 1 if request.param == "generic" else 0)
+    yield request.param
+    L.set_option("attn_generic", 0)
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,T,W,bits,mode,rank,k_out", CASES + [(1, 2, 1, 8320, 3, 2, "fp32", 8, 20),
