@@ -27,6 +27,8 @@ import torch
 from . import _lib as L
 
 _MODES = {"fp16": 0, "fp32": 1, 0: 0, 1: 1}
+# A/B switch for measurements (read once at import): GEAR_KEY_PATH=rows routes compress_key(path="auto") to the round-1 chain
+_KEY_PATH_DEFAULT = os.environ.get("GEAR_KEY_PATH", "auto")
 
 
 @dataclass
@@ -316,6 +318,8 @@ def compress_key(k: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: i
     shape allows it (head_dim 128, T % 64 == 0, group 32 / 64), otherwise -- or with path "rows" -- the round-1 chain
     K^T re-layout -> row compressor -> Gram -> Q pass; "fused" insists on the fused path."""
     assert path in ("auto", "rows", "fused")
+    if path == "auto" and _KEY_PATH_DEFAULT != "auto":
+        path = _KEY_PATH_DEFAULT
     B, H, T, D = k.shape
     if path == "fused" or (path == "auto" and key_fused_supported(T, D, group, bits, k_out)):
         return compress_key_fused(k, bits, group, k_out, rank, loop, mode, P0)

@@ -38,6 +38,7 @@ struct GearOptions {
     int rows_v1;           // row compressor: first-generation kernel also for fp32 arithmetic (cross-check)
     int kfused_generic;    // fused K path: the element-by-element tile body instead of the packed one
     int kselect_slow;      // fused K path: always the exact slow selection (no candidate lists)
+    int kfused_no_tr;      // fused K path: 16-bit LDS reads for the MFMA operands instead of ds_read_b64_tr_b16
 };
 GearOptions& gear_options();
 

@@ -43,8 +43,10 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 
 constexpr int KD = 128;          // head_dim
 constexpr int KS_CAP = 160;      // candidate slots per (channel, side) list
+constexpr int KS_STRIDE = 164;   // words between lists in LDS: 4 words of skew keep the quad-per-list reads conflict-free
 constexpr int KS_B = 8;          // words per candidate batch
-constexpr int ET_PITCH = 136;    // halfs per LDS row of a wave's error tile [64 tokens][128 channels (+8 pad)]
+constexpr int ET_PITCH = 144;    // halfs per LDS row of an error tile [64 tokens][128 channels (+16 pad)]: 72 words, so the
+                                 // 4 token rows x 4 x 8 bytes a 16-lane group gathers for ds_read_b64_tr_b16 hit 32 different banks
 
 __device__ __forceinline__ uint32_t sort_key16(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit); -0 == +0
     if (hbits == 0x8000u) hbits = 0u;
@@ -54,6 +56,43 @@ __device__ __forceinline__ uint32_t sort_key16(uint32_t hbits) {  // fp16 bits -
 __device__ __forceinline__ uint32_t order_key(uint32_t hbits, int side) {
     const uint32_t kx = sort_key16(hbits);
     return side == 0 ? kx : 0xFFFFu - kx;
+}
+
+__device__ __forceinline__ uint32_t vbfi(uint32_t m, uint32_t a, uint32_t bb) {   // (a & m) | (bb & ~m)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmin16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmax16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ float fmin_raw(float a, float bb) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ float fmax_raw(float a, float bb) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkminu16(uint32_t a, uint32_t bb) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
+    return r;
+}
+// sum over the 4 lanes of a DPP quad, result in all four (quad_perm xor 1, xor 2)
+__device__ __forceinline__ int quad_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    return v;
 }
 
 // ================================================================================================ select
@@ -83,17 +122,19 @@ struct SelArgs {
     uint16_t* oidx;         // [BH][128][2][kcap]: side slot 0 = the k smallest, 1 = the k largest, each ascending by token
     uint16_t* oval;
     int kcap, o_off, tok_base;
+    uint32_t* todo_cnt;     // lists the candidate path could not decide (count outside [k, KS_CAP]): handled by k_select_fix_kernel
+    uint32_t* todo;         // [BH * 256] entries (bh * 128 + channel) * 2 + side
 };
 
 __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
-    // dynamic LDS: cand [64 lists][KS_CAP] | cnt [64] | scratch (phase A: stat [16][16][4] floats; phase B: stash
+    // dynamic LDS: cand [64 lists][KS_STRIDE] | cnt [64] | kthr [64] | scratch (phase A: stat [16][16][4] floats; phase B: stash
     // [256][KS_B]; phase C: per wave 2 bitmaps + 1 prefix array of T/32 words)
     extern __shared__ __attribute__((aligned(16))) uint32_t sl[];
     uint32_t* cand = sl;
-    uint32_t* cnt = sl + 64 * KS_CAP;
-    uint32_t* scr = cnt + 64;
+    uint32_t* cnt = sl + 64 * KS_STRIDE;
+    uint32_t* kthr = cnt + 64;        // per list: composite threshold of the fast path (0: take the slow path)
+    uint32_t* scr = kthr + 64;
     __shared__ uint32_t thr_lds[32];
-    __shared__ float sum_lds[16][32];
 
     int q;
     int64_t bh;
@@ -108,21 +149,23 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     // ---------------------------------------------------------------- phase A: sample statistics -> threshold guess
     {
         float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
-        int ns = 0;
-        for (int i = 0; i < per_stream; i += a.sstride) {
-            const int t = s + 16 * i;
-            if (t < T) {
-                const uint32_t w = xw[(int64_t)t * 64];
-                const float f0 = h2f_bits((uint16_t)(w & 0xFFFFu)), f1 = h2f_bits((uint16_t)(w >> 16));
+        for (int i0 = 0; i0 < per_stream; i0 += 8 * a.sstride) {      // 8 sampled tokens per trip: their loads fly together
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * a.sstride, t = s + 16 * i;
+                w[j] = (i < per_stream && t < T) ? xw[(int64_t)t * 64] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float f0 = h2f_bits((uint16_t)(w[j] & 0xFFFFu)), f1 = h2f_bits((uint16_t)(w[j] >> 16));
                 s1a += f0; s2a = fmaf(f0, f0, s2a);
                 s1b += f1; s2b = fmaf(f1, f1, s2b);
-                ns++;
             }
         }
         float* stat = (float*)scr;                                   // [16 streams][16 pairs][4]
         *(float4*)&stat[(s * 16 + c2) * 4] = make_float4(s1a, s2a, s1b, s2b);
         if (tid < 64) cnt[tid] = 0u;
-        if (tid == 0) sum_lds[0][0] = 0.f;
         __syncthreads();
         if (tid < 32) {
             const int pr = tid >> 1, h = tid & 1;
@@ -140,10 +183,12 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
             const float rn = 1.0f / (float)max(n, 1);
             const float mean = t1 * rn;
             const float sd = sqrtf(fmaxf(t2 * rn - mean * mean, 0.0f));
-            const uint32_t th = f2h_bits(mean + a.zthr * sd), tl = f2h_bits(mean - a.zthr * sd);
+            uint32_t th = f2h_bits(mean + a.zthr * sd), tl = f2h_bits(mean - a.zthr * sd);
+            // never +-0: then clamp(x) != x happens only for x strictly outside [tl, th] (no -0 / +0 artefacts)
+            if ((th & 0x7FFFu) == 0u) th = 0x0001u;
+            if ((tl & 0x7FFFu) == 0u) tl = 0x8001u;
             thr_lds[tid] = th | (tl << 16);
         }
-        (void)ns;
         __syncthreads();
     }
     const uint32_t tw0 = thr_lds[2 * c2], tw1 = thr_lds[2 * c2 + 1];
@@ -151,10 +196,17 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     const half2v tlo2 = __builtin_bit_cast(half2v, (tw0 >> 16) | (tw1 & 0xFFFF0000u));
 
     // ---------------------------------------------------------------- phase B: stream every token once
+    // Row sums in fp32 (exact products on v_dot2, fp32 accumulate; the reference's own torch.mean is an fp32 reduction too).
+    // Candidates: x outside [tlo, thi] <=> clamp(x) != x -- two packed min / max, one xor, one packed "min(d, 1)" per word
+    // give a per-lane bit mask (bit 7-j: word j low half, bit 23-j: high half); the lanes then walk their set bits.
     float suma = 0.f, sumb = 0.f;
     {
         const half2v sel_a = {(_Float16)1.0f, (_Float16)0.0f}, sel_b = {(_Float16)0.0f, (_Float16)1.0f};
-        uint32_t* stash = scr + tid * KS_B;
+        const uint32_t thi_u = __builtin_bit_cast(uint32_t, thi2), tlo_u = __builtin_bit_cast(uint32_t, tlo2);
+        const float tloA = h2f_bits((uint16_t)(tlo_u & 0xFFFFu)), tloB = h2f_bits((uint16_t)(tlo_u >> 16));
+        uint32_t* stash = scr + tid;                                                  // word j of this lane: stash[j * 256]
+        // LDS byte offsets (from cnt) of the lane's four lists: [half][side] -> counter, candidate region
+        const uint32_t l0 = (uint32_t)(2 * c2) * 2u;
         const int nb = (per_stream + KS_B - 1) / KS_B;
         uint32_t cur[KS_B], nxt[KS_B];
         auto load_batch = [&](int b, uint32_t (&dst)[KS_B]) {
@@ -167,62 +219,94 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         load_batch(0, cur);
         for (int b = 0; b < nb; b++) {
             if (b + 1 < nb) load_batch(b + 1, nxt);
-            uint32_t sg_hi = 0u, sg_lo = 0u;
+            uint32_t m = 0u;
 #pragma unroll
             for (int j = 0; j < KS_B; j++) {
                 const half2v xv = __builtin_bit_cast(half2v, cur[j]);
                 suma = __builtin_amdgcn_fdot2(xv, sel_a, suma, false);
                 sumb = __builtin_amdgcn_fdot2(xv, sel_b, sumb, false);
-                const uint32_t dh = __builtin_bit_cast(uint32_t, (half2v)(xv - thi2));   // sign clear: x >= thi
-                const uint32_t dl = __builtin_bit_cast(uint32_t, (half2v)(tlo2 - xv));   // sign clear: x <= tlo
-                sg_hi |= (dh & 0x80008000u) >> j;
-                sg_lo |= (dl & 0x80008000u) >> j;
-                stash[j] = cur[j];
+                const uint32_t cl = pkmin16(pkmax16(cur[j], tlo_u), thi_u);
+                m = (m << 1) | pkminu16(cl ^ cur[j], 0x00010001u);
+                stash[j * 256] = cur[j];
             }
-            // bit 15-j <-> (word j, low half = even channel), bit 31-j <-> (word j, high half); words past T are masked
-            uint32_t valid = 0u;
-#pragma unroll
-            for (int j = 0; j < KS_B; j++)
-                if (s + 16 * (b * KS_B + j) < T) valid |= 0x80008000u >> j;
-            uint32_t mh = ~sg_hi & valid, ml = ~sg_lo & valid;
-            for (int side = 0; side < 2; side++) {
-                uint32_t msk = side == 0 ? mh : ml;
-                while (msk) {
-                    const int p = 31 - __clz(msk);                  // highest set bit first
-                    msk &= ~(1u << p);
-                    const int half = p >> 4, j = 15 - (p & 15);
-                    const uint32_t bits = (stash[j] >> (16 * half)) & 0xFFFFu;
-                    const int t = s + 16 * (b * KS_B + j);
-                    const int list = (2 * c2 + half) * 2 + side;
-                    const uint32_t slot = atomicAdd(&cnt[list], 1u);
-                    if (slot < (uint32_t)KS_CAP) cand[list * KS_CAP + slot] = (bits << 16) | (uint32_t)t;
-                }
+            const int nv = min(KS_B, per_stream - b * KS_B);                       // valid words of this batch (T % 16 == 0)
+            m &= ((0xFFu << (KS_B - nv)) & 0xFFu) * 0x00010001u;
+            const int tb0 = s + 16 * (b * KS_B + KS_B - 1);                         // token of word j: tb0 - 16 (p & 15)
+            while (m) {
+                const int p = 31 - __clz(m);
+                m &= ~(1u << p);
+                const int half = p >> 4, jr = p & 15;                               // word j = KS_B - 1 - jr
+                const uint32_t bits = (stash[(KS_B - 1 - jr) * 256] >> (16 * half)) & 0xFFFFu;
+                const bool is_lo = h2f_bits((uint16_t)bits) < (half ? tloB : tloA); // outside [tlo, thi] and not below: above
+                const uint32_t list = l0 + 2u * (uint32_t)half + (is_lo ? 1u : 0u);
+                const uint32_t slot = atomicAdd(&cnt[list], 1u);
+                if (slot < (uint32_t)KS_CAP) cand[list * KS_STRIDE + slot] = (bits << 16) | (uint32_t)(tb0 - 16 * jr);
             }
 #pragma unroll
             for (int j = 0; j < KS_B; j++) cur[j] = nxt[j];
         }
     }
-    sum_lds[s][2 * c2] = suma;
-    sum_lds[s][2 * c2 + 1] = sumb;
+    __syncthreads();                                   // the stash is dead: its space takes the 16 streams' partial sums
+    float* sum_lds = (float*)scr;                      // [16][32]
+    sum_lds[s * 32 + 2 * c2] = suma;
+    sum_lds[s * 32 + 2 * c2 + 1] = sumb;
     __syncthreads();
     if (tid < 32) {
         float tot = 0.f;
-        for (int st = 0; st < 16; st++) tot += sum_lds[st][tid];
-        const float mean = ((T & (T - 1)) == 0) ? tot * a.rlen : tot / (float)T;
-        a.omean[bh * KD + 32 * q + tid] = mean;
+        for (int st = 0; st < 16; st++) tot += sum_lds[st * 32 + tid];
+        a.omean[bh * KD + 32 * q + tid] = ((T & (T - 1)) == 0) ? tot * a.rlen : tot / (float)T;
     }
     if (k <= 0) return;
+    __syncthreads();                                   // (phase C reuses the scratch area)
 
-    // ---------------------------------------------------------------- phase C: exact selection, one wave per channel
+    // ---------------------------------------------------------------- phase C.1: the threshold of every list at once
+    // One DPP quad per list (16 lists per wave, 64 per workgroup): lane i4 of the quad holds candidates i4, i4 + 4, ... as
+    // composite keys (16-bit order key of the value, then 14 bits "earlier token first"), unique per list, and the quad finds
+    // the k-th largest by 31 rounds of bisection -- compare + add-with-carry per candidate, two DPP adds per round, no
+    // scalar dependency chain.  A list whose count is outside [k, KS_CAP] is left to the exact slow path below.
+    {
+        const int L = 16 * wave + (lane >> 2), i4 = lane & 3, side = L & 1;
+        const int n = (int)cnt[L];
+        const bool fast = n >= k && n <= KS_CAP;
+        int jm = fast ? (n + 3) >> 2 : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) jm = max(jm, __shfl_xor(jm, d, 64));
+        jm = __builtin_amdgcn_readfirstlane(jm);                                   // candidates per lane, max over the wave
+        uint32_t key[KS_CAP / 4];
+#pragma unroll
+        for (int j = 0; j < KS_CAP / 4; j++) {
+            const int g = i4 + 4 * j;
+            uint32_t c = 0u;
+            if (fast && g < n) c = cand[L * KS_STRIDE + g];
+            key[j] = (fast && g < n) ? (((order_key(c >> 16, side) << 14) | (0x3FFFu - (c & 0x3FFFu))) + 1u) : 0u;
+        }
+        uint32_t lo_b = 1u, hi_b = 0x40000000u;                                    // largest K with count(key >= K) >= k
+        for (int it = 0; it < 31; it++) {
+            const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int blk = 0; blk < KS_CAP / 32; blk++) {
+                if (blk * 8 < jm) {
+#pragma unroll
+                    for (int j = blk * 8; j < blk * 8 + 8; j++) c += (key[j] >= mid) ? 1 : 0;
+                }
+            }
+            c = quad_sum_i32(c);
+            const bool take = c >= k;
+            lo_b = take ? mid : lo_b;
+            hi_b = take ? hi_b : mid - 1u;
+        }
+        if (i4 == 0) kthr[L] = fast ? lo_b : 0u;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- phase C.2: outputs, one wave per channel
     const int nwords = (T + 31) >> 5;
     uint32_t* bmA = scr + wave * 3 * nwords;       // side 0 (large) bitmap of the current channel
     uint32_t* bmB = bmA + nwords;                  // side 1 (small)
     uint32_t* pfx = bmB + nwords;                  // exclusive prefix popcount per word (one side at a time)
     const int wpl = (nwords + 63) >> 6;            // bitmap words per lane
-    const unsigned long long lt = (1ull << lane) - 1ull;
     for (int lch = wave; lch < 32; lch += 4) {
         const int ch = 32 * q + lch;
-        const uint16_t* xc = a.x + bh * (int64_t)T * KD + ch;       // + t * 128
         for (int i = 0; i < wpl; i++) {
             const int w = lane * wpl + i;
             if (w < nwords) { bmA[w] = 0u; bmB[w] = 0u; }
@@ -233,82 +317,26 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
             uint32_t* bm = side == 0 ? bmA : bmB;
             const int list = lch * 2 + side;
             const int n = __builtin_amdgcn_readfirstlane((int)cnt[list]);
-            const bool fast = n >= k && n <= KS_CAP;
-            uint32_t cv[3] = {0u, 0u, 0u}, kx[3] = {0u, 0u, 0u};    // candidate (bits << 16 | t), order key + 1 (0 = none)
+            const uint32_t kt = (uint32_t)__builtin_amdgcn_readfirstlane((int)kthr[list]);
+            const bool fast = kt != 0u;
+            uint32_t cv[3] = {0u, 0u, 0u};                           // candidate (bits << 16 | t)
             bool sel[3] = {false, false, false};
-            uint32_t vstar = 0u;
-            int need = 0;
             if (fast) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     const int g = lane + 64 * i;
                     if (g < n) {
-                        cv[i] = cand[list * KS_CAP + g];
-                        kx[i] = order_key(cv[i] >> 16, side) + 1u;
+                        cv[i] = cand[list * KS_STRIDE + g];
+                        const uint32_t kx = ((order_key(cv[i] >> 16, side) << 14) | (0x3FFFu - (cv[i] & 0x3FFFu))) + 1u;
+                        sel[i] = kx >= kt;
+                        if (sel[i]) atomicOr(&bm[(cv[i] & 0xFFFFu) >> 5], 1u << (cv[i] & 31u));
                     }
                 }
-                uint32_t lo_b = 1u, hi_b = 0x10000u;               // largest V with count(key >= V) >= k (count(>= 1) = n >= k)
-                for (int it = 0; it < 17; it++) {
-                    const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
-                    const int c = __popcll(__ballot(kx[0] >= mid)) + __popcll(__ballot(kx[1] >= mid)) + __popcll(__ballot(kx[2] >= mid));
-                    if (c >= k) lo_b = mid; else hi_b = mid - 1u;
-                }
-                vstar = lo_b;
-                const int above = __popcll(__ballot(kx[0] > vstar)) + __popcll(__ballot(kx[1] > vstar)) + __popcll(__ballot(kx[2] > vstar));
-                need = k - above;
-                const bool e0 = kx[0] == vstar, e1 = kx[1] == vstar, e2 = kx[2] == vstar;
-                const int neq = __popcll(__ballot(e0)) + __popcll(__ballot(e1)) + __popcll(__ballot(e2));
-                uint32_t tmax = 0xFFFFu;                           // ties: the `need` lowest tokens
-                if (neq > need) {
-                    const uint32_t t0 = e0 ? (cv[0] & 0xFFFFu) : 0xFFFFFFFFu, t1 = e1 ? (cv[1] & 0xFFFFu) : 0xFFFFFFFFu,
-                                   t2 = e2 ? (cv[2] & 0xFFFFu) : 0xFFFFFFFFu;
-                    uint32_t lo_t = 0u, hi_t = 0xFFFFu;            // smallest Tt with count(tie && t <= Tt) >= need
-                    for (int it = 0; it < 16; it++) {
-                        const uint32_t mid = (lo_t + hi_t) >> 1;
-                        const int c = __popcll(__ballot(t0 <= mid)) + __popcll(__ballot(t1 <= mid)) + __popcll(__ballot(t2 <= mid));
-                        if (c >= need) hi_t = mid; else lo_t = mid + 1u;
-                    }
-                    tmax = hi_t;
-                }
-                sel[0] = kx[0] > vstar || (e0 && (cv[0] & 0xFFFFu) <= tmax);
-                sel[1] = kx[1] > vstar || (e1 && (cv[1] & 0xFFFFu) <= tmax);
-                sel[2] = kx[2] > vstar || (e2 && (cv[2] & 0xFFFFu) <= tmax);
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-                    if (sel[i]) atomicOr(&bm[(cv[i] & 0xFFFFu) >> 5], 1u << (cv[i] & 31u));
             } else {
-                // exact slow path (threshold guess missed, list overflow, k > what the candidate lists hold): bisection on
-                // the value key with one pass over the channel's column per round
-                uint32_t lo_b = 1u, hi_b = 0x10000u;
-                for (int it = 0; it < 17; it++) {
-                    const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
-                    int c = 0;
-                    for (int tb = 0; tb < T; tb += 64) {
-                        const int t = tb + lane;
-                        const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
-                        c += __popcll(__ballot(kk >= mid));
-                    }
-                    if (c >= k) lo_b = mid; else hi_b = mid - 1u;
-                }
-                vstar = lo_b;
-                int above = 0;
-                for (int tb = 0; tb < T; tb += 64) {
-                    const int t = tb + lane;
-                    const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
-                    above += __popcll(__ballot(kk > vstar));
-                }
-                need = k - above;
-                int taken = 0;                                      // ties taken so far, in token order
-                for (int tb = 0; tb < T; tb += 64) {
-                    const int t = tb + lane;
-                    const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
-                    const bool eq = kk == vstar;
-                    const unsigned long long be = __ballot(eq);
-                    const bool sl_ = kk > vstar || (eq && taken + __popcll(be & lt) < need);
-                    const unsigned long long bs = __ballot(sl_);
-                    if (lane == 0) { bm[tb >> 5] = (uint32_t)bs; if (tb + 32 < T) bm[(tb >> 5) + 1] = (uint32_t)(bs >> 32); }
-                    taken += __popcll(be);
-                }
+                // threshold guess missed, list overflow or k beyond what the lists hold: this (channel, side) goes to the exact
+                // slow selection of k_select_fix_kernel (which also ORs its bits into the channel's bitmap)
+                if (lane == 0) a.todo[atomicAdd(a.todo_cnt, 1u)] = (uint32_t)((bh * KD + ch) * 2 + side);
+                continue;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -328,7 +356,7 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const int64_t lbase = ((bh * KD + ch) * 2 + (side == 0 ? 1 : 0)) * (int64_t)a.kcap + a.o_off;
-            if (fast) {
+            {
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     if (sel[i]) {
@@ -336,15 +364,6 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
                         const uint32_t r = pfx[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
                         a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
                         a.oval[lbase + r] = (uint16_t)(cv[i] >> 16);
-                    }
-                }
-            } else {
-                for (int tb = 0; tb < T; tb += 64) {
-                    const uint32_t t = tb + lane;
-                    if ((int)t < T && ((bm[t >> 5] >> (t & 31u)) & 1u)) {
-                        const uint32_t r = pfx[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
-                        a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
-                        a.oval[lbase + r] = xc[(int64_t)t * KD];
                     }
                 }
             }
@@ -360,32 +379,106 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     }
 }
 
+// The lists k_select_kernel could not decide: exact selection over the channel's whole column, one wave per list.  Bisection
+// on the 16-bit order key (17 rounds), then one pass in token order that takes everything above the threshold value plus the
+// first `need` ties, writes the sorted list and ORs the bits into the channel's bitmap.  T <= 4096: the column's keys are
+// gathered once into registers; longer columns are re-read every round (they come from L2).
+__global__ __launch_bounds__(256) void k_select_fix_kernel(SelArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t ntodo = *a.todo_cnt;
+    const int T = a.T, k = a.k, ntiles = (T + 63) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < ntodo; w += gridDim.x * 4) {
+        const uint32_t e = a.todo[w];
+        const int side = e & 1, ch = (e >> 1) & 127;
+        const int64_t bh = e >> 8;
+        const uint16_t* xc = a.x + bh * (int64_t)T * KD + ch;       // + t * 128
+        const int64_t lbase = ((bh * KD + ch) * 2 + (side == 0 ? 1 : 0)) * (int64_t)a.kcap + a.o_off;
+        uint32_t* ob = a.obits + ((bh * ntiles) * KD + ch) * 2;     // + tile * 256 words
+        if (T <= 4096) {
+            uint32_t kv[64];
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                const int t = 64 * i + lane;
+                kv[i] = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+            }
+            uint32_t lo_b = 1u, hi_b = 0x10000u;
+            for (int it = 0; it < 17; it++) {
+                const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < 64; i++) c += (kv[i] >= mid) ? 1 : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+                if (c >= k) lo_b = mid; else hi_b = mid - 1u;
+            }
+            const uint32_t vstar = lo_b;
+            int above = 0;
+#pragma unroll
+            for (int i = 0; i < 64; i++) above += (kv[i] > vstar) ? 1 : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d, 64);
+            const int need = k - above;
+            int taken = 0, pos = 0;
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                if (64 * i < T) {
+                    const bool eq = kv[i] == vstar;
+                    const unsigned long long be = __ballot(eq);
+                    const bool sl_ = kv[i] > vstar || (eq && taken + __popcll(be & lt) < need);
+                    const unsigned long long bs = __ballot(sl_);
+                    if (sl_) {
+                        const int t = 64 * i + lane, r = pos + __popcll(bs & lt);
+                        a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
+                        a.oval[lbase + r] = xc[(int64_t)t * KD];
+                    }
+                    if (bs && lane < 2) atomicOr(&ob[i * (KD * 2) + lane], lane ? (uint32_t)(bs >> 32) : (uint32_t)bs);
+                    taken += __popcll(be);
+                    pos += __popcll(bs);
+                }
+            }
+        } else {
+            uint32_t lo_b = 1u, hi_b = 0x10000u;
+            for (int it = 0; it < 17; it++) {
+                const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                int c = 0;
+                for (int tb = 0; tb < T; tb += 64) {
+                    const int t = tb + lane;
+                    const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+                    c += __popcll(__ballot(kk >= mid));
+                }
+                if (c >= k) lo_b = mid; else hi_b = mid - 1u;
+            }
+            const uint32_t vstar = lo_b;
+            int above = 0;
+            for (int tb = 0; tb < T; tb += 64) {
+                const int t = tb + lane;
+                const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+                above += __popcll(__ballot(kk > vstar));
+            }
+            const int need = k - above;
+            int taken = 0, pos = 0;
+            for (int tb = 0; tb < T; tb += 64) {
+                const int t = tb + lane;
+                const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+                const bool eq = kk == vstar;
+                const unsigned long long be = __ballot(eq);
+                const bool sl_ = kk > vstar || (eq && taken + __popcll(be & lt) < need);
+                const unsigned long long bs = __ballot(sl_);
+                if (sl_) {
+                    const int r = pos + __popcll(bs & lt);
+                    a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
+                    a.oval[lbase + r] = xc[(int64_t)t * KD];
+                }
+                if (bs && lane < 2) atomicOr(&ob[(tb >> 6) * (KD * 2) + lane], lane ? (uint32_t)(bs >> 32) : (uint32_t)bs);
+                taken += __popcll(be);
+                pos += __popcll(bs);
+            }
+        }
+    }
+}
+
 // ================================================================================================ main
-__device__ __forceinline__ uint32_t vbfi(uint32_t m, uint32_t a, uint32_t bb) {   // (a & m) | (bb & ~m)
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(bb));
-    return r;
-}
-__device__ __forceinline__ uint32_t pkmin16(uint32_t a, uint32_t bb) {
-    uint32_t r;
-    asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
-    return r;
-}
-__device__ __forceinline__ uint32_t pkmax16(uint32_t a, uint32_t bb) {
-    uint32_t r;
-    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
-    return r;
-}
-__device__ __forceinline__ float fmin_raw(float a, float bb) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
-    return r;
-}
-__device__ __forceinline__ float fmax_raw(float a, float bb) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb));
-    return r;
-}
 // float(half HI ? high : low of w) + addend (the convert is exact: one rounding)
 template <int HI>
 __device__ __forceinline__ float add_mix(uint32_t w, float one, float addend) {
@@ -600,24 +693,93 @@ __host__ __device__ constexpr int blk_index(int I, int J) {  // upper-triangular
     return I * 4 - (I * (I - 1)) / 2 + (J - I);
 }
 
-// grid (nslab, BH), 256 threads = 4 waves, each wave walks its own tiles of the slab.
-template <int BITS, int MODE, int G, typename ST, bool FAST, bool LR>
-__global__ __launch_bounds__(256, 1) void k_main_kernel(MainArgs a) {
+// Which 32x32 blocks of the (block-upper-triangular) Gram matrix a wave accumulates, and which operand sets it needs.
+// w0: (0,0) (0,1) (1,1)   w1: (2,2) (2,3) (3,3)   w2: (0,2) (0,3)   w3: (1,2) (1,3)     -- 10 operand-set reads per k-step
+template <int W> struct WaveBlocks;
+template <> struct WaveBlocks<0> { static constexpr int n = 3; static constexpr int I[3] = {0, 0, 1}, J[3] = {0, 1, 1}; static constexpr int need = 0x3; };
+template <> struct WaveBlocks<1> { static constexpr int n = 3; static constexpr int I[3] = {2, 2, 3}, J[3] = {2, 3, 3}; static constexpr int need = 0xC; };
+template <> struct WaveBlocks<2> { static constexpr int n = 2; static constexpr int I[3] = {0, 0, 0}, J[3] = {2, 3, 3}; static constexpr int need = 0xD; };
+template <> struct WaveBlocks<3> { static constexpr int n = 2; static constexpr int I[3] = {1, 1, 1}, J[3] = {2, 3, 3}; static constexpr int need = 0xE; };
+
+// MFMA operand of lane (x31 = lane & 31, kg = lane >> 5): channel 32 I + x31, tokens t0 + 8 kg .. + 7 of an error tile
+// [64 tokens][ET_PITCH] in LDS.  TR: two ds_read_b64_tr_b16 -- inside a 16-lane group lane i supplies the address of 4
+// consecutive channels of token row i / 4 and receives column i of the [4 tokens][16 channels] block (the hardware's 4x4
+// transpose); otherwise eight 16-bit reads.
+template <bool TR>
+__device__ __forceinline__ half8_t load_operand(const uint16_t* etile, int t0, int I, int lane) {
+    const int x31 = lane & 31, kg = lane >> 5;
+    if (TR) {
+        const int i = lane & 15, c0 = 32 * I + 16 * ((lane >> 4) & 1);
+        const uint16_t* p = etile + (t0 + 8 * kg + (i >> 2)) * ET_PITCH + c0 + 4 * (i & 3);
+        const uint32_t addr = (uint32_t)(uintptr_t)p;      // LDS byte address (the low 32 bits of a shared pointer)
+        typedef short short4v __attribute__((ext_vector_type(4)));
+        short4v lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * ET_PITCH * 2) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        union { half8_t h; short4v s[2]; } cv;
+        cv.s[0] = lo;
+        cv.s[1] = hi;
+        return cv.h;
+    } else {
+        union { half8_t h; uint16_t u[8]; } cv;
+#pragma unroll
+        for (int j = 0; j < 8; j++) cv.u[j] = etile[(t0 + 8 * kg + j) * ET_PITCH + 32 * I + x31];
+        return cv.h;
+    }
+}
+
+template <int W, bool TR>
+__device__ __forceinline__ void gram_tile(const uint16_t* etile, int lane, float16_t (&acc)[3]) {
+    typedef WaveBlocks<W> WB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        half8_t f[4];
+#pragma unroll
+        for (int S = 0; S < 4; S++)
+            if (WB::need & (1 << S)) f[S] = load_operand<TR>(etile, 16 * ks, S, lane);
+#pragma unroll
+        for (int b = 0; b < WB::n; b++)
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[WB::I[b]], f[WB::J[b]], acc[b], 0, 0, 0);
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void gram_store(float* __restrict__ gp, int lane, const float16_t (&acc)[3]) {
+    typedef WaveBlocks<W> WB;
+    const int x31 = lane & 31, kg = lane >> 5;
+    // C layout of the 32x32 MFMA: lane l, reg q -> row (q & 3) + 8 (q >> 2) + 4 (l >> 5), col l & 31
+#pragma unroll
+    for (int b = 0; b < WB::n; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            gp[(32 * WB::I[b] + (q & 3) + 8 * (q >> 2) + 4 * kg) * KD + 32 * WB::J[b] + x31] = acc[b][q];
+}
+
+// grid (nslab, BH), 256 threads = 4 waves.  A round = 4 tiles of the slab, one per wave: the wave quantizes its tile
+// (registers), stores the payload and the error, puts the error tile into LDS; after a barrier every wave adds, for all four
+// tiles, ITS blocks of G = E^T E (the 10 blocks of the upper triangle are split 3 / 3 / 2 / 2 over the waves: 48 accumulator
+// registers instead of 160, which is what lets two workgroups share a CU, i.e. two waves per SIMD -- one wave's vector
+// arithmetic then overlaps the other's loads, LDS traffic and matrix-core work; with one wave per SIMD those costs simply
+// added up: 350 us of loads + 165 arithmetic + 150 Gram + 150 payload stores + 100 error store).
+template <int BITS, int MODE, int G, typename ST, bool FAST, bool LR, bool TR>
+__global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
     constexpr int CPW = 32 / BITS;
     constexpr int NW = 64 / CPW;             // code words per channel and tile
     constexpr int NG = 64 / G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slab = blockIdx.x;
     const int64_t bh = blockIdx.y;
     const int T = a.T, ntiles = T >> 6;
-    uint16_t* etile = (uint16_t*)smem + wave * 64 * ET_PITCH;   // this wave's error tile [64][ET_PITCH]
-    const int x31 = lane & 31, kg = lane >> 5;
+    uint16_t* etiles = (uint16_t*)smem;                         // [4][64][ET_PITCH]
+    uint16_t* etile = etiles + wave * 64 * ET_PITCH;            // this wave's error tile
 
-    float16_t acc[10];
+    float16_t acc[3];
     if (LR) {
 #pragma unroll
-        for (int b = 0; b < 10; b++)
+        for (int b = 0; b < 3; b++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
     }
@@ -628,119 +790,73 @@ __global__ __launch_bounds__(256, 1) void k_main_kernel(MainArgs a) {
     }
     const int tile_lo = slab * a.tiles_per_slab, tile_hi = min(ntiles, tile_lo + a.tiles_per_slab);
 
-    auto load_tile = [&](int tile, uint32_t (&dst)[64], uint4& mk) {
+    uint32_t xr[64];
+    uint4 mk = make_uint4(0, 0, 0, 0);
+    auto load_tile = [&](int tile) {
         const uint32_t* xw = (const uint32_t*)(a.x + (bh * T + (int64_t)tile * 64) * KD) + lane;
 #pragma unroll
-        for (int i = 0; i < 64; i++) dst[i] = xw[i * 64];
+        for (int i = 0; i < 64; i++) xr[i] = xw[i * 64];
         mk = make_uint4(0, 0, 0, 0);
         if (a.obits) mk = *(const uint4*)&a.obits[((bh * ntiles + tile) * KD + 2 * lane) * 2];
     };
-    auto process = [&](int tile, const uint32_t (&xr)[64], const uint4& mk) {
-        uint32_t ew[64], cwA[NW], cwB[NW];
-        float scA[NG], mnA[NG], scB[NG], mnB[NG];
-        if (FAST) tile_fast<BITS, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
-        else tile_generic<BITS, MODE, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
-        // ---- payload stores: channel-major rows, this tile's words / groups at the token offset
-        const int tok = a.t_off + tile * 64;
-        uint32_t* cA = a.code + (bh * KD + 2 * lane) * a.ldc + tok / CPW;
-        uint32_t* cB = cA + a.ldc;
-        if (NW == 4) {
-            *(uint4*)cA = make_uint4(cwA[0], cwA[1], cwA[2], cwA[3]);
-            *(uint4*)cB = make_uint4(cwB[0], cwB[1], cwB[2], cwB[3]);
-        } else {
+    if (tile_lo + wave < tile_hi) load_tile(tile_lo + wave);
+#pragma unroll 1
+    for (int t0 = tile_lo; t0 < tile_hi; t0 += 4) {
+        const int tile = t0 + wave;
+        if (tile < tile_hi) {
+            uint32_t ew[64], cwA[NW], cwB[NW];
+            float scA[NG], mnA[NG], scB[NG], mnB[NG];
+            if (FAST) tile_fast<BITS, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
+            else tile_generic<BITS, MODE, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
+            // ---- payload stores: channel-major rows, this tile's words / groups at the token offset
+            const int tok = a.t_off + tile * 64;
+            uint32_t* cA = a.code + (bh * KD + 2 * lane) * a.ldc + tok / CPW;
+            uint32_t* cB = cA + a.ldc;
 #pragma unroll
             for (int w = 0; w < NW; w += 4) {
                 *(uint4*)(cA + w) = make_uint4(cwA[w], cwA[w + 1], cwA[w + 2], cwA[w + 3]);
                 *(uint4*)(cB + w) = make_uint4(cwB[w], cwB[w + 1], cwB[w + 2], cwB[w + 3]);
             }
-        }
-        ST* sA = (ST*)a.scale + (bh * KD + 2 * lane) * a.lds + tok / G;
-        ST* nA = (ST*)a.mn + (bh * KD + 2 * lane) * a.lds + tok / G;
+            ST* sA = (ST*)a.scale + (bh * KD + 2 * lane) * a.lds + tok / G;
+            ST* nA = (ST*)a.mn + (bh * KD + 2 * lane) * a.lds + tok / G;
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) {
-            st_st<ST>(sA + gi, scA[gi]);
-            st_st<ST>(nA + gi, mnA[gi]);
-            st_st<ST>(sA + a.lds + gi, scB[gi]);
-            st_st<ST>(nA + a.lds + gi, mnB[gi]);
-        }
-        if (a.err) {
-            uint32_t* ep = (uint32_t*)(a.err + (bh * T + (int64_t)tile * 64) * KD) + lane;
-#pragma unroll
-            for (int i = 0; i < 64; i++) ep[i * 64] = ew[i];
-        }
-        if (LR) {
-            // ---- error tile -> LDS (row = token, conflict-free 4-byte stores) -> MFMA operands (lane (x31, kg) holds channel
-            // 32 I + x31 of tokens 16 ks + 8 kg .. +7) -> the 10 upper-triangular 32x32 blocks of G += E^T E
-#pragma unroll
-            for (int i = 0; i < 64; i++) ((uint32_t*)(etile + i * ET_PITCH))[lane] = ew[i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                half8_t f[4];
-#pragma unroll
-                for (int I = 0; I < 4; I++) {
-                    union { half8_t h; uint16_t u[8]; } cv;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) cv.u[j] = etile[(16 * ks + 8 * kg + j) * ET_PITCH + 32 * I + x31];
-                    f[I] = cv.h;
-                }
-#pragma unroll
-                for (int I = 0; I < 4; I++)
-#pragma unroll
-                    for (int J = I; J < 4; J++)
-                        acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
+            for (int gi = 0; gi < NG; gi++) {
+                st_st<ST>(sA + gi, scA[gi]);
+                st_st<ST>(nA + gi, mnA[gi]);
+                st_st<ST>(sA + a.lds + gi, scB[gi]);
+                st_st<ST>(nA + a.lds + gi, mnB[gi]);
             }
-            __builtin_amdgcn_wave_barrier();
-        }
-    };
-
-    // two register sets: the loads of the wave's next tile are in flight while the current one is processed (one copy of the
-    // tile body in the instruction stream: 64 register moves per tile are cheaper than 17 KB more code)
-    uint32_t xa[64], xb[64];
-    uint4 ma, mb = make_uint4(0, 0, 0, 0);
-    int tile = tile_lo + wave;
-    if (tile < tile_hi) load_tile(tile, xa, ma);
-#pragma unroll 1
-    while (tile < tile_hi) {
-        const bool more = tile + 4 < tile_hi;
-        if (more) load_tile(tile + 4, xb, mb);
-        process(tile, xa, ma);
-        if (more) {
+            if (a.err) {   // (4-byte stores straight from the registers: re-reading the LDS tile for 16-byte stores measured slower)
+                uint32_t* ep = (uint32_t*)(a.err + (bh * T + (int64_t)tile * 64) * KD) + lane;
 #pragma unroll
-            for (int i = 0; i < 64; i++) xa[i] = xb[i];
-            ma = mb;
+                for (int i = 0; i < 64; i++) ep[i * 64] = ew[i];
+            }
+            if (LR) {   // error tile -> LDS (row = token, conflict-free 4-byte stores)
+#pragma unroll
+                for (int i = 0; i < 64; i++) ((uint32_t*)(etile + i * ET_PITCH))[lane] = ew[i];
+            }
         }
-        tile += 4;
+        // the registers of x are free: the loads of the wave's next tile fly during the Gram phase
+        if (tile + 4 < tile_hi) load_tile(tile + 4);
+        if (LR) {
+            __syncthreads();
+            const int nt = min(4, tile_hi - t0);
+            for (int tt = 0; tt < nt; tt++) {
+                const uint16_t* et = etiles + tt * 64 * ET_PITCH;
+                if (wave == 0) gram_tile<0, TR>(et, lane, acc);
+                else if (wave == 1) gram_tile<1, TR>(et, lane, acc);
+                else if (wave == 2) gram_tile<2, TR>(et, lane, acc);
+                else gram_tile<3, TR>(et, lane, acc);
+            }
+            __syncthreads();
+        }
     }
     if (!LR) return;
-    // ---- the four waves' partial Gram matrices -> LDS, one wave at a time (deterministic), then one coalesced write of
-    // the blocks on / above the block diagonal.  C layout of the 32x32 MFMA: lane l, reg q -> row (q&3) + 8 (q>>2) + 4 (l>>5), col l&31
-    float* Gs = (float*)smem;                                  // [128][GS_GP], aliases the error tiles
-    __syncthreads();
-    for (int i = tid; i < GS_GD * GS_GP; i += 256) Gs[i] = 0.0f;
-    for (int turn = 0; turn < 4; turn++) {
-        __syncthreads();
-        if (wave == turn) {
-#pragma unroll
-            for (int I = 0; I < 4; I++)
-#pragma unroll
-                for (int J = I; J < 4; J++) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const int row = 32 * I + (q & 3) + 8 * (q >> 2) + 4 * kg, col = 32 * J + x31;
-                        Gs[row * GS_GP + col] += acc[blk_index(I, J)][q];
-                    }
-                }
-        }
-    }
-    __syncthreads();
     float* gp = a.gpart + (bh * a.nslab + slab) * (int64_t)(KD * KD);
-    for (int idx = tid; idx < KD * KD; idx += 256) {
-        const int row = idx >> 7, col = idx & 127;
-        if ((col >> 5) >= (row >> 5)) gp[idx] = Gs[row * GS_GP + col];
-    }
+    if (wave == 0) gram_store<0>(gp, lane, acc);
+    else if (wave == 1) gram_store<1>(gp, lane, acc);
+    else if (wave == 2) gram_store<2>(gp, lane, acc);
+    else gram_store<3>(gp, lane, acc);
 }
 
 // ================================================================================================ solve
@@ -799,7 +915,7 @@ double inv_norm_cdf(double p) {  // Acklam's rational approximation (relative er
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KfWs {       // workspace carve-up
-    size_t obits, omean, err, gpart, W, total;
+    size_t obits, omean, err, gpart, W, todo, total;
     int nslab, tiles_per_slab;
 };
 KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
@@ -817,24 +933,32 @@ KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
     w.err = off;   off += align256(rank > 0 ? (size_t)BH * T * KD * 2 : 0);
     w.gpart = off; off += align256(rank > 0 ? (size_t)BH * nslab * KD * KD * 4 : 0);
     w.W = off;     off += align256(rank > 0 ? (size_t)BH * KD * RP * 4 : 0);
+    w.todo = off;  off += align256(k > 0 ? 256 + (size_t)BH * 256 * 4 : 0);   // counter (first 256 bytes) + list ids
     w.total = off + 256;
     return w;
 }
 
 template <int BITS, int MODE, int G, typename ST>
-void launch_main(const MainArgs& a, int64_t BH, bool fast, bool lr, hipStream_t st) {
-    const size_t shmem = lr ? (size_t)max(4 * 64 * ET_PITCH * 2, GS_GD * GS_GP * 4) : 0;
+void launch_main(const MainArgs& a, int64_t BH, bool fast, bool lr, bool tr, hipStream_t st) {
+    const size_t shmem = lr ? (size_t)4 * 64 * ET_PITCH * 2 : 0;
     const dim3 grid((unsigned)a.nslab, (unsigned)BH);
-#define KF_GO(FASTV, LRV)                                                                                              \
+#define KF_GO(FASTV, LRV, TRV)                                                                                         \
     do {                                                                                                               \
-        auto kfn = k_main_kernel<BITS, MODE, G, ST, FASTV, LRV>;                                                       \
+        auto kfn = k_main_kernel<BITS, MODE, G, ST, FASTV, LRV, TRV>;                                                  \
         if (shmem > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
         hipLaunchKernelGGL(kfn, grid, dim3(256), shmem, st, a);                                                        \
     } while (0)
     if constexpr (MODE == 1) {
-        if (fast) { if (lr) KF_GO(true, true); else KF_GO(true, false); return; }
+        if (fast) {
+            if (!lr) KF_GO(true, false, false);
+            else if (tr) KF_GO(true, true, true);
+            else KF_GO(true, true, false);
+            return;
+        }
     }
-    if (lr) KF_GO(false, true); else KF_GO(false, false);
+    if (!lr) KF_GO(false, false, false);
+    else if (tr) KF_GO(false, true, true);
+    else KF_GO(false, true, false);
 #undef KF_GO
 }
 
@@ -865,7 +989,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         GEAR_CHECK_ARG(loop >= 1 && P0 && P_out && Q_out, "gear_compress_key_fused: low-rank needs loop >= 1, P0, P_out, Q_out");
         GEAR_CHECK_ARG(p_inner >= 1 && q_tcap >= q_toff + T, "gear_compress_key_fused: bad factor geometry");
     }
-    if (k > 0) GEAR_CHECK_ARG(oidx && oval && kcap >= o_off + k && t_off + T <= 65536, "gear_compress_key_fused: bad outlier geometry");
+    if (k > 0) GEAR_CHECK_ARG(oidx && oval && kcap >= o_off + k && t_off + T <= 65536 && T <= 16384, "gear_compress_key_fused: bad outlier geometry");
     const KfWs ws = kf_workspace(BH, T, k, rank);
     GEAR_CHECK_ARG(workspace_bytes >= ws.total, "gear_compress_key_fused: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -879,7 +1003,8 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     if (k > 0) {
         SelArgs sa;
         sa.x = (const uint16_t*)x; sa.BH = BH; sa.T = T; sa.k = k;
-        // candidates per side and row: k + 5 sqrt(k) + 8 expected (the guess is validated by the counts; lists hold KS_CAP)
+        // candidates per side and row: k + 5 sqrt(k) + 8 expected.  Measured on the 7B / 4k tensor (k = 40): a target of 56 / 64 /
+        // 72 / 80 / 92 gives 542 / 591 / 598 / 610 / 628 us of select + 673 / 101 / 79 / 77 / 74 us of fix kernel (the guess is validated by the counts; lists hold KS_CAP)
         const double target = k + 5.0 * sqrt((double)k) + 8.0;
         double p = target / (double)T;
         if (p > 0.5) p = 0.5;
@@ -888,11 +1013,17 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         sa.rlen = 1.0f / (float)T;
         sa.obits = obits; sa.omean = omean; sa.oidx = (uint16_t*)oidx; sa.oval = (uint16_t*)oval;
         sa.kcap = kcap; sa.o_off = o_off; sa.tok_base = t_off;
+        sa.todo_cnt = (uint32_t*)(base + ws.todo);
+        sa.todo = sa.todo_cnt + 64;
+        if (hipMemsetAsync(sa.todo_cnt, 0, 4, st) != hipSuccess) { gear_set_error("gear_compress_key_fused: memset failed"); return -2; }
         const int nwords = (T + 31) / 32;
         const size_t scr_words = (size_t)max(max(16 * 16 * 4, 256 * KS_B), 4 * 3 * nwords);
-        const size_t shmem = ((size_t)64 * KS_CAP + 64 + scr_words) * 4;
+        const size_t shmem = ((size_t)64 * KS_STRIDE + 128 + scr_words) * 4;
         hipLaunchKernelGGL(k_select_kernel, dim3((unsigned)(4 * BH)), dim3(256), shmem, st, sa);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(select)");
+        const unsigned fix_grid = (unsigned)(BH * 64 < 1024 ? BH * 64 : 1024);   // waves loop over the to-do list
+        hipLaunchKernelGGL(k_select_fix_kernel, dim3(fix_grid), dim3(256), 0, st, sa);
+        GEAR_CHECK_LAUNCH("gear_compress_key_fused(select fix)");
     }
     MainArgs ma;
     ma.x = (const uint16_t*)x; ma.obits = obits; ma.omean = omean; ma.T = T;
@@ -900,7 +1031,8 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     ma.code = (uint32_t*)code; ma.scale = scale; ma.mn = mn; ma.ldc = ldc; ma.lds = lds; ma.t_off = t_off;
     ma.err = err; ma.gpart = gpart;
     const bool fast = (variant & 1) == 0 && !gear_options().kfused_generic, lr = rank > 0;
-#define KF_DISPATCH(B, M, GG, STT) launch_main<B, M, GG, STT>(ma, BH, fast, lr, st)
+    const bool tr = (variant & 4) == 0 && !gear_options().kfused_no_tr;
+#define KF_DISPATCH(B, M, GG, STT) launch_main<B, M, GG, STT>(ma, BH, fast, lr, tr, st)
     if (mode == GEAR_MODE_FP32) {
         if (bits == 2) { if (group == 64) KF_DISPATCH(2, 1, 64, float); else KF_DISPATCH(2, 1, 32, float); }
         else { if (group == 64) KF_DISPATCH(4, 1, 64, float); else KF_DISPATCH(4, 1, 32, float); }

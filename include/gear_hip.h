@@ -44,7 +44,7 @@ const char* gear_last_error(void);
 int gear_abi_version(void);
 /* Run-time options: switches that select an alternative, equally exact code path (used by the tests to reach the
  * paths ordinary inputs do not).  Names: "attn_generic", "lowrank_generic", "rows_hist_only", "rows_v1",
- * "kfused_generic", "kselect_slow".  Each is also read once from the environment (GEAR_<NAME>) when the library is
+ * "kfused_generic", "kselect_slow", "kfused_no_tr".  Each is also read once from the environment (GEAR_<NAME>) when the library is
  * first used.  Returns 0, or -1 for an unknown name. */
 int gear_set_option(const char* name, int value);
 
@@ -128,7 +128,8 @@ int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t ou
  *         index is t_off + t.  Ties at the selection boundary: lower token first (as gear_compress_rows).
  *   rank  0: no low-rank part.  P0 float [BH, 128, rank]; P_out fp16, head bh at element offset
  *         (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * rank;  Q_out fp16 [BH, q_tcap, rank], rows q_toff ..
- *   variant: bit 0 = element-by-element tile arithmetic, bit 1 = always the exact slow selection (cross-checks)
+ *   variant: bit 0 = element-by-element tile arithmetic, bit 1 = always the exact slow selection, bit 2 = 16-bit LDS reads
+ *         instead of the transposing ones for the matrix-core operands (cross-checks)
  *   workspace: gear_compress_key_fused_workspace(BH, T, k, rank) bytes of device scratch.
  * With t_off / ldc / lds / q_tcap / kcap the call appends a block to a pre-allocated streaming cache in place.
  */

@@ -35,6 +35,7 @@ def timed(fn, reps=5):
 
 
 n = K.numel()
+only = os.environ.get("ONLY")
 for name, fn in [
     ("rows  k+r", lambda: C.compress_key(K, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0, path="rows")),
     ("fused k+r", lambda: C.compress_key_fused(K, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0)),
@@ -42,7 +43,9 @@ for name, fn in [
     ("fused k only", lambda: C.compress_key_fused(K, bits, g, k_out=k, rank=0, mode="fp32")),
     ("fused r only", lambda: C.compress_key_fused(K, bits, g, k_out=0, rank=rank, loop=3, mode="fp32", P0=P0)),
     ("fused quant only", lambda: C.compress_key_fused(K, bits, g, k_out=0, rank=0, mode="fp32")),
-]:
+]+[("fused k+r no-tr", lambda: C.compress_key_fused(K, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0, variant=4))]:
+    if only and only != name:
+        continue
     try:
         ms = timed(fn)
         print(f"{name:26s} {ms:8.3f} ms   {2 * n / ms / 1e6:8.1f} GB/s of fp16 K", flush=True)

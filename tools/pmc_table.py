@@ -7,7 +7,7 @@ for r in rows:
     n = re.sub(r"\(.*", "", n)[:60]
     tab.setdefault(n, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for n, cs in tab.items():
-    if "compress_rows" not in n and "lr_" not in n and "decompress" not in n and "attn" not in n:
+    if not any(t in n for t in ("compress_rows", "lr_", "decompress", "attn", "k_select", "k_main", "k_solve", "v_")):
         continue
     print("##", n)
     for c, v in cs.items():
