@@ -4,10 +4,23 @@ cuda_supported_gear/modeling_llamagear.py:273-286, :365-378, and re-lays the who
 quant/matmul.py:205, :215-216).
 
 State machine = the attention hook's (modeling_llamagear.py:177-484): an fp16 window of the most recent < `residual`
-tokens; when it fills, the block is compressed (quantize + pack + per-block rank-r factors) in place behind the already
-compressed tokens.  Layout = what gear_attn_decode_seg streams: K channel-major with a fixed row pitch (so a block append
-is 128 short row segments, never a re-layout), V token-major, token-side factors per token, channel-side factors per
-segment (segment 0 = the prompt, then one per block).
+tokens; when it fills, the block is compressed IN PLACE behind the already compressed tokens: quantized backbone, per-block
+rank-r factors and -- when the config carries a sparsity (`left`, the simulated path's name,
+GenerationBench/.../Simulated/compress_config.py) -- the sparse outliers of the block, which is what the reference's
+streaming hook applies to every new block (Simulated/modeling_llama_new.py:979-1019 -> compress_function.py:261-333).
+Layout = what gear_attn_decode_stream streams: K channel-major with a fixed row pitch (a block append is 128 short row
+segments, never a re-layout), V token-major, token-side factors per token, channel-side factors per segment (segment 0 =
+the prompt, then one per block), K outlier lists per (channel, side) that grow by `kk_blk` entries per block (later blocks
+hold later tokens, so the lists stay sorted), V outlier lists per token row.
+
+The compress calls write straight into these tensors (gear_compress_key_fused / gear_compress_value_fused with a token
+offset and row pitches): no intermediate payload, no strided copies.
+
+Outlier counts.  V rows (a token across the heads) and the K rows of the prompt segment use the reference's formula
+(compress_function.py:264-267, :299-303: int(H*D*s/2) per side, capped at half the row).  For the K rows of a 64-token
+decode block that formula asks for more outliers than the row has elements (defect B7: it depends on H*D, not on the
+row length; torch.topk then takes overlapping sets and the block ends up stored losslessly); the cache uses the NOMINAL
+count max(1, round(64*s/2)) per side there.
 
 Differences from the hook, on purpose: K and V are compressed in lockstep (the hook compresses V only when T > residual,
 :416, which strands V in fp16 when the prompt is exactly `residual` long), and the block factors start from a
@@ -24,17 +37,30 @@ from . import _lib as L
 from . import compress as C
 
 
+def _sparsity(cc) -> float:
+    return float(cc.get("left", cc.get("sparsity", 0.0)) or 0.0)
+
+
 def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128):
     bits, group, R = cc["quantize_bit"], cc["group_size"], cc["residual"]
     m = cc["compress_method"]
     lowrank = ("gearl" in m) or ("gearsl" in m)
     rk = int(cc["rank"]) if lowrank else 0
     rv = int(cc["rankv"]) if lowrank else 0
-    assert R % 64 == 0 and R % group == 0
+    if R != 64:
+        raise L.GearError(f"GearKVCache: residual must be 64 (got {R}): the decode attention kernel holds at most 64 window "
+                          "tokens (gear_attn_decode: 0 <= W <= 64)")
+    assert R % group == 0 and group in (32, 64) and bits in (2, 4), "GearKVCache: group 32 / 64, 2 or 4 bits"
     fpi = 32 // bits
     Tmax = (max_tokens + R - 1) // R * R
+    assert Tmax <= 16384, "GearKVCache: at most 16384 tokens"
     nseg = 1 + Tmax // R
     B, H, D, T = batch, n_kv_heads, head_dim, Tmax
+    s = _sparsity(cc)
+    kv = int(int(B * H * T * D * s) / B / T / 2) if s > 0 else 0          # per side per token row (compress_function.py:300-303)
+    kk0_max = kv                                                          # the same formula for the prompt's channel rows
+    kk_blk = max(1, round(R * s / 2)) if s > 0 else 0                     # nominal count for a 64-token block (B7)
+    kcap = kk0_max + (Tmax // R) * kk_blk
     shapes = dict(kcode=((B, H, D, T // fpi), torch.int32), kscale=((B, H, D, T // group), torch.float16),
                   kmn=((B, H, D, T // group), torch.float16), vcode=((B, H, T, D // fpi), torch.int32),
                   vscale=((B, H, T, D // group), torch.float16), vmn=((B, H, T, D // group), torch.float16),
@@ -42,51 +68,85 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128):
     if lowrank:
         shapes.update(kPseg=((nseg, B, H, D, rk), torch.float16), kQtok=((B, H, T, rk), torch.float16),
                       vPseg=((nseg, B, H, D, rv), torch.float16), vQtok=((B, H, T, rv), torch.float16))
-    return shapes, dict(bits=bits, group=group, R=R, lowrank=lowrank, rk=rk, rv=rv, fpi=fpi, Tmax=Tmax, nseg=nseg)
+    if kk_blk > 0:
+        shapes.update(koidx=((B, H, D, 2, kcap), torch.int16), koval=((B, H, D, 2, kcap), torch.float16))
+    if kv > 0:
+        shapes.update(voidx=((B, T, 2 * kv), torch.int16), voval=((B, T, 2 * kv), torch.float16))
+    return shapes, dict(bits=bits, group=group, R=R, lowrank=lowrank, rk=rk, rv=rv, fpi=fpi, Tmax=Tmax, nseg=nseg,
+                        kv=kv, kk0_max=kk0_max, kk_blk=kk_blk, kcap=kcap)
+
+
+def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_off, loop, gen):
+    """Compress K / V [lead*B, H, T, 128] (lead = layers riding in the batch dimension of pooled storage) and write the
+    payload behind token t_off of the cache tensors in `bufs` (same leading dimension), factors into segment `seg`, K outlier
+    lists at position o_off.  fp16-stepwise arithmetic (the fused path's mode)."""
+    lib = L.load()
+    p = L.ptr
+    NB = lead * B
+    dev = k_src.device
+    Tmax, g, fpi, bits = d["Tmax"], d["group"], d["fpi"], d["bits"]
+    P0k = P0v = None
+    if d["lowrank"]:
+        P0k = torch.rand((NB, H, D, d["rk"]), device=dev, generator=gen)
+        P0v = torch.rand((NB, H, D, d["rv"]), device=dev, generator=gen)
+    # per-segment channel factors [lead, nseg, B, H, D, r]: head (l, b, h) of segment seg
+    def pseg(name, r):
+        if not d["lowrank"]:
+            return None, 0
+        t = bufs[name]
+        seg_elems = B * H * D * r
+        return t.view(-1)[seg * seg_elems:], d["nseg"] * seg_elems
+    kP, kP_stride = pseg("kPseg", d["rk"])
+    vP, vP_stride = pseg("vPseg", d["rv"])
+    wsb = max(lib.gear_compress_key_fused_workspace(NB * H, T, kk, d["rk"]),
+              lib.gear_compress_value_fused_workspace(NB, H, T, d["rv"]))
+    ws = C._workspace(wsb, dev)
+    st = L.stream_ptr(k_src)
+    rc = lib.gear_compress_key_fused(
+        p(k_src), NB * H, T, g, bits, 0, kk, p(bufs["kcode"]), p(bufs["kscale"]), p(bufs["kmn"]), Tmax // fpi, Tmax // g,
+        t_off, d["rk"], loop, p(P0k), p(kP), B * H, kP_stride, p(bufs.get("kQtok")), Tmax, t_off,
+        p(bufs.get("koidx")) if kk else None, p(bufs.get("koval")) if kk else None, d["kcap"], o_off, 0, p(ws), ws.numel(), st)
+    L.check(rc, "gear_compress_key_fused")
+    rc = lib.gear_compress_value_fused(
+        p(v_src), NB, H, T, g, bits, 0, d["kv"], p(bufs["vcode"]), p(bufs["vscale"]), p(bufs["vmn"]), Tmax, t_off, d["rv"],
+        loop, p(P0v), p(vP), B * H, vP_stride, p(bufs.get("vQtok")), Tmax, t_off, p(bufs.get("voidx")), p(bufs.get("voval")),
+        p(ws), ws.numel(), st)
+    L.check(rc, "gear_compress_value_fused")
 
 
 class GearKVCachePool:
     """The buffers of ALL layers' caches as one tensor per field with a leading layer dimension.  Every layer's
     GearKVCache takes its (contiguous) slice, so nothing changes for the kernels; what the pool buys is the block boundary:
-    all layers fill their fp16 windows on the same token, and with pooled storage the 32 per-layer compress + 10-copy
-    sequences (~800 launches) become ONE compress_key / compress_value over [layers * batch, H, residual, 128] and one
-    strided copy per field (compress_all)."""
+    all layers fill their fp16 windows on the same token, and with pooled storage the 32 per-layer compress sequences become
+    ONE gear_compress_key_fused + ONE gear_compress_value_fused over [layers * batch, H, residual, 128] that write the block
+    of every layer in place (compress_all): 7 launches per block boundary."""
 
     def __init__(self, n_layers: int, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device,
                  head_dim: int = 128, seed: int = 0):
         shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim)
         self.L, self.B, self.H, self.D = n_layers, batch, n_kv_heads, head_dim
         self.loop = int(compress_config.get("loop", 3))
-        self.buf = {n: torch.zeros((n_layers,) + shp, dtype=dt, device=device) for n, (shp, dt) in shapes.items()}
+        self.buf = {}
+        for n, (shp, dt) in shapes.items():
+            if n in ("kPseg", "vPseg"):
+                self.buf[n] = torch.zeros((n_layers,) + shp, dtype=dt, device=device)     # [L, nseg, B, H, D, r]
+            else:
+                self.buf[n] = torch.zeros((n_layers,) + shp, dtype=dt, device=device)
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
         self.caches = []
 
     def compress_all(self):
-        """Every layer's window holds `residual` tokens: compress all of them in one go and append behind the compressed
-        tokens (same arithmetic as GearKVCache._store_block, the layers ride in the batch dimension)."""
+        """Every layer's window holds `residual` tokens: compress all of them in one go, in place behind the compressed
+        tokens (the layers ride in the batch dimension)."""
         d, b, c0 = self.dims, self.buf, self.caches[0]
-        L_, B, H, D, R, g, fpi = self.L, self.B, self.H, self.D, d["R"], d["group"], d["fpi"]
-        assert all(c.n_win == R and c.n_comp == c0.n_comp for c in self.caches)
+        R = d["R"]
+        assert all(c.n_win == R and c.n_comp == c0.n_comp and c.kk0 == c0.kk0 for c in self.caches)
         t0, seg = c0.n_comp, c0._segment_of(c0.n_comp)
         assert t0 + R <= d["Tmax"], "cache capacity exceeded"
-        P0k = P0v = None
-        if d["lowrank"]:
-            P0k = torch.rand((L_ * B, H, D, d["rk"]), device=b["kwin"].device, generator=self.gen)
-            P0v = torch.rand((L_ * B, H, D, d["rv"]), device=b["kwin"].device, generator=self.gen)
-        pk = C.compress_key(b["kwin"].view(L_ * B, H, R, D), d["bits"], g, rank=d["rk"], loop=self.loop, mode="fp16", P0=P0k)
-        pv = C.compress_value(b["vwin"].view(L_ * B, H, R, D), d["bits"], g, rank=d["rv"], loop=self.loop, mode="fp16", P0=P0v)
-        b["kcode"][..., t0 // fpi:(t0 + R) // fpi] = pk.code.view(L_, B, H, D, R // fpi)
-        b["kscale"][..., t0 // g:(t0 + R) // g] = pk.scale.view(L_, B, H, D, R // g)
-        b["kmn"][..., t0 // g:(t0 + R) // g] = pk.mn.view(L_, B, H, D, R // g)
-        b["vcode"][:, :, :, t0:t0 + R] = pv.code.view(L_, B, H, R, D // fpi)
-        b["vscale"][:, :, :, t0:t0 + R] = pv.scale.view(L_, B, H, R, D // g)
-        b["vmn"][:, :, :, t0:t0 + R] = pv.mn.view(L_, B, H, R, D // g)
-        if d["lowrank"]:
-            b["kPseg"][:, seg] = pk.P.view(L_, B, H, D, d["rk"])
-            b["kQtok"][:, :, :, t0:t0 + R] = pk.Q.view(L_, B, H, R, d["rk"])
-            b["vPseg"][:, seg] = pv.P.view(L_, B, H, D, d["rv"])
-            b["vQtok"][:, :, :, t0:t0 + R] = pv.Q.view(L_, B, H, R, d["rv"])
+        o_off = c0.kk0 + ((t0 - c0.seg0) // R) * d["kk_blk"]
+        _compress_into(b, d, self.L, self.B, self.H, self.D, b["kwin"], b["vwin"], R, t0, seg, d["kk_blk"], o_off, self.loop,
+                       self.gen)
         for c in self.caches:
             c.n_comp += R
             c.n_win = 0
@@ -98,24 +158,32 @@ class GearKVCache:
         assert head_dim == 128
         cc = compress_config
         shapes, d = _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim)
+        self.dims = d
         self.B, self.H, self.D = batch, n_kv_heads, head_dim
         self.bits, self.group, self.R = d["bits"], d["group"], d["R"]
         self.lowrank, self.rk, self.rv = d["lowrank"], d["rk"], d["rv"]
         self.loop = int(cc.get("loop", 3))
         self.fpi, self.Tmax = d["fpi"], d["Tmax"]
-        for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn", "kPseg", "kQtok", "vPseg", "vQtok", "kwin", "vwin"):
+        self.kv, self.kk_blk, self.kcap = d["kv"], d["kk_blk"], d["kcap"]
+        self.bufs = {}
+        for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn", "kPseg", "kQtok", "vPseg", "vQtok", "kwin", "vwin",
+                     "koidx", "koval", "voidx", "voval"):
             if name not in shapes:
-                setattr(self, name, None)
+                t = None
             elif pool is not None:          # this layer's slice of the pooled storage (contiguous, same layout)
-                setattr(self, name, pool.buf[name][layer])
+                t = pool.buf[name][layer]
             else:
                 shp, dt = shapes[name]
-                setattr(self, name, torch.zeros(shp, dtype=dt, device=device))
+                t = torch.zeros(shp, dtype=dt, device=device)
+            setattr(self, name, t)
+            if t is not None:
+                self.bufs[name] = t
         if pool is not None:
             pool.caches.append(self)
         self.n_comp = 0      # compressed tokens
         self.n_win = 0       # tokens in the fp16 window
         self.seg0 = 0        # tokens of segment 0 (the compressed part of the prompt)
+        self.kk0 = 0         # K outliers per side and channel row of segment 0
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
         self._ws = None
@@ -130,28 +198,11 @@ class GearKVCache:
     def _segment_of(self, t0: int) -> int:
         return 0 if t0 < self.seg0 else 1 + (t0 - self.seg0) // self.R
 
-    def _store_block(self, k_blk: torch.Tensor, v_blk: torch.Tensor, seg: int):
-        """Compress [B,H,n,128] K and V and write them behind the compressed tokens."""
-        n, t0, g, fpi = k_blk.shape[2], self.n_comp, self.group, self.fpi
-        assert t0 + n <= self.Tmax, "cache capacity exceeded"
-        P0k = P0v = None
-        if self.lowrank:
-            P0k = torch.rand((self.B, self.H, self.D, self.rk), device=k_blk.device, generator=self.gen)
-            P0v = torch.rand((self.B, self.H, self.D, self.rv), device=k_blk.device, generator=self.gen)
-        pk = C.compress_key(k_blk, self.bits, g, rank=self.rk, loop=self.loop, mode="fp16", P0=P0k)
-        pv = C.compress_value(v_blk, self.bits, g, rank=self.rv, loop=self.loop, mode="fp16", P0=P0v)
-        self.kcode[:, :, :, t0 // fpi:(t0 + n) // fpi] = pk.code
-        self.kscale[:, :, :, t0 // g:(t0 + n) // g] = pk.scale
-        self.kmn[:, :, :, t0 // g:(t0 + n) // g] = pk.mn
-        self.vcode[:, :, t0:t0 + n] = pv.code
-        self.vscale[:, :, t0:t0 + n] = pv.scale
-        self.vmn[:, :, t0:t0 + n] = pv.mn
-        if self.lowrank:
-            self.kPseg[seg] = pk.P
-            self.kQtok[:, :, t0:t0 + n] = pk.Q
-            self.vPseg[seg] = pv.P
-            self.vQtok[:, :, t0:t0 + n] = pv.Q
-        self.n_comp += n
+    def _store(self, k_src, v_src, T, seg, kk, o_off):
+        assert self.n_comp + T <= self.Tmax, "cache capacity exceeded"
+        _compress_into(self.bufs, self.dims, 1, self.B, self.H, self.D, k_src, v_src, T, self.n_comp, seg, kk, o_off, self.loop,
+                       self.gen)
+        self.n_comp += T
 
     def prefill(self, k: torch.Tensor, v: torch.Tensor):
         """k, v fp16 [B,Hkv,T,128] (post-RoPE): the first T - T % residual tokens are compressed as segment 0, the tail
@@ -161,7 +212,8 @@ class GearKVCache:
         nq = T - T % self.R
         if nq:
             self.seg0 = nq
-            self._store_block(k[:, :, :nq].contiguous(), v[:, :, :nq].contiguous(), 0)
+            self.kk0 = min(self.dims["kk0_max"], nq // 2) if self.kk_blk else 0
+            self._store(k[:, :, :nq].contiguous(), v[:, :, :nq].contiguous(), nq, 0, self.kk0, 0)
         self.n_win = T - nq
         if self.n_win:
             self.kwin[:, :, :self.n_win] = k[:, :, nq:]
@@ -171,7 +223,7 @@ class GearKVCache:
         """qkv fp16 [B, (Hq + 2 Hkv) * 128] of the new token -> RoPE, k / v into the window; returns q [B,Hq,1,128]."""
         q = torch.empty((self.B, n_q_heads, 1, self.D), dtype=torch.float16, device=qkv.device)
         rc = L.load().gear_rope_append(L.ptr(qkv), self.B, n_q_heads, self.H, self.D, pos, theta, L.ptr(q), L.ptr(self.kwin),
-                                       L.ptr(self.vwin), self.n_win, self.R, L.stream_ptr())
+                                       L.ptr(self.vwin), self.n_win, self.R, L.stream_ptr(qkv))
         L.check(rc, "gear_rope_append")
         self.n_win += 1
         return q
@@ -182,8 +234,7 @@ class GearKVCache:
         self.vwin[:, :, self.n_win] = v_new[:, :, 0]
         self.n_win += 1
 
-    def attend(self, q: torch.Tensor) -> torch.Tensor:
-        """q fp16 [B,Hq,1,128] -> softmax(q Khat^T / sqrt(128)) Vhat over compressed + window tokens, fp16 [B,Hq,1,128]."""
+    def _attend(self, q, T, W, dyn):
         B, Hq = q.shape[0], q.shape[1]
         lib = L.load()
         out = torch.empty((B, Hq, 1, self.D), dtype=torch.float16, device=q.device)
@@ -191,44 +242,36 @@ class GearKVCache:
         if self._ws is None or self._ws.numel() < wsb:
             self._ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
         p = L.ptr
-        T = self.n_comp
-        rc = lib.gear_attn_decode_seg(
-            p(q), p(self.kcode), p(self.kscale), p(self.kmn), p(self.kPseg), p(self.kQtok), None, None,
-            p(self.vcode), p(self.vscale), p(self.vmn), p(self.vPseg), p(self.vQtok), None, None,
-            p(self.kwin) if self.n_win else None, p(self.vwin) if self.n_win else None,
-            B, Hq, self.H, self.D, T, self.n_win, self.Tmax // self.fpi, self.Tmax // self.group, self.Tmax, self.Tmax,
-            self.Tmax, self.group, self.bits, 0, self.rk, self.rv, 0, 0, self.seg0, self.R if self.lowrank else 0, self.R,
-            1.0 / math.sqrt(self.D), p(out), None, p(self._ws), self._ws.numel(), L.stream_ptr())
-        L.check(rc, "gear_attn_decode_seg")
+        rc = lib.gear_attn_decode_stream(
+            p(q), p(self.kcode), p(self.kscale), p(self.kmn), p(self.kPseg), p(self.kQtok), p(self.koidx), p(self.koval),
+            p(self.vcode), p(self.vscale), p(self.vmn), p(self.vPseg), p(self.vQtok), p(self.voidx), p(self.voval),
+            p(self.kwin) if (W or dyn is not None) else None, p(self.vwin) if (W or dyn is not None) else None,
+            B, Hq, self.H, self.D, T, W, self.Tmax // self.fpi, self.Tmax // self.group, self.Tmax, self.Tmax, self.Tmax,
+            self.group, self.bits, 0, self.rk, self.rv, self.kcap if self.kk_blk else 0, self.kk0, self.kk_blk, self.kv,
+            self.seg0, self.R if (self.lowrank or self.kk_blk) else 0, self.R, p(dyn), 1.0 / math.sqrt(self.D), p(out), None,
+            p(self._ws), self._ws.numel(), L.stream_ptr(q))
+        L.check(rc, "gear_attn_decode_stream")
         return out
+
+    def attend(self, q: torch.Tensor) -> torch.Tensor:
+        """q fp16 [B,Hq,1,128] -> softmax(q Khat^T / sqrt(128)) Vhat over compressed + window tokens, fp16 [B,Hq,1,128]."""
+        return self._attend(q, self.n_comp, self.n_win, None)
 
     # ---- device-state variants: no host-side counters change here (a captured graph replays these launches) ----------
     def append_rope_dyn(self, qkv: torch.Tensor, n_q_heads: int, theta: float) -> torch.Tensor:
         q = torch.empty((self.B, n_q_heads, 1, self.D), dtype=torch.float16, device=qkv.device)
         rc = L.load().gear_rope_append_dyn(L.ptr(qkv), self.B, n_q_heads, self.H, self.D, L.ptr(self.state), theta, L.ptr(q),
-                                           L.ptr(self.kwin), L.ptr(self.vwin), self.R, L.stream_ptr())
+                                           L.ptr(self.kwin), L.ptr(self.vwin), self.R, L.stream_ptr(qkv))
         L.check(rc, "gear_rope_append_dyn")
         return q
 
     def attend_dyn(self, q: torch.Tensor) -> torch.Tensor:
-        B, Hq = q.shape[0], q.shape[1]
-        lib = L.load()
-        out = torch.empty((B, Hq, 1, self.D), dtype=torch.float16, device=q.device)
-        wsb = lib.gear_attn_decode_workspace(B, Hq, self.Tmax, self.bits)
-        if self._ws is None or self._ws.numel() < wsb:
-            self._ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
-        p = L.ptr
-        rc = lib.gear_attn_decode_dyn(
-            p(q), p(self.kcode), p(self.kscale), p(self.kmn), p(self.kPseg), p(self.kQtok), None, None,
-            p(self.vcode), p(self.vscale), p(self.vmn), p(self.vPseg), p(self.vQtok), None, None, p(self.kwin), p(self.vwin),
-            B, Hq, self.H, self.D, self.Tmax, self.R, self.Tmax // self.fpi, self.Tmax // self.group, self.Tmax, self.Tmax,
-            self.Tmax, self.group, self.bits, 0, self.rk, self.rv, 0, 0, self.seg0, self.R if self.lowrank else 0, self.R,
-            p(self.state), 1.0 / math.sqrt(self.D), p(out), None, p(self._ws), self._ws.numel(), L.stream_ptr())
-        L.check(rc, "gear_attn_decode_dyn")
-        return out
+        return self._attend(q, self.Tmax, self.R, self.state)
 
     def maybe_compress(self):
         """Compress the window when it holds `residual` tokens (modeling_llamagear.py:265, :335)."""
         if self.n_win == self.R:
-            self._store_block(self.kwin, self.vwin, self._segment_of(self.n_comp))
+            seg = self._segment_of(self.n_comp)
+            o_off = self.kk0 + ((self.n_comp - self.seg0) // self.R) * self.kk_blk
+            self._store(self.kwin, self.vwin, self.R, seg, self.kk_blk, o_off)
             self.n_win = 0

@@ -47,6 +47,10 @@ struct AttnArgs {
     int ldk, lsk;            // K code / scale row pitch
     int tcap_v, tf_k, tf_v;  // token capacity (row count) of V tensors / factor tensors
     int group, rk, rv, kk, kv;
+    // K outlier lists of a streaming cache: every (channel, side) list has room for kk_stride entries, the first
+    // kk0 + kkb * (blocks appended so far) are valid -- kk0 from the prompt segment, kkb per `seglen` tokens after seg0.
+    // Plain payloads: kk_stride == kk, kkb == 0.
+    int kk_stride, kk0, kkb;
     int seg0, seglen;        // low-rank factor segments: tokens [0, seg0) use channel factors #0, then one set per `seglen`
                              // tokens (seglen == 0: a single segment).  kP / vP are [nseg, B*Hkv, 128, r].
     int64_t kP_seg_stride, vP_seg_stride;
@@ -63,6 +67,13 @@ struct AttnArgs {
     const uint8_t* vochunk;
     int nbk, nbv;
 };
+
+// valid entries of a K outlier list when the cache holds Tc compressed tokens
+__device__ __forceinline__ int k_list_len(const AttnArgs& a, int Tc) {
+    if (a.kkb == 0) return a.kk;
+    const int nblk = (a.seglen > 0 && Tc > a.seg0) ? (Tc - a.seg0) / a.seglen : 0;
+    return min(a.kk_stride, a.kk0 + nblk * a.kkb);
+}
 
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
 #pragma unroll
@@ -239,10 +250,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     if (a.kk > 0 && tid < AD) {
         const int d = tid;
         const float qd = qs[d];
+        const int klen = k_list_len(a, Tc);
         for (int side = 0; side < 2; side++) {
-            const uint16_t* oi = a.koidx + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
-            const uint16_t* ov = a.koval + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk;
-            for (int i = lower_bound_u16(oi, a.kk, t0); i < a.kk; i++) {
+            const uint16_t* oi = a.koidx + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk_stride;
+            const uint16_t* ov = a.koval + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk_stride;
+            for (int i = lower_bound_u16(oi, klen, t0); i < klen; i++) {
                 const int t = oi[i];
                 if (t >= t0 + tn) break;
                 const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + t / CPW];
@@ -621,11 +633,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         {   // one sorted list per (channel, side) = per thread; its entries inside the chunk are [i0, i1)
             const int side = tid >> 7;
             const int64_t list = (bhk * AD + dq) * 2 + side;
-            const uint16_t* oi = a.koidx + list * (int64_t)a.kk;
-            const uint16_t* ov = a.koval + list * (int64_t)a.kk;
-            int i0, i1 = a.kk;
+            const uint16_t* oi = a.koidx + list * (int64_t)a.kk_stride;
+            const uint16_t* ov = a.koval + list * (int64_t)a.kk_stride;
+            int i0, i1 = k_list_len(a, Tc);
             if (a.kochunk) { i0 = ki0; i1 = ki1; }
-            else i0 = lower_bound_u16(oi, a.kk, t0);
+            else i0 = lower_bound_u16(oi, i1, t0);
             const int64_t ch = bhk * AD + dq;
             for (int base = i0; base < i1; base += 4) {   // 4 entries per trip: their loads fly together
                 int tt[4];
@@ -907,7 +919,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
                                 int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
                                 int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, const void* dyn_state,
                                 float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream,
-                     const void* kochunk, const void* vochunk) {
+                     const void* kochunk, const void* vochunk, int kk_stride = 0, int kk0 = 0, int kkb = 0) {
     GEAR_CHECK_ARG(wcap >= W, "gear_attn_decode: window pitch %d smaller than the window %d", wcap, W);
     GEAR_CHECK_ARG(seglen == 0 || (seglen % 64 == 0 && seg0 % 64 == 0 && seg0 >= 0),
                    "gear_attn_decode: factor segments must be multiples of 64 tokens (seg0=%d seglen=%d)", seg0, seglen);
@@ -937,11 +949,13 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     a.ldk = ldk; a.lsk = lsk; a.tcap_v = tcap_v; a.tf_k = tf_k; a.tf_v = tf_v;
     a.group = group; a.rk = (kP && kQ) ? rk : 0; a.rv = (vP && vQ) ? rv : 0;
     a.kk = (koidx && koval) ? kk : 0; a.kv = (voidx && voval) ? kv : 0;
+    a.kk_stride = kk_stride > 0 ? kk_stride : a.kk; a.kk0 = kk0; a.kkb = a.kk ? kkb : 0;
+    GEAR_CHECK_ARG(a.kk_stride >= a.kk && (a.kkb == 0 || (seglen > 0 && kk0 >= 0)), "gear_attn_decode: bad outlier list geometry");
     a.qscale = qscale;
     a.seg0 = seg0; a.seglen = seglen;
     a.dyn = (const int*)dyn_state;
     // chunk index of the outlier lists: only with 128-token bounds (K) / one bound per KV head (V), the small kernel's chunks
-    a.kochunk = a.kk ? (const uint8_t*)kochunk : nullptr;
+    a.kochunk = (a.kk && a.kkb == 0 && a.kk_stride == a.kk) ? (const uint8_t*)kochunk : nullptr;
     a.vochunk = a.kv ? (const uint8_t*)vochunk : nullptr;
     a.nbk = (T + SC - 1) / SC + 1;
     a.nbv = Hkv + 1;
@@ -1024,4 +1038,26 @@ extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void
     return gear_attn_decode_dyn(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin,
                                 vwin, B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv, kk, kv,
                                 seg0, seglen, wcap, nullptr, qscale, out, lse, workspace, workspace_bytes, stream);
+}
+
+// The streaming cache's entry point: as gear_attn_decode_dyn, with growing K outlier lists (see include/gear_hip.h).
+extern "C" int gear_attn_decode_stream(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                                       const void* kQ, const void* koidx, const void* koval, const void* vcode,
+                                       const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
+                                       const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D,
+                                       int T, int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits,
+                                       int mode, int rk, int rv, int kk_cap, int kk0, int kkb, int kv, int seg0, int seglen,
+                                       int wcap, const void* dyn_state, float qscale, void* out, void* lse, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    // kk (the argument the kernels treat as "there are K outliers") = the current length when it is known on the host
+    int kk_now = kk_cap;
+    if (!dyn_state && kkb > 0) {
+        const int nblk = (seglen > 0 && T > seg0) ? (T - seg0) / seglen : 0;
+        kk_now = kk0 + nblk * kkb;
+        if (kk_now > kk_cap) kk_now = kk_cap;
+    }
+    return attn_decode_impl(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin, vwin,
+                            B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv,
+                            kkb > 0 ? kk_cap : kk_now, kv, seg0, seglen, wcap, dyn_state, qscale, out, lse, workspace,
+                            workspace_bytes, stream, nullptr, nullptr, kk_cap, kk0, kkb);
 }

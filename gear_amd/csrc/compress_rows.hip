@@ -31,6 +31,10 @@ struct RowGeom {
     int64_t seg_stride;        // elements
     int seglen_shift;          // log2(seglen) if it is a power of two, else -1
     int group_shift;           // log2(group) (group is a power of two)
+    // geometry of code / scale / mn (elements of the fp16 tensor they describe): equal to the input's unless the payload is
+    // written in place into a larger pre-allocated tensor (the streaming cache); the error output follows the input.
+    int64_t o_outer_stride, o_inner_stride, o_seg_stride;
+    int o_list_outer;          // row r's sparse list is list row (r / rows_inner) * o_list_outer + r % rows_inner
 };
 
 // integer divisions by run-time values cost ~30-100 VALU instructions per lane on this VALU-bound kernel: every
@@ -44,6 +48,17 @@ __device__ __forceinline__ int64_t row_base_of(const RowGeom& gm, int64_t r) {
     const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;   // n_rows < 2^31 (checked on the host)
     const uint32_t qo = ru / ri;
     return (int64_t)qo * gm.outer_stride + (int64_t)(ru - qo * ri) * gm.inner_stride;
+}
+
+__device__ __forceinline__ int64_t lrow_of(const RowGeom& gm, int64_t r) {
+    const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;
+    const uint32_t qo = ru / ri;
+    return (int64_t)qo * gm.o_list_outer + (int64_t)(ru - qo * ri);
+}
+__device__ __forceinline__ int64_t row_base_out(const RowGeom& gm, int64_t r) {
+    const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;
+    const uint32_t qo = ru / ri;
+    return (int64_t)qo * gm.o_outer_stride + (int64_t)(ru - qo * ri) * gm.o_inner_stride;
 }
 
 __device__ __forceinline__ uint32_t sort_key(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit)
@@ -193,6 +208,7 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     if (active) seg_pos(gm, j0, seg, pos);
     const int64_t row_base = row_base_of(gm, r);
     const int64_t off = row_base + (int64_t)seg * gm.seg_stride + pos;  // element offset of this lane's 16 values
+    const int64_t ooff = row_base_out(gm, r) + (int64_t)seg * gm.o_seg_stride + pos;   // ... in the payload tensors
 
     uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
     if (active) {
@@ -320,8 +336,8 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
                     sv = wave_bitonic_sort<false>(sv);
                     if (lane < k) {
                         const uint32_t idx = sv >> 16;
-                        uint16_t* oi = oidx + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
-                        uint16_t* ov = oval + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                        uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                        uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
                         oi[lane] = (uint16_t)idx;
                         ov[lane] = (uint16_t)(sv & 0xFFFFu);
                         atomicOr(&omask[side][idx >> 5], 1u << (idx & 31));
@@ -398,8 +414,8 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
             unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
             unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
             int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
-            uint16_t* oi = oidx + r * (int64_t)(2 * k);
-            uint16_t* ov = oval + r * (int64_t)(2 * k);
+            uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k);
+            uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 if (flag_lo & (1u << j)) {
@@ -447,12 +463,12 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
         float d = (MODE == 0) ? dequant_one<0>(q, qp.scale, qp.mn) : hround(dequant_one<1>(q, qp.scale, qp.mn));
         e[j] = (outl & (1u << j)) ? 0.0f : (v[j] - d);
     }
-    uint32_t* cp = code + off / CPW;
+    uint32_t* cp = code + ooff / CPW;
 #pragma unroll
     for (int w = 0; w < WPL; w++) cp[w] = words[w];
     if ((tid & (lanes_per_group - 1)) == 0) {
-        st_st<ST>(scale + (off >> gm.group_shift), qp.scale);
-        st_st<ST>(mn + (off >> gm.group_shift), qp.mn);
+        st_st<ST>(scale + (ooff >> gm.group_shift), qp.scale);
+        st_st<ST>(mn + (ooff >> gm.group_shift), qp.mn);
     }
     if (err) {
         uint4* ep = (uint4*)(err + off);
@@ -589,9 +605,11 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     const int64_t row_base = row_base_of(gm, r);
     const uint32_t loff = (uint32_t)seg * (uint32_t)gm.seg_stride + (uint32_t)pos;
     const uint16_t* xrow = x + row_base;
-    uint32_t* code_row = code + row_base / CPW;                 // row_base is a multiple of the group size
-    ST* scale_row = scale + (row_base >> gm.group_shift);
-    ST* mn_row = mn + (row_base >> gm.group_shift);
+    const int64_t orow_base = row_base_out(gm, r);
+    const uint32_t ooff = (uint32_t)seg * (uint32_t)gm.o_seg_stride + (uint32_t)pos;
+    uint32_t* code_row = code + orow_base / CPW;                // row bases are multiples of the group size
+    ST* scale_row = scale + (orow_base >> gm.group_shift);
+    ST* mn_row = mn + (orow_base >> gm.group_shift);
     uint16_t* err_row = err ? err + row_base : nullptr;
 
     uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
@@ -726,8 +744,8 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
                     const bool s0 = x0 > lo_b || (t0 && r0 < need), s1 = x1 > lo_b || (t1 && r1 < need);
                     const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
                     const int p0 = __popcll(b0 & lt), p1 = __popcll(b0) + __popcll(b1 & lt);
-                    uint16_t* oi = oidx + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
-                    uint16_t* ov = oval + r * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                    uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                    uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
                     if (s0) {
                         const uint32_t idx = c0 & 0xFFFFu;
                         oi[p0] = (uint16_t)idx;
@@ -814,8 +832,8 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
             unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
             int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
-            uint16_t* oi = oidx + r * (int64_t)(2 * k);
-            uint16_t* ov = oval + r * (int64_t)(2 * k);
+            uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k);
+            uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 if (flag_lo & (1u << j)) {
@@ -918,12 +936,12 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
 #pragma unroll
         for (int w = 0; w < WPL; w++) words[w] = bfi32(spread_flags<BITS>(outl >> (w * CPW)), qrep, words[w]);
     }
-    uint32_t* cp = code_row + loff / CPW;
+    uint32_t* cp = code_row + ooff / CPW;
 #pragma unroll
     for (int w = 0; w < WPL; w++) cp[w] = words[w];
     if ((tid & (lanes_per_group - 1)) == 0) {
-        st_st<ST>(scale_row + (loff >> gm.group_shift), qscale);
-        st_st<ST>(mn_row + (loff >> gm.group_shift), qmn);
+        st_st<ST>(scale_row + (ooff >> gm.group_shift), qscale);
+        st_st<ST>(mn_row + (ooff >> gm.group_shift), qmn);
     }
     if (err) {
         // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
@@ -962,10 +980,10 @@ static double inv_norm_cdf(double p) {
            (((((b[0] * rr + b[1]) * rr + b[2]) * rr + b[3]) * rr + b[4]) * rr + 1);
 }
 
-extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride,
-                                  int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int group, int bits,
-                                  int mode, int k, void* code, void* scale, void* mn, void* err, void* oidx, void* oval,
-                                  void* omean, void* stream) {
+int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride,
+                            int nseg, int seglen, int64_t seg_stride, int64_t o_outer_stride, int64_t o_inner_stride,
+                            int64_t o_seg_stride, int o_list_outer, int group, int bits, int mode, int k, void* code,
+                            void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, void* stream) {
     GEAR_CHECK_ARG(bits == 2 || bits == 4 || bits == 8, "gear_compress_rows: bits must be 2, 4 or 8 (got %d)", bits);
     GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_compress_rows: bad mode %d", mode);
     GEAR_CHECK_ARG(n_rows > 0 && n_rows < 0x7FFFFFFFLL && nseg > 0 && seglen > 0, "gear_compress_rows: empty input");
@@ -976,13 +994,17 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
     GEAR_CHECK_ARG(k >= 0 && 2 * (int64_t)k <= len, "gear_compress_rows: k=%d out of range for row length %lld", k, (long long)len);
     GEAR_CHECK_ARG(outer_stride % group == 0 && inner_stride % group == 0 && (nseg == 1 || seg_stride % group == 0),
                    "gear_compress_rows: strides must be multiples of the group size");
+    GEAR_CHECK_ARG(o_outer_stride % group == 0 && o_inner_stride % group == 0 && (nseg == 1 || o_seg_stride % group == 0) &&
+                   (nseg - 1) * o_seg_stride + seglen < 0x7FFFFFFFLL && o_seg_stride >= 0,
+                   "gear_compress_rows: bad output strides");
+    GEAR_CHECK_ARG(o_list_outer >= rows_inner, "gear_compress_rows: bad sparse-list row pitch");
     GEAR_CHECK_ARG(x && code && scale && mn, "gear_compress_rows: null pointer");
     GEAR_CHECK_ARG((nseg - 1) * seg_stride + seglen < 0x7FFFFFFFLL && seg_stride >= 0,
                    "gear_compress_rows: a row must span fewer than 2^31 elements");
     GEAR_CHECK_ARG(k == 0 || (oidx && oval), "gear_compress_rows: outlier buffers required when k > 0");
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
     RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride,
-               gear_is_pow2(seglen) ? ilog2(seglen) : -1, ilog2(group)};
+               gear_is_pow2(seglen) ? ilog2(seglen) : -1, ilog2(group), o_outer_stride, o_inner_stride, o_seg_stride, o_list_outer};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     // tier-0 threshold: let about 2.2 k of a normal row's elements pass on each side (at most 128 may)
     float zthr = 0.0f;
@@ -1020,4 +1042,13 @@ extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner,
 #undef GO
     GEAR_CHECK_LAUNCH("gear_compress_rows");
     return 0;
+}
+
+extern "C" int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride,
+                                  int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int group, int bits,
+                                  int mode, int k, void* code, void* scale, void* mn, void* err, void* oidx, void* oval,
+                                  void* omean, void* stream) {
+    return gear_compress_rows_geom(x, n_rows, rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, outer_stride,
+                                   inner_stride, seg_stride, rows_inner, group, bits, mode, k, code, scale, mn, err, oidx, oval, omean,
+                                   stream);
 }

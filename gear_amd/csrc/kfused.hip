@@ -32,6 +32,13 @@
 
 int gear_qpass_tm(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_dtype, int q_tcap, int q_toff,
                   hipStream_t st);
+int gear_lowrank_gram_ex(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
+                         int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, int out_dtype,
+                         void* workspace, hipStream_t st);
+int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride,
+                            int nseg, int seglen, int64_t seg_stride, int64_t o_outer_stride, int64_t o_inner_stride,
+                            int64_t o_seg_stride, int o_list_outer, int group, int bits, int mode, int k, void* code,
+                            void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, void* stream);
 
 namespace {
 
@@ -1059,4 +1066,46 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         return gear_qpass_tm(err, Wws, BH, T, rank, Q_out, GEAR_DTYPE_F16, q_tcap, q_toff, st);
     }
     return 0;
+}
+
+// ================================================================================================ V side, in place
+// V [B][H][T][128] token-major -> V payload written at token row t_off of tensors with tcap token rows per head (the
+// streaming cache): the row compressor (rows = tokens across the H heads) with its output geometry, then the Gram-matrix
+// power iteration of the error and the Q pass with the factor row pitch.  Three launches + the solve inside the Gram kernel.
+extern "C" size_t gear_compress_value_fused_workspace(int64_t B, int H, int T, int rank) {
+    if (B <= 0 || H <= 0 || T <= 0) return 0;
+    const size_t RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
+    return (rank > 0 ? (size_t)B * H * T * KD * 2 + 256 + (size_t)B * H * KD * RP * 4 + 256 : 0) + 512;
+}
+
+extern "C" int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group, int bits, int mode, int k,
+                                         void* code, void* scale, void* mn, int tcap, int t_off, int rank, int loop,
+                                         const void* P0, void* P_out, int64_t p_inner, int64_t p_outer_stride, void* Q_out,
+                                         int q_tcap, int q_toff, void* oidx, void* oval, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    GEAR_CHECK_ARG(x && code && scale && mn && workspace, "gear_compress_value_fused: null pointer");
+    GEAR_CHECK_ARG(B > 0 && H > 0 && T > 0 && tcap >= t_off + T && t_off >= 0, "gear_compress_value_fused: bad shape");
+    GEAR_CHECK_ARG(workspace_bytes >= gear_compress_value_fused_workspace(B, H, T, rank), "gear_compress_value_fused: workspace too small");
+    GEAR_CHECK_ARG(rank == 0 || (P0 && P_out && Q_out && loop >= 1 && q_tcap >= q_toff + T && p_inner >= 1),
+                   "gear_compress_value_fused: bad factor geometry");
+    const int cpw = 32 / (bits ? bits : 2);
+    const int sel = mode == GEAR_MODE_FP16_STEPWISE ? 2 : 4;       // bytes per scale / mn element
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    uint16_t* err = rank > 0 ? (uint16_t*)base : nullptr;
+    void* lrws = rank > 0 ? (void*)(base + (((size_t)B * H * T * KD * 2 + 255) & ~(size_t)255)) : nullptr;
+    // payload row t of head h of batch b: element offset ((b * H + h) * tcap + t_off + t) * 128
+    char* code_o = (char*)code + (size_t)t_off * KD / cpw * 4;
+    char* scale_o = (char*)scale + (size_t)t_off * KD / group * sel;
+    char* mn_o = (char*)mn + (size_t)t_off * KD / group * sel;
+    // sparse part: oidx / oval [B][tcap][2k] rows t_off ..
+    uint16_t* oi = k > 0 ? (uint16_t*)oidx : nullptr;
+    uint16_t* ov = k > 0 ? (uint16_t*)oval : nullptr;
+    // one launch over all batch entries: row (b, t) -> payload row b * (H * tcap) ... + t_off + t, sparse list row b * tcap + t_off + t
+    const int rc = gear_compress_rows_geom(x, B * T, T, (int64_t)H * T * KD, KD, H, KD, (int64_t)T * KD, (int64_t)H * tcap * KD, KD,
+                                           (int64_t)tcap * KD, tcap, group, bits, mode, k, code_o, scale_o, mn_o, err,
+                                           oi ? oi + (int64_t)t_off * (2 * k) : nullptr, ov ? ov + (int64_t)t_off * (2 * k) : nullptr,
+                                           nullptr, stream);
+    if (rc != 0 || rank == 0) return rc;
+    return gear_lowrank_gram_ex(err, 0, B * H, T, rank, loop, P0, P_out, p_inner, p_outer_stride, Q_out, q_tcap, q_toff,
+                                GEAR_DTYPE_F16, lrws, (hipStream_t)stream);
 }

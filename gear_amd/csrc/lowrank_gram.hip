@@ -37,7 +37,7 @@ template <int RP, bool TOKEN_MAJOR>
 __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* __restrict__ E, int S, int loop,
                                                                const float* __restrict__ P0, int r,
                                                                float* __restrict__ Wout, void* __restrict__ P_out,
-                                                               int out_f16) {
+                                                               int out_f16, int64_t p_inner, int64_t p_outer_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* G = (float*)smem;                                  // [128][GP]
     uint16_t* tile = (uint16_t*)smem;                         // staging (aliases G during phase 1)
@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
     }
     // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS (lowrank_solve.h)
     __syncthreads();
+    // head bh of P_out lives at (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * r (a per-segment factor tensor of a cache)
+    const int64_t po = (bh / p_inner) * p_outer_stride + (bh % p_inner) * (int64_t)(GD * r);
     gram_solve_phase2<RP>(G, Pa, Pb, Md, Rinv, P0 + bh * GD * r, r, loop, Wout + bh * GD * RP,
-                          out_f16 ? (void*)((uint16_t*)P_out + bh * GD * r) : (void*)((float*)P_out + bh * GD * r), out_f16);
+                          out_f16 ? (void*)((uint16_t*)P_out + po) : (void*)((float*)P_out + po), out_f16);
 }
 
 template <int N>
@@ -326,21 +328,22 @@ __global__ __launch_bounds__(256) void lr_qpass_tm_mfma_kernel(const uint16_t* _
 
 template <int RP>
 int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int loop, const float* P0, void* P_out,
-             void* Q_out, int out_dtype, float* Wws, hipStream_t st) {
+             void* Q_out, int out_dtype, float* Wws, hipStream_t st, int64_t p_inner, int64_t p_outer_stride, int q_tcap,
+             int q_toff) {
     const int of16 = out_dtype == GEAR_DTYPE_F16;
     size_t shmem = (size_t)GD * GP * 4 + 2 * (size_t)GD * RP * 4 + 3 * (size_t)RP * RP * 8 + 16;
     if (transposed) {
         auto kfn = lr_gram_solve_kernel<RP, false>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16, p_inner, p_outer_stride);
         hipLaunchKernelGGL((lr_qpass_kt_kernel<RP>), dim3((S + 2047) / 2048, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
                            Q_out, of16);
     } else {
         auto kfn = lr_gram_solve_kernel<RP, true>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16, p_inner, p_outer_stride);
         hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<RP>), dim3((S + 511) / 512, (unsigned)bh), dim3(256), 0, st, E, Wws, S,
-                               r, Q_out, of16, S, 0);
+                               r, Q_out, of16, q_tcap, q_toff);
     }
     GEAR_CHECK_LAUNCH("gear_lowrank(gram)");
     return 0;
@@ -348,14 +351,21 @@ int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int lo
 
 }  // namespace
 
-// Called by gear_lowrank() when the fast path applies: fp16 error, Dm == 128, S % 8 == 0 (K^T layout).
-int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
-                      void* Q_out, int out_dtype, void* workspace, hipStream_t st) {
+// Called by gear_lowrank() when the fast path applies: fp16 error, Dm == 128, S % 8 == 0 (K^T layout).  The _ex form writes
+// P at a per-head offset and Q at a row offset of a larger tensor (token-major E only): the streaming cache's layouts.
+int gear_lowrank_gram_ex(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
+                         int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, int out_dtype,
+                         void* workspace, hipStream_t st) {
     const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
     float* Wws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    if (RP == 4) return run_gram<4>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
-    if (RP == 8) return run_gram<8>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
-    return run_gram<16>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st);
+    if (RP == 4) return run_gram<4>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st, p_inner, p_outer_stride, q_tcap, q_toff);
+    if (RP == 8) return run_gram<8>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st, p_inner, p_outer_stride, q_tcap, q_toff);
+    return run_gram<16>((const uint16_t*)E, transposed, bh, S, r, loop, (const float*)P0, P_out, Q_out, out_dtype, Wws, st, p_inner, p_outer_stride, q_tcap, q_toff);
+}
+
+int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
+                      void* Q_out, int out_dtype, void* workspace, hipStream_t st) {
+    return gear_lowrank_gram_ex(E, transposed, bh, S, r, loop, P0, P_out, bh, 0, Q_out, S, 0, out_dtype, workspace, st);
 }
 
 // Q' = E W for a token-major fp16 error E [bh][S][128] with the token-side factor written at row q_toff of a [bh][q_tcap][r]

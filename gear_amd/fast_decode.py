@@ -56,6 +56,7 @@ class FastGearDecoder:
         for lw in self.layers:
             lw["cache"].state = self.state
         self.graph = None
+        self._state_dirty = True      # host counters moved without the device-side state (eager step / prefill)
         self.tok = torch.zeros((batch, 1), dtype=torch.long, device=dev)
         self.logits_static = None
 
@@ -135,6 +136,7 @@ class FastGearDecoder:
             h = h + F.linear(a.transpose(1, 2).reshape(B, T, self.Hq * self.D), lw["wo"])
             h = h + layer.mlp(layer.post_attention_layernorm(h))
         self.pos = T
+        self._state_dirty = True
         return self.model.lm_head(m.norm(h[:, -1]))
 
     # ------------------------------------------------------------------------------------------------ decode
@@ -151,6 +153,7 @@ class FastGearDecoder:
             act = self._norm_linear(res, lw["wgu"], swiglu=True)
             res = self._linear_add(act, lw["wd"], res)
         self.pos += 1
+        self._state_dirty = True          # (the captured graph reads pos / slot / T / W from self.state)
         if self.layers[0]["cache"].n_win == self.layers[0]["cache"].R:
             self.pool.compress_all()
         return self._norm_linear(res, self.w_head)
@@ -185,11 +188,15 @@ class FastGearDecoder:
             self.tok.copy_(token_ids.view(self.batch, 1))
         if self.graph is None:
             self._sync_state()
+            self._state_dirty = False
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.logits_static = self._step_body_dyn()
             self.graph = g
+        elif self._state_dirty:          # an eager step() / prefill() ran since the last replay: bring the device state up to date
+            self._sync_state()
+        self._state_dirty = False
         self.graph.replay()
         self.pos += 1
         full = False

@@ -140,6 +140,17 @@ int gear_compress_key_fused(const void* x, int64_t BH, int T, int group, int bit
                             void* oval, int kcap, int o_off, int variant, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* V side, written in place (the streaming cache): V [B, H, T, 128] token-major -> payload rows t_off .. t_off + T of tensors
+ * with `tcap` token rows per head: code int32 [B, H, tcap, 128/fpi], scale / mn [B, H, tcap, 128/group], sparse lists
+ * oidx / oval [B, tcap, 2k] (gears_tokenQ semantics: a row = one token across the H heads,
+ * GenerationBench/.../Simulated/compress_function.py:297-333), factors as gear_compress_key_fused.  The row compressor with an
+ * output geometry, then the Gram-matrix power iteration and the Q pass. */
+size_t gear_compress_value_fused_workspace(int64_t B, int H, int T, int rank);
+int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group, int bits, int mode, int k, void* code,
+                              void* scale, void* mn, int tcap, int t_off, int rank, int loop, const void* P0, void* P_out,
+                              int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, void* oidx,
+                              void* oval, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a4 / a10: low-rank power iteration ---------------------------------------------------------------------
  * Replaces headwise_lrap (cuda_supported_gear/quant/new_pack.py:291-311) and fake_poweriteration_group
  * (compress_function.py:69-98).  for i < loop: [last: P = orth(P)] Q = E P [last: Q = orth(Q)] P = E^T Q.
@@ -249,6 +260,17 @@ int gear_attn_decode_idx(const void* q, const void* kcode, const void* kscale, c
                          int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv,
                          int kk, int kv, float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* Decode attention over a streaming cache whose K outlier lists grow block by block: koidx / koval are
+ * [B*Hkv, 128, 2, kk_cap]; of every (channel, side) list the first kk0 + kkb * ((T - seg0) / seglen) entries are valid (kk0 from
+ * the prompt segment, kkb appended per block, ascending token order is kept because later blocks hold later tokens).  With
+ * dyn_state the length follows the device-side T.  Everything else as gear_attn_decode_dyn. */
+int gear_attn_decode_stream(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
+                            const void* kQ, const void* koidx, const void* koval, const void* vcode, const void* vscale,
+                            const void* vmn, const void* vP, const void* vQ, const void* voidx, const void* voval,
+                            const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T, int W, int ldk, int lsk,
+                            int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv, int kk_cap, int kk0,
+                            int kkb, int kv, int seg0, int seglen, int wcap, const void* dyn_state, float qscale, void* out,
+                            void* lse, void* workspace, size_t workspace_bytes, void* stream);
 int gear_rope_append_dyn(const void* qkv, int B, int Hq, int Hkv, int D, const void* dyn_state, float theta, void* q_out,
                          void* kwin, void* vwin, int W, void* stream);
 int gear_decode_state_advance(void* state, void* stream);

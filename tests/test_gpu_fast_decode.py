@@ -25,6 +25,23 @@ def _reconstruct_cache(c):
          + np.repeat(host(c.kmn[:, :, :, :n // g]).astype(np.float64), g, 3)).transpose(0, 1, 3, 2)
     vq = orc.unpack_tensor(host(c.vcode[:, :, :n]), b, 3).astype(np.float64)                           # [B,H,n,D]
     V = vq * np.repeat(host(c.vscale[:, :, :n]).astype(np.float64), g, 3) + np.repeat(host(c.vmn[:, :, :n]).astype(np.float64), g, 3)
+    # sparse part: a stored outlier replaces the DEQUANTIZED value at its position; the low-rank term is added on top, as in the
+    # simulated path (output + error_lr with the outliers restored in output, compress_function.py:204-220)
+    if c.kk_blk and n:
+        klen = c.kk0 + ((n - c.seg0) // c.R) * c.kk_blk
+        oi = host(c.koidx[..., :klen]).astype(np.int64) & 0xFFFF                       # [B,H,D,2,klen] token indices
+        ov = host(c.koval[..., :klen]).astype(np.float64)
+        B_, H_, D_ = oi.shape[:3]
+        for b_ in range(B_):
+            for h_ in range(H_):
+                for d_ in range(D_):
+                    K[b_, h_, oi[b_, h_, d_].reshape(-1), d_] = ov[b_, h_, d_].reshape(-1)
+    if c.kv and n:
+        oi = host(c.voidx[:, :n]).astype(np.int64) & 0xFFFF                            # [B,n,2kv] column h*128 + d
+        ov = host(c.voval[:, :n]).astype(np.float64)
+        for b_ in range(oi.shape[0]):
+            for t_ in range(n):
+                V[b_, oi[b_, t_] // 128, t_, oi[b_, t_] % 128] = ov[b_, t_]
     if c.lowrank:
         t = 0
         while t < n:
@@ -58,14 +75,16 @@ def attn_option():
     L.set_option("attn_generic", 0)
 
 
-@pytest.mark.parametrize("method,bits,Hq,Hkv,T0", [("gearlKIVI", 2, 4, 4, 200), ("gearlKIVI", 4, 4, 2, 64), ("KIVI", 2, 2, 2, 30),
-                                                   ("gearlKIVI", 2, 2, 2, 2304)])
+@pytest.mark.parametrize("method,bits,Hq,Hkv,T0,left", [("gearlKIVI", 2, 4, 4, 200, 0.0), ("gearlKIVI", 4, 4, 2, 64, 0.0),
+                                                        ("KIVI", 2, 2, 2, 30, 0.0), ("gearlKIVI", 2, 2, 2, 2304, 0.0),
+                                                        ("gearlKIVI", 2, 4, 4, 200, 0.02), ("gearslKIVI", 4, 8, 2, 320, 0.05),
+                                                        ("KIVI", 2, 2, 2, 130, 0.02)])
 @pytest.mark.parametrize("kernel", ["planned", "generic"])
-def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, Hq, Hkv, T0):
+def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, Hq, Hkv, T0, left):
     from gear_amd.cache import GearKVCache
     attn_option(kernel == "generic")
     torch.manual_seed(71)
-    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3, left=left)
     B, D, steps = 2, 128, 150
     c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
     c.prefill(torch.randn(B, Hkv, T0, D).half().cuda(), torch.randn(B, Hkv, T0, D).half().cuda())
@@ -83,6 +102,93 @@ def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, 
         assert c.seq_len == T0 + i + 1 and c.n_win < 64
     assert worst < 2e-3, worst
     assert c.n_comp == (T0 + steps) - (T0 + steps) % 64
+
+
+def _oracle_block(x, layout, k, g, bits):
+    """Oracle (fp16-stepwise arithmetic, the fused path's mode) on one block: outlier selection on the block's rows, fill with the
+    fp16-rounded row mean, group quantization.  x fp16 [B,H,T,128]; layout "k": rows = channels over T, "v": rows = tokens
+    over H*128.  Returns (codes [rows, len], scale, mn, isml, ilrg, rows32)."""
+    B, H, T, D = x.shape
+    if layout == "k":
+        rows = np.ascontiguousarray(x.transpose(0, 1, 3, 2)).reshape(B * H * D, T).astype(np.float32)
+    else:
+        rows = np.ascontiguousarray(x.transpose(0, 2, 1, 3)).reshape(B * T, H * D).astype(np.float32)
+    orig = rows.copy()
+    isml = ilrg = None
+    if k > 0:
+        isml, ilrg, mean = orc.outlier_select(rows, k)
+        fill = mean.astype(np.float16).astype(np.float32)
+        np.put_along_axis(rows, isml, fill[:, None], 1)
+        np.put_along_axis(rows, ilrg, fill[:, None], 1)
+    q = orc.quant_pack_lastdim(rows.astype(np.float16), g, bits, mode=0)
+    return orc.unpack_tensor(q["code"], bits, 1), q["scale"], q["mn"], isml, ilrg, orig
+
+
+@pytest.mark.parametrize("left,bits,Hkv", [(0.0, 2, 2), (0.02, 2, 4), (0.05, 4, 2)])
+def test_cache_contents_match_oracle_block_by_block(left, bits, Hkv):
+    """After a prefill and 150 appended tokens every block of the cache -- packed codes, scale / zero point, outlier lists
+    and values -- is what the ORACLE makes of the fp16 K / V of exactly that block (bit-exact: fp16-stepwise arithmetic):
+    a block written from the wrong window slice, at the wrong offset or with the wrong list position fails here."""
+    from gear_amd.cache import GearKVCache
+    torch.manual_seed(73)
+    B, D, T0, steps, g, R = 2, 128, 200, 150, 64, 64
+    cc = dict(compress_method="gearlKIVI", group_size=g, residual=R, quantize_bit=bits, rank=4, rankv=4, loop=3, left=left)
+    c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
+    k_all = torch.randn(B, Hkv, T0 + steps, D).half()
+    v_all = torch.randn(B, Hkv, T0 + steps, D).half()
+    c.prefill(k_all[:, :, :T0].cuda(), v_all[:, :, :T0].cuda())
+    for i in range(T0, T0 + steps):
+        c.append(k_all[:, :, i:i + 1].cuda(), v_all[:, :, i:i + 1].cuda())
+        c.maybe_compress()
+    n = c.n_comp
+    assert n == (T0 + steps) // R * R and c.seg0 == T0 // R * R
+    fpi = 32 // bits
+    kcode = orc.unpack_tensor(host(c.kcode[:, :, :, :n // fpi]), bits, 3)        # [B,H,D,n]
+    vcode = orc.unpack_tensor(host(c.vcode[:, :, :n]), bits, 3)                  # [B,H,n,D]
+    blocks = [(0, c.seg0, c.kk0)] + [(t, t + R, c.kk_blk) for t in range(c.seg0, n, R)]
+    o_off = 0
+    for t0, t1, kk in blocks:
+        kb, vb = k_all[:, :, t0:t1].numpy(), v_all[:, :, t0:t1].numpy()
+        T = t1 - t0
+        # ---- K: rows = channels over the block's tokens
+        qc, sc, mn, isml, ilrg, rows = _oracle_block(kb, "k", kk, g, bits)
+        got = kcode[:, :, :, t0:t1].reshape(B * Hkv * D, T)
+        mask = np.ones_like(qc, bool)
+        if kk:
+            np.put_along_axis(mask, isml, False, 1)
+            np.put_along_axis(mask, ilrg, False, 1)
+            oi = (host(c.koidx[..., o_off:o_off + kk]).astype(np.int64) & 0xFFFF).reshape(B * Hkv * D, 2, kk) - t0
+            assert np.array_equal(oi[:, 0], np.sort(isml, 1)) and np.array_equal(oi[:, 1], np.sort(ilrg, 1)), (t0, "K outlier sets")
+            ov = host(c.koval[..., o_off:o_off + kk]).reshape(B * Hkv * D, 2 * kk)
+            assert np.array_equal(ov.view(np.uint16), np.take_along_axis(rows, oi.reshape(B * Hkv * D, 2 * kk), 1).astype(np.float16).view(np.uint16))
+        assert np.array_equal(got[mask], qc[mask]), (t0, "K codes")
+        assert np.array_equal(host(c.kscale[:, :, :, t0 // g:t1 // g]).reshape(sc.shape).view(np.uint16), sc.view(np.uint16)), (t0, "K scale")
+        assert np.array_equal(host(c.kmn[:, :, :, t0 // g:t1 // g]).reshape(mn.shape).view(np.uint16), mn.view(np.uint16)), (t0, "K mn")
+        o_off += kk
+        # ---- V: rows = tokens across the heads
+        qc, sc, mn, isml, ilrg, rows = _oracle_block(vb, "v", c.kv, g, bits)
+        got = np.ascontiguousarray(vcode[:, :, t0:t1].transpose(0, 2, 1, 3)).reshape(B * T, Hkv * D)
+        mask = np.ones_like(qc, bool)
+        if c.kv:
+            np.put_along_axis(mask, isml, False, 1)
+            np.put_along_axis(mask, ilrg, False, 1)
+            oi = (host(c.voidx[:, t0:t1]).astype(np.int64) & 0xFFFF).reshape(B * T, 2 * c.kv)
+            assert np.array_equal(oi[:, :c.kv], np.sort(isml, 1)) and np.array_equal(oi[:, c.kv:], np.sort(ilrg, 1)), (t0, "V outlier sets")
+            ov = host(c.voval[:, t0:t1]).reshape(B * T, 2 * c.kv)
+            assert np.array_equal(ov.view(np.uint16), np.take_along_axis(rows, oi, 1).astype(np.float16).view(np.uint16))
+        assert np.array_equal(got[mask], qc[mask]), (t0, "V codes")
+        vs = np.ascontiguousarray(host(c.vscale[:, :, t0:t1]).transpose(0, 2, 1, 3)).reshape(sc.shape)
+        vm = np.ascontiguousarray(host(c.vmn[:, :, t0:t1]).transpose(0, 2, 1, 3)).reshape(mn.shape)
+        assert np.array_equal(vs.view(np.uint16), sc.view(np.uint16)) and np.array_equal(vm.view(np.uint16), mn.view(np.uint16)), (t0, "V scale / mn")
+    # nothing was written past the compressed tokens
+    assert int(c.kcode[:, :, :, n // fpi:].abs().max()) == 0 and int(c.vcode[:, :, n:].abs().max()) == 0
+    # the factors of every segment approximate that block's error: reconstruction beats the quantized backbone alone
+    K, V = _reconstruct_cache(c)
+    ek = np.linalg.norm(K - k_all[:, :, :n].numpy().astype(np.float64))
+    c.lowrank = False
+    K0, _ = _reconstruct_cache(c)
+    c.lowrank = True
+    assert ek < np.linalg.norm(K0 - k_all[:, :, :n].numpy().astype(np.float64))
 
 
 def test_glue_kernels_match_torch():
@@ -163,6 +269,35 @@ def test_fast_decoder_generate_lowrank_deterministic():
     a = FastGearDecoder(model, 256, batch=2, seed=3).generate(ids, 200)
     b = FastGearDecoder(model, 256, batch=2, seed=3).generate(ids, 200)
     assert a.shape == (2, 200) and torch.equal(a, b) and torch.equal(a[:, :70], ids)
+
+
+def test_graph_and_eager_steps_interleave():
+    """step() after the graph was captured moves the host counters only; the next replay must first bring the device-side
+    {pos, slot, T, W} up to date (round-1 advisor finding: it replayed with a stale state).  Teacher-forced against a purely
+    eager decoder over a run with outliers in the cache and one block boundary."""
+    from gear_amd.fast_decode import FastGearDecoder
+    from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
+    cfg = LlamaConfigLite(vocab_size=1000, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, k_bits=2, v_bits=2)
+    cc = dict(compress_method="gearlKIVI", group_size=64, residual=64, quantize_bit=2, rank=4, rankv=4, loop=3, left=0.03)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM_GEARKIVI(cfg, cc).half().cuda().eval()
+    ids = torch.randint(0, 1000, (1, 100)).cuda()
+    fe, fg = FastGearDecoder(model, 512, seed=5), FastGearDecoder(model, 512, seed=5)
+    tok = fe.prefill(ids).argmax(-1, keepdim=True)
+    fg.prefill(ids)
+    worst = 1.0
+    for i in range(60):
+        le = fe.step(tok)
+        if i % 3 == 2 or i < 2:
+            lg = fg.step(tok)                     # eager step in between
+        else:
+            fg.step_graph(tok)
+            lg = fg.logits_static
+        worst = min(worst, float(torch.nn.functional.cosine_similarity(le.float(), lg.float()).min()))
+        tok = le.argmax(-1, keepdim=True)
+    assert worst > 0.9995, worst
+    assert (fe.pos, fe.layers[0]["cache"].n_comp) == (fg.pos, fg.layers[0]["cache"].n_comp) == (160, 128)
 
 
 def test_graph_replay_matches_eager_decode():
@@ -283,12 +418,13 @@ def test_fused_qkv_rope_matches_gemv_plus_rope_append():
         assert float(kw1[:, :, :slot].abs().max()) == 0 and float(kw1[:, :, slot + 1:].abs().max()) == 0
 
 
-def test_pooled_block_compress_matches_per_layer():
+@pytest.mark.parametrize("left", [0.0, 0.03])
+def test_pooled_block_compress_matches_per_layer(left):
     """GearKVCachePool.compress_all (all layers' windows in one compress call) writes exactly what the per-layer
-    GearKVCache.maybe_compress path writes (quantization-only cache: no random bases involved)."""
+    GearKVCache.maybe_compress path writes (quantization-only cache: no random bases involved), outlier lists included."""
     from gear_amd.cache import GearKVCache, GearKVCachePool
     torch.manual_seed(91)
-    cc = dict(compress_method="KIVI", group_size=64, residual=64, quantize_bit=2, rank=0, rankv=0, loop=0)
+    cc = dict(compress_method="KIVI", group_size=64, residual=64, quantize_bit=2, rank=0, rankv=0, loop=0, left=left)
     Lyr, B, H, D = 3, 2, 2, 128
     pool = GearKVCachePool(Lyr, B, H, 256, cc, "cuda", D)
     pooled = [GearKVCache(B, H, 256, cc, "cuda", D, pool=pool, layer=i) for i in range(Lyr)]
@@ -304,7 +440,11 @@ def test_pooled_block_compress_matches_per_layer():
             cs.maybe_compress()
         for cp, cs in zip(pooled, single):
             assert cp.n_comp == cs.n_comp == 64 * (blk + 1) and cp.n_win == cs.n_win == 0
-            for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn"):
+            for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn") + (("koidx", "koval", "voidx", "voval") if left else ()):
                 assert torch.equal(getattr(cp, name), getattr(cs, name)), name
     q = torch.randn(B, 4, 1, D).half().cuda()
-    assert torch.equal(pooled[1].attend(q), single[1].attend(q))
+    a, b_ = pooled[1].attend(q), single[1].attend(q)
+    if left:   # the sparse corrections are added with fp32 LDS atomics: the order of the additions is not fixed
+        assert float((a.float() - b_.float()).abs().max()) <= 2e-3 * float(b_.float().abs().max())
+    else:
+        assert torch.equal(a, b_)
