@@ -41,7 +41,7 @@ def _sparsity(cc) -> float:
     return float(cc.get("left", cc.get("sparsity", 0.0)) or 0.0)
 
 
-def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128):
+def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=None):
     bits, group, R = cc["quantize_bit"], cc["group_size"], cc["residual"]
     m = cc["compress_method"]
     lowrank = ("gearl" in m) or ("gearsl" in m)
@@ -58,7 +58,11 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128):
     B, H, D, T = batch, n_kv_heads, head_dim, Tmax
     s = _sparsity(cc)
     kv = int(int(B * H * T * D * s) / B / T / 2) if s > 0 else 0          # per side per token row (compress_function.py:300-303)
-    kk0_max = kv                                                          # the same formula for the prompt's channel rows
+    # the same formula for the prompt's channel rows -- on the FULL head count when this cache is one head shard of several
+    # (a K row lives inside one head, so its outlier count must not depend on how the heads are spread over GPUs; a V row
+    # spans the heads, so a shard selects k / world inside its own heads: see parallel.py)
+    Ht = heads_total or H
+    kk0_max = int(int(B * Ht * T * D * s) / B / T / 2) if s > 0 else 0
     kk_blk = max(1, round(R * s / 2)) if s > 0 else 0                     # nominal count for a 64-token block (B7)
     kcap = kk0_max + (Tmax // R) * kk_blk
     shapes = dict(kcode=((B, H, D, T // fpi), torch.int32), kscale=((B, H, D, T // group), torch.float16),
@@ -122,8 +126,8 @@ class GearKVCachePool:
     of every layer in place (compress_all): 7 launches per block boundary."""
 
     def __init__(self, n_layers: int, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device,
-                 head_dim: int = 128, seed: int = 0):
-        shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim)
+                 head_dim: int = 128, seed: int = 0, heads_total: int = None):
+        shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim, heads_total)
         self.L, self.B, self.H, self.D = n_layers, batch, n_kv_heads, head_dim
         self.loop = int(compress_config.get("loop", 3))
         self.buf = {}
@@ -154,10 +158,11 @@ class GearKVCachePool:
 
 class GearKVCache:
     def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device, head_dim: int = 128,
-                 seed: int = 0, state: torch.Tensor = None, pool: GearKVCachePool = None, layer: int = 0):
+                 seed: int = 0, state: torch.Tensor = None, pool: GearKVCachePool = None, layer: int = 0,
+                 heads_total: int = None):
         assert head_dim == 128
         cc = compress_config
-        shapes, d = _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim)
+        shapes, d = _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim, heads_total)
         self.dims = d
         self.B, self.H, self.D = batch, n_kv_heads, head_dim
         self.bits, self.group, self.R = d["bits"], d["group"], d["R"]

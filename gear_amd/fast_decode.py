@@ -19,11 +19,20 @@ from .modeling_llamagear import apply_rotary_pos_emb
 
 
 class FastGearDecoder:
-    def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0):
+    def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0, tp_rank: int = 0, tp_world: int = 1,
+                 tp_group=None):
+        """tp_world > 1: the cache and the attention are sharded head-wise: this rank owns
+        Hq / tp_world query heads with their KV heads -- local q/k/v projection rows, local compressed cache, local attention --
+        and all-gathers the per-rank attention output (parallel.HeadGather, pre-allocated) in front of the replicated
+        o_proj / MLP, which every rank computes in full.  The model passed in holds the full (replicated) weights."""
         self.model = model
         cfg = model.config
         self.cfg = cfg
-        self.Hq, self.Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.tp_rank, self.tp_world = tp_rank, tp_world
+        self.Hq_full, self.Hkv_full = cfg.num_attention_heads, cfg.num_key_value_heads
+        if self.Hq_full % tp_world or self.Hkv_full % tp_world:
+            raise ValueError(f"{self.Hq_full} query / {self.Hkv_full} KV heads do not divide across {tp_world} ranks")
+        self.Hq, self.Hkv = self.Hq_full // tp_world, self.Hkv_full // tp_world          # local heads
         self.D = cfg.hidden_size // cfg.num_attention_heads
         self.eps = cfg.rms_norm_eps
         self.theta = float(cfg.rope_theta)
@@ -32,7 +41,8 @@ class FastGearDecoder:
         self.layers = []
         cc0 = model.model.layers[0].self_attn.compress_config
         # pooled cache storage: block boundaries compress every layer's window in one launch sequence
-        self.pool = GearKVCachePool(len(model.model.layers), batch, self.Hkv, max_tokens, cc0, dev, self.D, seed=seed)
+        self.pool = GearKVCachePool(len(model.model.layers), batch, self.Hkv, max_tokens, cc0, dev, self.D, seed=seed,
+                                    heads_total=self.Hkv_full)
         for i, layer in enumerate(model.model.layers):
             at, mlp = layer.self_attn, layer.mlp
             assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
@@ -40,12 +50,19 @@ class FastGearDecoder:
             # row scale rsqrt(mean(h^2) + eps) to its finished dot products), gate/up rows are interleaved so a GEMV
             # block finishes whole SwiGLU pairs
             n1, n2 = layer.input_layernorm.weight, layer.post_attention_layernorm.weight
-            wqkv = torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], 0) * n1[None, :]
+            wqkv_full = torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], 0) * n1[None, :]
+            if tp_world > 1:
+                D, r = self.D, tp_rank
+                wqkv = torch.cat([at.q_proj.weight[r * self.Hq * D:(r + 1) * self.Hq * D],
+                                  at.k_proj.weight[r * self.Hkv * D:(r + 1) * self.Hkv * D],
+                                  at.v_proj.weight[r * self.Hkv * D:(r + 1) * self.Hkv * D]], 0) * n1[None, :]
+            else:
+                wqkv = wqkv_full
             wgu = torch.stack([mlp.gate_proj.weight, mlp.up_proj.weight], 1).reshape(-1, n2.shape[0]) * n2[None, :]
             self.layers.append(dict(
-                wqkv=wqkv.contiguous(), wo=at.o_proj.weight, wgu=wgu.contiguous(), wd=mlp.down_proj.weight,
+                wqkv=wqkv.contiguous(), wqkv_full=wqkv_full if tp_world > 1 else None, wo=at.o_proj.weight, wgu=wgu.contiguous(), wd=mlp.down_proj.weight,
                 cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i,
-                                  pool=self.pool, layer=i),
+                                  pool=self.pool, layer=i, heads_total=self.Hkv_full),
                 rotary=at.rotary_emb))
         self.w_head = (model.lm_head.weight * model.model.norm.weight[None, :]).contiguous()
         self.pos = 0
@@ -59,6 +76,15 @@ class FastGearDecoder:
         self._state_dirty = True      # host counters moved without the device-side state (eager step / prefill)
         self.tok = torch.zeros((batch, 1), dtype=torch.long, device=dev)
         self.logits_static = None
+        self.gather = None
+        if tp_world > 1:
+            from .parallel import HeadGather
+            self.gather = HeadGather(tp_world, batch, self.Hq * self.D, torch.float16, dev, tp_group)
+
+    def _attn_out(self, a):
+        """[B, Hq_local, 1, D] of this rank -> [B, Hq_full * D] (all-gather over the head shards when sharded)."""
+        a = a.view(a.shape[0], self.Hq * self.D)
+        return a if self.gather is None else self.gather(a)
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _fused(self, B, K):
@@ -120,20 +146,24 @@ class FastGearDecoder:
         m = self.model.model
         h = m.embed_tokens(input_ids)
         pos = torch.arange(T, device=self.dev).unsqueeze(0)
-        n_rep = self.Hq // self.Hkv
+        n_rep = self.Hq_full // self.Hkv_full
         for lw, layer in zip(self.layers, m.layers):
-            qkv = F.linear(self._unit_rms(h), lw["wqkv"])      # input_layernorm's weight lives in wqkv's columns
-            q, k, v = qkv.split([self.Hq * self.D, self.Hkv * self.D, self.Hkv * self.D], dim=-1)
-            q = q.view(B, T, self.Hq, self.D).transpose(1, 2)
-            k = k.view(B, T, self.Hkv, self.D).transpose(1, 2)
-            v = v.view(B, T, self.Hkv, self.D).transpose(1, 2)
+            # (the prompt is processed replicated, with every head; each rank keeps its own heads' K / V)
+            wq = lw["wqkv"] if lw["wqkv_full"] is None else lw["wqkv_full"]
+            qkv = F.linear(self._unit_rms(h), wq)              # input_layernorm's weight lives in wqkv's columns
+            Hq, Hkv = self.Hq_full, self.Hkv_full
+            q, k, v = qkv.split([Hq * self.D, Hkv * self.D, Hkv * self.D], dim=-1)
+            q = q.view(B, T, Hq, self.D).transpose(1, 2)
+            k = k.view(B, T, Hkv, self.D).transpose(1, 2)
+            v = v.view(B, T, Hkv, self.D).transpose(1, 2)
             cos, sin = lw["rotary"](v, pos)
             q, k = apply_rotary_pos_emb(q, k, cos, sin)
-            lw["cache"].prefill(k, v)
+            k0 = self.tp_rank * self.Hkv
+            lw["cache"].prefill(k[:, k0:k0 + self.Hkv], v[:, k0:k0 + self.Hkv])
             kk = k if n_rep == 1 else k.repeat_interleave(n_rep, 1)
             vv = v if n_rep == 1 else v.repeat_interleave(n_rep, 1)
             a = F.scaled_dot_product_attention(q, kk, vv, is_causal=True)
-            h = h + F.linear(a.transpose(1, 2).reshape(B, T, self.Hq * self.D), lw["wo"])
+            h = h + F.linear(a.transpose(1, 2).reshape(B, T, Hq * self.D), lw["wo"])
             h = h + layer.mlp(layer.post_attention_layernorm(h))
         self.pos = T
         self._state_dirty = True
@@ -149,7 +179,7 @@ class FastGearDecoder:
             cache = lw["cache"]
             q = self._norm_qkv_rope(res, lw, dyn=False)
             a = cache.attend(q)
-            res = self._linear_add(a.view(a.shape[0], self.Hq * self.D), lw["wo"], res)
+            res = self._linear_add(self._attn_out(a), lw["wo"], res)
             act = self._norm_linear(res, lw["wgu"], swiglu=True)
             res = self._linear_add(act, lw["wd"], res)
         self.pos += 1
@@ -171,7 +201,7 @@ class FastGearDecoder:
         for lw in self.layers:
             q = self._norm_qkv_rope(res, lw, dyn=True)
             a = lw["cache"].attend_dyn(q)
-            res = self._linear_add(a.view(a.shape[0], self.Hq * self.D), lw["wo"], res)
+            res = self._linear_add(self._attn_out(a), lw["wo"], res)
             act = self._norm_linear(res, lw["wgu"], swiglu=True)
             res = self._linear_add(act, lw["wd"], res)
         logits = self._norm_linear(res, self.w_head)

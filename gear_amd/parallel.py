@@ -13,7 +13,7 @@ BASELINE.json's 1/2/4/8-GPU rows:
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Tuple
 
 import torch
 
@@ -35,9 +35,36 @@ def all_gather_heads(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
     """x [B, q, H_local*D] on every rank -> [B, q, world*H_local*D] with rank r's heads at slot r."""
     import torch.distributed as dist
     x = x.contiguous()
-    parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(parts, x, group=group)
-    return torch.cat(parts, dim=-1)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)   # ranks concatenated on dim 0
+    with torch.no_grad():                                 # (inference path; gloo's implementation writes through views)
+        dist.all_gather_into_tensor(out, x.detach(), group=group)   # one collective into one buffer (no tensor list, no cat)
+    return out.view((world,) + tuple(x.shape)).movedim(0, -2).reshape(*x.shape[:-1], world * x.shape[-1])
+
+
+class HeadGather:
+    """All-gather of the per-rank attention output of a decode step into a PRE-ALLOCATED buffer with
+    all_gather_into_tensor: one collective per layer per token, no list of tensors, no torch.cat (the exchange is a few KiB
+    and latency-bound: a single hop over xGMI on MI355X, where backend "nccl" is RCCL).
+    x [B, H_local*D] on every rank -> [B, world*H_local*D] with rank r's heads at slot r."""
+
+    def __init__(self, world: int, batch: int, width: int, dtype, device, group=None):
+        import torch.distributed as dist
+        self.world, self.B, self.width, self.group = world, batch, width, group
+        self.buf = torch.empty((world * batch, width), dtype=dtype, device=device)       # ranks concatenated on dim 0
+        # gloo cannot gather device tensors: the one-GPU debug mode of bench.py / the tests stage through the host
+        self.stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        if self.stage:
+            hb = torch.empty(self.buf.shape, dtype=self.buf.dtype)
+            dist.all_gather_into_tensor(hb, x.contiguous().cpu(), group=self.group)
+            self.buf.copy_(hb)
+        else:
+            dist.all_gather_into_tensor(self.buf, x.contiguous(), group=self.group)
+        if self.B == 1:
+            return self.buf.view(1, self.world * self.width)          # rank-major == head-major for one row
+        return self.buf.view(self.world, self.B, self.width).permute(1, 0, 2).reshape(self.B, self.world * self.width)
 
 
 def shard_attention_weights(full_attn, local_attn):
