@@ -9,14 +9,21 @@ per second, whole job (all ranks).
 
 Workload (BASELINE.json): default = configs[2], the one the metric is quoted on
     "Llama-2-7B, seq=4096, 2-bit KIVI-style per-channel K / per-token V + rank-8 + 2% outlier, 1xMI355X"
-    (--config c2 selects configs[1]: seq=2048, 4-bit, rank-4, 1%).
-Multi-GPU: KV heads are sharded across ranks (7B: 32/N heads per GPU); compress / decompress need no data-path
-collective (V outlier rows are selected per shard with k scaled by 1/N); total work is fixed ->
-"scaling": "strong".
+    --config c2 = configs[1] (seq 2048, 4-bit, rank 4, 1 %), c4 = configs[3] (13B, 1 %), c5 = configs[4] (70B GQA, 8k, rank 16).
+Multi-GPU: KV heads are sharded across ranks (7B: 32/N heads per GPU, 13B: 40/4, 70B: 8/8 = one KV head with its 8 query
+heads); compress / decompress need no data-path collective (V outlier rows are selected per shard with k / N, see
+DESIGN.md); total work is fixed -> "scaling": "strong".  The decode leg shards the attention the same way and all-gathers
+the per-rank attention output (RCCL) in front of the replicated o_proj.
+
+Accounting: `roofline` = the single longest kernel of the step, timed in isolation with HIP events on
+its launch stream, ALGORITHMIC bytes of SURVEY.md 8(d) (read 2n, write codes + scale/mn + outliers -- no error term);
+`roofline_chain` = the same byte definition per whole stage; `kernels` = the other large kernels one by one;
+`traffic` comes from profiles/r2_traffic.json and only when that file was measured on the library that is loaded now.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      (N > 1 via torch.distributed.run, one rank per GPU)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,12 +36,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (model, layers, kv_heads, head_dim, T, bits, group, rank, loop, sparsity)
-    "c3": ("Llama-2-7B", 32, 32, 128, 4096, 2, 64, 8, 3, 0.02),
-    "c2": ("Llama-2-7B", 32, 32, 128, 2048, 4, 64, 4, 3, 0.01),
+    "c3": dict(model="Llama-2-7B", layers=32, q_heads=32, kv_heads=32, hidden=4096, inter=11008, T=4096, bits=2, group=64,
+               rank=8, loop=3, s=0.02, idx=2),
+    "c2": dict(model="Llama-2-7B", layers=32, q_heads=32, kv_heads=32, hidden=4096, inter=11008, T=2048, bits=4, group=64,
+               rank=4, loop=3, s=0.01, idx=1),
+    "c4": dict(model="Llama-2-13B", layers=40, q_heads=40, kv_heads=40, hidden=5120, inter=13824, T=4096, bits=2, group=64,
+               rank=8, loop=3, s=0.01, idx=3),
+    "c5": dict(model="Llama-2-70B (GQA)", layers=80, q_heads=64, kv_heads=8, hidden=8192, inter=28672, T=8192, bits=2, group=64,
+               rank=16, loop=3, s=0.02, idx=4),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_C3 = 2.4917e9   # HBM bytes per compress_rows launch (mean of the V and K^T launches), profiles/r1_pmc_traffic_rows_fp32.md
+D = 128
+HBM_PEAK_GBS = 8000.0  # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is what a plain copy reaches
 
 
 def parse():
@@ -49,26 +61,35 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 4, 8),
                     help="1: one stream; 2: the K chain and the V chain of a step run on two HIP streams (they are independent); "
                          "4 / 8: each of them additionally split into 2 / 4 groups of layers")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the step's launches once as a hipGraph and replay it (takes the host enqueue cost out of short "
-                         "steps; measured within noise of eager launches at every size tried, so it is off by default)")
+    ap.add_argument("--key-path", default="auto", choices=("auto", "fused", "rows"),
+                    help="K compress route: fused token-major kernels, or the transpose + row-compressor chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the full-model decode tokens/s leg")
+    ap.add_argument("--decode-tokens", type=int, default=64)
     return ap.parse_args()
+
+
+def lib_sha256():
+    from gear_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
 
 
 def cpu_baseline(cfg):
     """The oracle (CPU restatement of the reference's simulated path, validated against the reference in the build
-    container) on a bounded sample of the same workload: ONE layer's K and V at full heads / context."""
+    container) on a bounded sample of the same workload: 8 layers' K and V at full heads / context."""
     import numpy as np
     from oracle import oracle as orc
-    model, layers, H, D, T, bits, group, rank, loop, s = cfg
-    Hs, nl = H, 8  # bounded sample: 8 of the 32 layers, all heads, full context (about 10 s on the GPU box's host cores)
+    H, T, bits, group, rank, loop, s = cfg["kv_heads"], cfg["T"], cfg["bits"], cfg["group"], cfg["rank"], cfg["loop"], cfg["s"]
+    nl = max(1, min(8, (32 * 4096 * 8) // (H * T)))   # about 10 s on the GPU box's host cores
     rng = np.random.default_rng(0)
-    k = rng.standard_normal((nl, Hs, T, D)).astype(np.float16)
-    v = rng.standard_normal((nl, Hs, T, D)).astype(np.float16)
-    P0k = rng.random((nl, Hs, D, rank), dtype=np.float32)
-    P0v = rng.random((nl, Hs, D, rank), dtype=np.float32)
+    k = rng.standard_normal((nl, H, T, D)).astype(np.float16)
+    v = rng.standard_normal((nl, H, T, D)).astype(np.float16)
+    P0k = rng.random((nl, H, D, rank), dtype=np.float32)
+    P0v = rng.random((nl, H, D, rank), dtype=np.float32)
     orc.compress_insert_function(k[:1, :1, :256], v[:1, :1, :256], "GEAR", bits, group, rank, rank, loop, s,
                                  P0k[:1, :1], P0v[:1, :1])  # warm up / load the library
     t0 = time.perf_counter()
@@ -77,35 +98,43 @@ def cpu_baseline(cfg):
     nbytes = 2 * (k.size + v.size) * 2  # quantize->dequantize round trip: counted like the GPU step
     return {
         "value": nbytes / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
-        "sample": f"oracle compress_insert_function(GEAR) on {nl} layers x {Hs} heads x T={T} (K+V), {dt:.2f} s",
+        "sample": f"oracle compress_insert_function(GEAR) on {nl} layers x {H} heads x T={T} (K+V), {dt:.2f} s",
+        # for scale: the reference's own torch CPU path, measured in the BUILD container (it cannot travel), BASELINE.md section 2
+        "reference_torch_in_build_container": {"value": 0.15, "unit": "GB/s", "cores": 8,
+                                               "what": "compress_insert_function(GEAR, prefill) 7B one layer T=4096, 8 vCPU Xeon 2.1 GHz"},
     }
 
 
-def decode_tokens_per_s(cfg, dev, new_tokens=64):
-    """a14 counterpart (cuda_supported_gear/test.py:95-102): random-weight Llama-2-7B through the GEAR attention hook
-    (packed cache, fused dequant GEMV, block compression every `residual` tokens), greedy decode, one synchronize
-    before the clock stops.  Prefill = context - new_tokens so that decoding happens AT the named context."""
-    import torch
+def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
+    """a14 counterpart (cuda_supported_gear/test.py:95-102): random-weight model of the named shapes through the GEAR cache
+    (packed cache with per-block low-rank factors and sparse outliers, fused decode attention, block compression every 64
+    tokens), greedy decode, one synchronize before the clock stops.  Prefill = context - new_tokens so that decoding happens
+    AT the named context.  world > 1: head-sharded attention + all-gather of the attention output."""
     from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
-    model_name, layers, H, D, T, bits, group, rank, loop, s = cfg
-    mcfg = LlamaConfigLite(num_hidden_layers=layers, num_attention_heads=H, num_key_value_heads=H, hidden_size=H * D,
-                           max_position_embeddings=max(4096, T), k_bits=bits, v_bits=bits, group_size=group, residual_length=64)
-    cc = dict(compress_method="gearlKIVI", group_size=group, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=loop)
+    T, bits, group, rnk, loop, s = cfg["T"], cfg["bits"], cfg["group"], cfg["rank"], cfg["loop"], cfg["s"]
+    mcfg = LlamaConfigLite(num_hidden_layers=cfg["layers"], num_attention_heads=cfg["q_heads"],
+                           num_key_value_heads=cfg["kv_heads"], hidden_size=cfg["hidden"], intermediate_size=cfg["inter"],
+                           max_position_embeddings=max(4096, T + 256), k_bits=bits, v_bits=bits, group_size=group,
+                           residual_length=64)
+    cc = dict(compress_method="gearslKIVI", group_size=group, residual=64, quantize_bit=bits, rank=rnk, rankv=rnk, loop=loop,
+              left=s)
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.float16)
     try:
+        torch.manual_seed(0)                       # every rank holds the same (replicated) weights
         with torch.device(dev):
             model = LlamaForCausalLM_GEARKIVI(mcfg, cc).eval()
     finally:
         torch.set_default_dtype(old)
     prompt = T - new_tokens
+    torch.manual_seed(1)
     ids = torch.randint(0, mcfg.vocab_size, (1, prompt), device=dev)
-    res = {"context": T, "batch": 1, "weights": "random init, Llama-2-7B shapes",
-           "method": "gearlKIVI %d-bit rank %d, residual 64 (CSG fused path)" % (bits, rank)}
-    # (1) the build's fast path: pre-allocated GearKVCache + fused attention, ~10 launches per layer
+    res = {"context": T, "batch": 1, "weights": f"random init, {cfg['model']} shapes",
+           "method": "gearslKIVI %d-bit, rank %d per block, %.0f%% outliers (V rows: reference count%s; K prompt rows: reference "
+                     "count, K 64-token blocks: nominal count), residual 64" % (bits, rnk, s * 100, " / world per shard" if world > 1 else ""),
+           "parallelism": f"head-shard x{world}" + (", all_gather_into_tensor of the attention output per layer" if world > 1 else "")}
     from gear_amd.fast_decode import FastGearDecoder
-    torch.manual_seed(0)
-    fast = FastGearDecoder(model, T + 2 * new_tokens + 8)
+    fast = FastGearDecoder(model, T + 2 * new_tokens + 8, tp_rank=rank, tp_world=world)
     nxt = fast.prefill(ids).argmax(-1, keepdim=True)
     for _ in range(2):
         nxt = fast.step(nxt).argmax(-1, keepdim=True)
@@ -115,45 +144,50 @@ def decode_tokens_per_s(cfg, dev, new_tokens=64):
         nxt = fast.step(nxt).argmax(-1, keepdim=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res.update({"eager_fast_path_tokens_per_s": (new_tokens - 2) / dt})
-    # (1b) the same token step captured once as a HIP graph (device-side pos / slot / T / W) and replayed
-    n_graph = new_tokens - 2
-    fast.tok.copy_(nxt)
-    fast.step_graph()                                    # capture + first replay
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_graph):
-        fast.step_graph()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    graph_tps = n_graph / dt
-    eager_tps = res["eager_fast_path_tokens_per_s"]
-    # headline = the faster of the two launch modes of the same token step (eager launches pipeline ahead of the GPU once the
-    # step is down to ~200 kernels; graph replay wins when the host is slow)
-    best = max(graph_tps, eager_tps)
-    res.update({"tokens_per_s": best, "ms_per_token": 1e3 / best, "graph_replay_tokens_per_s": graph_tps,
-                "path": "FastGearDecoder (GearKVCache + fused GEMVs + gear_attn_decode): "
-                        + ("step_graph, one hipGraph per token step" if graph_tps >= eager_tps else "step, eager launches"),
+    c0 = fast.layers[0]["cache"]
+    res.update({"eager_tokens_per_s": (new_tokens - 2) / dt, "outliers_per_side": {"v_row": c0.kv, "k_prompt_row": c0.kk0,
+                                                                                 "k_block_row": c0.kk_blk}})
+    best = res["eager_tokens_per_s"]
+    if world == 1:
+        # the same token step captured once as a HIP graph (device-side pos / slot / T / W) and replayed
+        n_graph = new_tokens - 2
+        fast.tok.copy_(nxt)
+        fast.step_graph()                                    # capture + first replay
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_graph):
+            fast.step_graph()
+        torch.cuda.synchronize()
+        res["graph_replay_tokens_per_s"] = n_graph / (time.perf_counter() - t0)
+        best = max(best, res["graph_replay_tokens_per_s"])
+    # headline = the faster launch mode of the same token step (both reported)
+    res.update({"tokens_per_s": best, "ms_per_token": 1e3 / best,
+                "path": "FastGearDecoder (GearKVCache with in-place block compress + fused GEMVs + gear_attn_decode_stream)",
                 "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20})
     del fast
     torch.cuda.empty_cache()
-    # (2) the reference-shaped attention hook (17-slot tuple cache, torch.cat appends, ~60 eager ops per layer)
-    torch.manual_seed(0)
-    with torch.no_grad():
-        logits, past = model(ids, None, True)
-        nxt = logits[:, -1].argmax(-1, keepdim=True)
-        for _ in range(2):
-            logits, past = model(nxt, past, True)
+    if world == 1 and cfg["layers"] * cfg["hidden"] <= 32 * 4096:
+        # the reference-shaped attention hook (17-slot tuple cache, torch.cat appends, ~60 eager ops per layer): what a
+        # reference user gets from the documented import swap alone (no outliers: the reference's fused path stores none)
+        cc2 = dict(cc, compress_method="gearlKIVI")
+        for layer in model.model.layers:
+            layer.self_attn.compress_config = cc2
+        with torch.no_grad():
+            logits, past = model(ids, None, True)
             nxt = logits[:, -1].argmax(-1, keepdim=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(new_tokens - 2):
-            logits, past = model(nxt, past, True)
-            nxt = logits[:, -1].argmax(-1, keepdim=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    res["hook_module_tokens_per_s"] = (new_tokens - 2) / dt
-    del model, past
+            for _ in range(2):
+                logits, past = model(nxt, past, True)
+                nxt = logits[:, -1].argmax(-1, keepdim=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(new_tokens - 2):
+                logits, past = model(nxt, past, True)
+                nxt = logits[:, -1].argmax(-1, keepdim=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        res["hook_module_tokens_per_s"] = (new_tokens - 2) / dt
+        del past
+    del model
     torch.cuda.empty_cache()
     return res
 
@@ -182,19 +216,22 @@ def main():
 
     from gear_amd import compress as C
     from gear_amd import _lib
-    _lib.load()
+    lib = _lib.load()
 
-    cfg = CONFIGS[args.config]
-    model, layers, H, D, T, bits, group, rnk, loop, sparsity = cfg
+    cfg = dict(CONFIGS[args.config])
     if args.layers:
-        layers = args.layers
+        cfg["layers"] = args.layers
+    layers, H, T, bits, group, rnk, loop, sparsity = (cfg["layers"], cfg["kv_heads"], cfg["T"], cfg["bits"], cfg["group"],
+                                                      cfg["rank"], cfg["loop"], cfg["s"])
     shards = args.emulate_world if (args.emulate_world and world == 1) else world
     assert H % shards == 0, "KV heads must divide across ranks"
     Hl = H // shards
-    # k per side: reference formula on the FULL row (compress_function.py:300-303); per-shard V rows take k/N
+    # k per side: reference formula on the FULL row (compress_function.py:265-267 / :300-303); K rows live inside a head
+    # (count independent of the sharding), per-shard V rows take k / N
     k_full = C.outlier_count(1, H, T, D, sparsity)
-    k_key = k_full
-    k_val = max(1, k_full // shards)
+    k_key = min(k_full, T // 2)
+    k_val = max(1, k_full // shards) if k_full else 0
+    key_path = args.key_path
 
     torch.manual_seed(1234 + rank)
     K = torch.empty((layers, Hl, T, D), dtype=torch.float16, device=dev)
@@ -205,6 +242,12 @@ def main():
     P0k = torch.rand((layers, Hl, D, rnk), device=dev, dtype=torch.float32)
     P0v = torch.rand((layers, Hl, D, rnk), device=dev, dtype=torch.float32)
 
+    def comp_k(x, p0):
+        return C.compress_key(x, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=p0, path=key_path)
+
+    def comp_v(x, p0):
+        return C.compress_value(x, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=p0)
+
     ev = {}
 
     def stage(name):
@@ -214,10 +257,9 @@ def main():
 
     def step_serial():
         stage("t0")
-        # K^T re-layout (what the attention hook hands over, llamagear.py:268) + compress
-        pk = C.compress_key(K, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k)
+        pk = comp_k(K, P0k)
         stage("k_compress")
-        pv = C.compress_value(V, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v)
+        pv = comp_v(V, P0v)
         stage("v_compress")
         kr = C.decompress(pk, transposed_out=True)
         stage("k_decompress")
@@ -232,20 +274,18 @@ def main():
 
     def step_streams():
         # K and V (and groups of layers) are independent: their compress -> decompress chains run on separate HIP streams,
-        # so the VALU-bound row compressor of one chain overlaps the HBM-bound low-rank / decompress kernels of another
+        # so the instruction-bound kernels of one chain overlap the HBM-bound kernels of the other
         cur = torch.cuda.current_stream()
         outs = []
         for i, (l0, l1) in enumerate(lb):
             sk, sv = pool[2 * i], pool[2 * i + 1]
             sk.wait_stream(cur)
             sv.wait_stream(cur)
-            # (the V chain is enqueued first: it starts with the VALU-bound row compressor, which then overlaps the K chain's
-            # HBM-bound re-layout; measured 1250 vs 1205 GB/s the other way round)
             with torch.cuda.stream(sv):
-                pv = C.compress_value(V[l0:l1], bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=P0v[l0:l1])
+                pv = comp_v(V[l0:l1], P0v[l0:l1])
                 vr = C.decompress(pv)
             with torch.cuda.stream(sk):
-                pk = C.compress_key(K[l0:l1], bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=P0k[l0:l1])
+                pk = comp_k(K[l0:l1], P0k[l0:l1])
                 kr = C.decompress(pk, transposed_out=True)
             outs.append((pk, pv, kr, vr))
         for st in pool:
@@ -263,22 +303,10 @@ def main():
     for _ in range(max(1, args.warmup)):
         out = step()
     sync()
-    run_step, graphed = step, False
-    if args.graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = step()
-            graph.replay()                      # one untimed replay
-            run_step, graphed = graph.replay, True
-        except Exception as e:                  # capture is an optimisation of the host side only: fall back to eager
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-    sync()
     ev.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step()
+        out = step()
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -287,20 +315,21 @@ def main():
         dt = float(t.item())
 
     del out
-    n_elem_rank = K.numel()                       # per tensor kind, this rank
-    fp16_bytes_job = 2 * n_elem_rank * 2 * world  # K + V, whole job
+    n = K.numel()                                 # elements per tensor kind, this rank
+    BH = layers * Hl
+    fp16_bytes_job = 2 * n * 2 * world            # K + V, whole job
     value = 2 * fp16_bytes_job * args.steps / dt / 1e9   # through compress + through decompress
 
     # ---- per-stage GPU time (HIP events on the launch stream): a dedicated serial pass, outside the timed region
-    step_serial()                                # (untimed: first main-stream allocations of the 2.7 GB of outputs)
+    step_serial()                                # (untimed: first main-stream allocations of the outputs)
     torch.cuda.synchronize()
     ev.clear()
     pk = pv = kr = vr = out = None
     for _ in range(3):
-        pk = pv = kr = vr = out = None           # (drop the previous outputs first: the allocator then reuses their blocks
-        pk, pv, kr, vr = out = step_serial()     #  instead of a 60 ms first-touch allocation of a second 2.7 GB set)
+        pk = pv = kr = vr = out = None           # (drop the previous outputs first: the allocator then reuses their blocks)
+        pk, pv, kr, vr = out = step_serial()
     torch.cuda.synchronize()
-    names = ["k_compress", "v_compress", "k_decompress", "v_decompress"]   # k_compress includes the K^T re-layout
+    names = ["k_compress", "v_compress", "k_decompress", "v_decompress"]
     prev = "t0"
     stages = {}
     for nme in names:
@@ -308,56 +337,85 @@ def main():
         stages[nme] = sum(ms) / len(ms)
         prev = nme
 
-    # ---- roofline of the dominant kernel: the V row compressor (outlier select + fill + quant + pack + error)
-    # is timed as its own event interval in a dedicated loop (the compress stages above also contain the low-rank
-    # launches).  Algorithmic bytes per launch (DESIGN.md "compress_rows"): read 2n; write codes n*b/8 +
-    # scale/mn 8n/g (fp32) + error 2n + outliers rows*2k*4.
-    # Launches are the ones the step issues: one per chunk of layers (gear_amd/compress.py cache blocking), V geometry
-    # and K^T geometry alternating -- both are the same kernel symbol, so this is also what the rocprofv3 kernel
-    # summary averages over.
-    from gear_amd.compress import compress_rows_once, _batches_per_chunk
-    nb = _batches_per_chunk(layers, Hl * T * D * 2)
-    n = nb * Hl * T * D                               # elements per launch
-    geom_v = (nb * T, T, Hl * T * D, D, Hl, D, T * D)
-    geom_k = (nb * Hl * D, D, D * T, T, 1, T, 0)
-    errb = torch.empty((nb, Hl, T, D), dtype=torch.float16, device=dev)
-    ktb = C.transpose_last2(K[:nb])
-    chunks = [(b0, b0 + nb) for b0 in range(0, layers - nb + 1, nb)]
+    # ---- algorithmic bytes (one K or V tensor of n elements on this rank): read 2n, write the payload
+    def payload_bytes(kind):
+        rows = BH * D if kind == "k" else layers * T
+        kk = k_key if kind == "k" else k_val
+        return (n * bits / 8 + 8 * n / group                 # codes, scale + mn (float32 each in the simulated arithmetic)
+                + 2 * rnk * (T + D) * BH                     # P, Q fp16
+                + rows * 2 * kk * 4)                         # outliers: uint16 index + fp16 value
 
-    def rows_pass():
-        for b0, b1 in chunks:
-            compress_rows_once(V[b0:b1], geom_v, group, bits, 1, k_val, True, err=errb)
-            compress_rows_once(ktb, geom_k, group, bits, 1, k_key, True, err=errb.view(nb, Hl, D, T))
-    for _ in range(2):
-        rows_pass()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-    e0.record()
-    for _ in range(reps):
-        rows_pass()
-    e1.record()
-    torch.cuda.synchronize()
-    rows_ms = e0.elapsed_time(e1) / (reps * 2 * len(chunks))
-    k_avg = 0.5 * (nb * T * 2 * k_val + nb * Hl * D * 2 * k_key)   # outlier entries per launch (V rows / K^T rows)
-    alg_bytes = 2 * n + n * bits / 8 + 8 * n / group + 2 * n + k_avg * 4
-    achieved = alg_bytes / (rows_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC passes committed in profiles/r1_pmc_traffic_rows_fp32.md (FETCH_SIZE x2 per the
-    # gfx950 correction + WRITE_SIZE); measured for exactly these launches (C3, 1 GPU, all layers), null otherwise
-    traffic = TRAFFIC_C3 if (args.config == "c3" and world == 1 and not args.layers and nb == layers) else None
-    roofline = {"bound": "hbm", "kernel": f"compress_rows_fp32_kernel<{bits}, float> (V-layout and K^T-layout launches, {nb} layers each)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "alg_bytes_per_launch": alg_bytes, "ms_per_launch": rows_ms}
+    alg = {"k_compress": 2 * n + payload_bytes("k"), "v_compress": 2 * n + payload_bytes("v"),
+           "k_decompress": payload_bytes("k") + 2 * n, "v_decompress": payload_bytes("v") + 2 * n}
+    chain = {nme: {"alg_bytes": alg[nme], "ms": stages[nme], "achieved": alg[nme] / (stages[nme] * 1e-3) / 1e9,
+                   "frac": alg[nme] / (stages[nme] * 1e-3) / 1e9 / HBM_PEAK_GBS} for nme in names}
+
+    # ---- the large kernels one by one (HIP events around back-to-back launches of ONE kernel on the launch stream)
+    def timed(fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    kernels = []
+    # (1) the V row compressor: outlier select + fill + quantize + pack + error, one launch over all layers
+    geom_v = (layers * T, T, Hl * T * D, D, Hl, D, T * D)
+    errb = torch.empty((layers, Hl, T, D), dtype=torch.float16, device=dev)
+    rows_out = C._alloc_rows(tuple(V.shape), layers * T, group, bits, 1, k_val, dev)
+    ms_rows = timed(lambda: C._compress_rows(V, geom_v, group, bits, 1, k_val, rows_out, errb))
+    b_rows = 2 * n + n * bits / 8 + 8 * n / group + layers * T * 2 * k_val * 4
+    kernels.append({"kernel": f"compress_rows_fp32_kernel<{bits}, float> (V rows: select + fill + quantize + pack + error)",
+                    "ms": ms_rows, "alg_bytes": b_rows, "not_counted": "the fp16 error it also writes (2n bytes): an intermediate"})
+    del errb, rows_out
+    # (2) the fused K path, kernel by kernel (variant hooks of gear_compress_key_fused)
+    if C.key_fused_supported(T, D, group, bits, k_key):
+        ms_full = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k))
+        ms_sel = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=32)) if k_key else 0.0
+        ms_main = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=8 | 16))
+        b_sel = 2 * n + BH * D * 2 * k_key * 4 + n / 8
+        b_main = 2 * n + n / 8 * (1 if k_key else 0) + n * bits / 8 + 8 * n / group
+        kernels.append({"kernel": "k_select_kernel + k_select_fix_kernel (K: per-channel outlier selection over T, token-major input)",
+                        "ms": ms_sel, "alg_bytes": b_sel})
+        kernels.append({"kernel": f"k_main_kernel<{bits}, 1, {group}, float, ...> (K: fused quantize + pack + error + Gram on the matrix cores)",
+                        "ms": ms_main, "alg_bytes": b_main,
+                        "not_counted": "the fp16 error written once for the Q pass (2n bytes) and the partial Gram matrices"})
+        kernels.append({"kernel": "fused K chain (select, main, per-head solve, Q pass)", "ms": ms_full, "alg_bytes": alg["k_compress"]})
+    for kx in kernels:
+        kx["achieved"] = kx["alg_bytes"] / (kx["ms"] * 1e-3) / 1e9 if kx["ms"] else None
+        kx["frac"] = kx["achieved"] / HBM_PEAK_GBS if kx["ms"] else None
+    dom = max(kernels[:3], key=lambda kx: kx["ms"])
+    # HBM bytes from PMC counters: only from a profile taken on exactly this library (profiles/r2_traffic.json)
+    traffic, tnote = None, "no profile for this library build"
+    tp = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    if os.path.exists(tp) and world == 1 and not args.layers and not args.emulate_world:
+        prof = json.load(open(tp))
+        if prof.get("lib_sha256") == lib_sha256() and prof.get("config") == args.config:
+            for kname, tb in prof.get("kernels", {}).items():
+                if dom["kernel"].startswith(kname):
+                    traffic, tnote = tb, f"profiles/r2_traffic.json ({prof.get('how', '')})"
+        else:
+            tnote = "profiles/r2_traffic.json was measured on a different library build / config"
+    roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac"], "traffic": traffic, "traffic_source": tnote, "alg_bytes_per_launch": dom["alg_bytes"],
+                "ms_per_launch": dom["ms"],
+                "bytes_definition": "SURVEY.md 8(d): read 2n + codes n*b/8 + scale/mn 8n/g + outliers; no error term",
+                "spread": "the same binary measures within +-4 % from box to box (round-1 observation, DESIGN.md section 6)"}
 
     # ---- decompress-into-attention: one decode token's attention over the compressed cache of ALL layers
     from gear_amd.attention import decode_attention
     from gear_amd import parallel
-    qv = torch.randn((layers, Hl, 1, D), device=dev, dtype=torch.float16)
+    n_rep = cfg["q_heads"] // cfg["kv_heads"]
+    qv = torch.randn((layers, Hl * n_rep, 1, D), device=dev, dtype=torch.float16)
 
     def attn_step():
         o = decode_attention(qv, pk, pv)
-        if dist is not None:       # head shards -> full [layers, 1, H*D] on every rank (latency-bound, a few KiB / layer)
-            o = parallel.all_gather_heads(o.transpose(1, 2).reshape(layers, 1, Hl * D), world)
+        if dist is not None:       # head shards -> full [layers, 1, Hq*D] on every rank (latency-bound, a few KiB / layer)
+            o = parallel.all_gather_heads(o.transpose(1, 2).reshape(layers, 1, Hl * n_rep * D), world)
         return o
 
     for _ in range(3):
@@ -376,33 +434,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         attn_ms = float(t.item())
     payload_bytes_job = (pk.nbytes() + pv.nbytes()) * world
+    payload_ratio = (2 * n * 2) / (pk.nbytes() + pv.nbytes())
 
+    res = None
     if rank == 0:
         res = {
             "metric": "KV compress+decompress GB/s (fp16 KV bytes through compress + through decompress per second)",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 arithmetic on fp16 data, int%d payload" % bits, "data": "synthetic",
-            "config": {"workload": f"{model} KV cache, {layers} layers x {H} KV heads x T={T} x D={D}, "
+            "config": {"workload": f"{cfg['model']} KV cache, {layers} layers x {H} KV heads x T={T} x D={D}, "
                                    f"{bits}-bit g={group} per-channel K / per-token V + rank-{rnk} (loop {loop}) + "
-                                   f"{sparsity * 100:.0f}% outliers (BASELINE configs[{2 if args.config == 'c3' else 1}])",
+                                   f"{sparsity * 100:.0f}% outliers (BASELINE configs[{cfg['idx']}])",
                        "parallelism": f"head-shard x{world}", "k_outliers_per_side": [k_key, k_val],
-                       "streams": args.streams, "hipgraph": graphed},
+                       "streams": args.streams, "key_path": key_path if key_path != "auto" else
+                       ("fused" if C.key_fused_supported(T, D, group, bits, k_key) and C._KEY_PATH_DEFAULT == "auto" else C._KEY_PATH_DEFAULT)},
             "compress_GBps": fp16_bytes_job / ((stages["k_compress"] + stages["v_compress"]) * 1e-3) / 1e9,
             "decompress_GBps": fp16_bytes_job / ((stages["k_decompress"] + stages["v_decompress"]) * 1e-3) / 1e9,
             "stage_ms": stages,
-            "payload_ratio": (2 * n_elem_rank * 2) / (pk.nbytes() + pv.nbytes()),
+            "payload_ratio": payload_ratio,
             "attn_decode": {"ms_per_token_all_layers": attn_ms, "compressed_GBps": payload_bytes_job / (attn_ms * 1e-3) / 1e9,
                             "fp16_equiv_GBps": fp16_bytes_job / (attn_ms * 1e-3) / 1e9,
                             "collective": "all_gather of per-rank attention output" if world > 1 else None},
             "roofline": roofline,
+            "roofline_chain": chain,
+            "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
-        if world == 1 and not args.no_decode and not args.layers:
-            del K, V, kr, vr, pk, pv, out
-            torch.cuda.empty_cache()
-            res["decode"] = decode_tokens_per_s(cfg, dev)
+    del K, V, kr, vr, pk, pv, out, qv
+    torch.cuda.empty_cache()
+    if not args.no_decode and not args.layers and not args.emulate_world:
+        dec = decode_tokens_per_s(cfg, dev, world, rank, args.decode_tokens)     # (every rank takes part when sharded)
+        if dist is not None:
+            t = torch.tensor([1.0 / dec["tokens_per_s"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)                           # slowest rank
+            dec["tokens_per_s"] = 1.0 / float(t.item())
+            dec["ms_per_token"] = 1e3 * float(t.item())
+        if rank == 0:
+            res["decode"] = dec
+    if rank == 0:
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -30,6 +30,7 @@ SIGNATURES = {
     "gear_compress_value_fused": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _i64,
                                        _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gear_attn_decode_stream": (_i, [_vp] * 17 + [_i] * 23 + [_vp, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "gear_quant_rows_whole": (_i, [_vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "gear_quant_pack_lastdim": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_quant_pack_k": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_unpack_dequant_lastdim": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),

@@ -326,6 +326,28 @@ def compress_key(k: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: i
     return _compress_key_impl(k, False, bits, group, k_out, rank, loop, mode, P0)
 
 
+def quant_whole_rows(x: torch.Tensor, layout: str, bits: int, mode="fp32", oidx: Optional[torch.Tensor] = None, k_out: int = 0,
+                     want_err: bool = False):
+    """Quantize -> dequantize with ONE group per row (the KCVT variants, csrc/rows_whole.hip).  x fp16 [B,H,T,D].
+    layout "k": a row = one channel over all T tokens (group = seq_len); "v": a row = one token across all heads (group =
+    H*D).  oidx: the rows' outlier lists as compress_key / compress_value return them (they keep their original value).
+    Returns y fp16 [B,H,T,D] (and the error x - y when want_err)."""
+    assert x.dim() == 4 and x.dtype == torch.float16 and layout in ("k", "v")
+    x = x.contiguous()
+    L.require_gpu(x, oidx)
+    B, H, T, D = x.shape
+    y = torch.empty_like(x)
+    err = torch.empty_like(x) if want_err else None
+    if layout == "k":     # row (bh, d): elements x[bh, t, d], t = 0..T-1 -> T segments of one element, D apart
+        geom = (B * H * D, D, T * D, 1, T, 1, D)
+    else:                 # row (b, t): H segments of D contiguous elements, T*D apart
+        geom = (B * T, T, H * T * D, D, H, D, T * D)
+    rc = L.load().gear_quant_rows_whole(L.ptr(x), *geom, bits, _MODES[mode], L.ptr(oidx), k_out if oidx is not None else 0,
+                                        L.ptr(y), L.ptr(err), L.stream_ptr(x))
+    L.check(rc, "gear_quant_rows_whole")
+    return (y, err) if want_err else y
+
+
 def decompress(p: Payload, transposed_out: bool = False) -> torch.Tensor:
     """Payload -> fp16 [B,H,T,D] (or K^T [B,H,D,T] when transposed_out and kind == 'k')."""
     B, H, T, D = p.shape

@@ -1007,7 +1007,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     float* gpart = rank > 0 ? (float*)(base + ws.gpart) : nullptr;
     float* Wws = rank > 0 ? (float*)(base + ws.W) : nullptr;
 
-    if (k > 0) {
+    if (k > 0 && !(variant & 8)) {
         SelArgs sa;
         sa.x = (const uint16_t*)x; sa.BH = BH; sa.T = T; sa.k = k;
         // candidates per side and row: k + 5 sqrt(k) + 8 expected.  Measured on the 7B / 4k tensor (k = 40): a target of 56 / 64 /
@@ -1031,6 +1031,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         const unsigned fix_grid = (unsigned)(BH * 64 < 1024 ? BH * 64 : 1024);   // waves loop over the to-do list
         hipLaunchKernelGGL(k_select_fix_kernel, dim3(fix_grid), dim3(256), 0, st, sa);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(select fix)");
+        if (variant & 32) return 0;
     }
     MainArgs ma;
     ma.x = (const uint16_t*)x; ma.obits = obits; ma.omean = omean; ma.T = T;
@@ -1049,6 +1050,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     }
 #undef KF_DISPATCH
     GEAR_CHECK_LAUNCH("gear_compress_key_fused(main)");
+    if (variant & 16) return 0;
     if (rank > 0) {
         const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
         const int of16 = 1;

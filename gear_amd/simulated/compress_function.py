@@ -6,8 +6,12 @@ same function names run the REAL thing on the GPU: compress to the packed payloa
 (BASELINE.json north_star): within 1e-3 relative of the reference's simulated output on identical K/V; bit-exact
 where the result is a pure quantize/dequantize (KIVI_V2).
 
-Not reproduced: token_preserving windows (start_saving / locality_saving, :433-438) and group sizes that span heads
-(the KCVT variants, :441-452, :496-525, :555-582) -- both raise NotImplementedError.
+All of the dispatcher's methods are built: KIVI_V2, KCVT, GEAR, GEAR-KCVT, GEARL, GEARL-KCVT (the -KCVT variants quantize
+with ONE group per channel row over the whole sequence / per token row over all heads: gear_quant_rows_whole) and the
+token_preserving window of the KCVT / KIVI_V2 branches (:433-464).  Restrictions (the reference has none of them, it is torch
+eager): head_dim-local group sizes must divide head_dim, sequence lengths must be a multiple of the group size (of 16 where
+outliers are selected), tensors are fp16-representable.  The GEAR paths return fp16 (the reference returns the unrounded
+fp32 sum and its caller applies .half(), compress_function.py:481, :494).
 """
 from __future__ import annotations
 
@@ -18,8 +22,16 @@ from .. import compress as C
 
 def _need_head_local(group_size, D, what):
     if group_size > D or D % group_size:
-        raise NotImplementedError(f"{what}: group_size {group_size} must divide head_dim {D} "
-                                  "(groups spanning heads -- the KCVT variants -- are not built)")
+        raise NotImplementedError(f"{what}: group_size {group_size} must divide head_dim {D} or be the whole token row "
+                                  "(num_head * head_dim, the KCVT variants)")
+
+
+def _sel_group(T):
+    """A group size the outlier selection kernels accept for rows of length T (the quantization itself is whole-row)."""
+    for g in (64, 32, 16):
+        if T % g == 0:
+            return g
+    raise NotImplementedError(f"outlier selection needs a sequence length that is a multiple of 16 (got {T})")
 
 
 def _half(x):
@@ -37,6 +49,8 @@ def fake_groupwise_token_asymmetric_quantization(input: torch.Tensor, quantize_b
     B, H, T, D = input.shape
     if (H * D) % group_size:
         raise ValueError("group_size should be a factor of the last dimension size")   # :16-17
+    if group_size == H * D and H > 1:     # KCVT: one group per token row across all heads
+        return C.quant_whole_rows(_half(input), "v", quantize_bit, "fp32").type(input.dtype)
     _need_head_local(group_size, D, "token quantization")
     p = C.compress_value(_half(input), quantize_bit, group_size, mode="fp32")
     return C.decompress(p).type(input.dtype)
@@ -47,6 +61,8 @@ def fake_groupwise_channel_asymmetric_quantization_new(input: torch.Tensor, quan
     B, H, T, D = input.shape
     assert T % group_size == 0
     mode = "fp16" if input.dtype == torch.float16 else "fp32"
+    if group_size == T and group_size not in (32, 64):     # KCVT: one group per channel over the whole sequence
+        return C.quant_whole_rows(_half(input), "k", quantize_bit, mode).type(input.dtype)
     p = C.compress_key(_half(input), quantize_bit, group_size, mode=mode)
     return C.decompress(p).type(input.dtype)
 
@@ -66,15 +82,45 @@ def gears_channelQ(input, quantize_bit, group_size=128, sparsity=0.0):
     """compress_function.py:261-296: K outliers per channel row + fp32 channel quantization -> fp16."""
     B, H, T, D = input.shape
     k = C.outlier_count(B, H, T, D, sparsity)
+    if group_size == T and group_size not in (32, 64):
+        return _gears_whole(input, "k", quantize_bit, k)[0]
     p = C.compress_key(_half(input), quantize_bit, group_size, k_out=k, mode="fp32")
     return C.decompress(p)
+
+
+def _gears_whole(input, layout, bits, k, want_err=False):
+    """gears_channelQ / gears_tokenQ with the group spanning the whole row: the sparse lists come from the regular selection
+    kernels (their quantized backbone is not used), the whole-row quantizer keeps those positions at their original value."""
+    x = _half(input)
+    B, H, T, D = x.shape
+    oidx = None
+    if k > 0:
+        sel = C.compress_key(x, bits, _sel_group(T), k_out=k, mode="fp32") if layout == "k" else \
+            C.compress_value(x, bits, 64 if D % 64 == 0 else 32, k_out=k, mode="fp32")
+        oidx = sel.oidx
+    res = C.quant_whole_rows(x, layout, bits, "fp32", oidx=oidx, k_out=k, want_err=want_err)
+    return res if want_err else (res, None)
+
+
+def _gear_whole(input, layout, bits, k, rank, loop, P0):
+    """gearslkivi_*Q_new with a whole-row group: output (outliers restored) + rank-r approximation of input - output."""
+    y, err = _gears_whole(input, layout, bits, k, want_err=True)
+    if rank <= 0:
+        return y
+    B, H, T, D = y.shape
+    if P0 is None:
+        P0 = C.draw_p0(B, H, T, D, rank, y.device)
+    P, Q = C.lowrank(err, rank, loop, P0, out_dtype=torch.float32)
+    return (y.float() + torch.matmul(Q, P.transpose(2, 3))).half()
 
 
 def gears_tokenQ(input, quantize_bit, group_size=128, sparsity=0.0):
     """compress_function.py:297-333: V outliers per token row (across heads) + fp32 token quantization -> fp16."""
     B, H, T, D = input.shape
-    _need_head_local(group_size, D, "token quantization")
     k = C.outlier_count(B, H, T, D, sparsity)
+    if group_size == H * D and H > 1:
+        return _gears_whole(input, "v", quantize_bit, k)[0]
+    _need_head_local(group_size, D, "token quantization")
     p = C.compress_value(_half(input), quantize_bit, group_size, k_out=k, mode="fp32")
     return C.decompress(p)
 
@@ -84,6 +130,8 @@ def gearslkivi_channelQ_new(input, quantize_bit, group_size=128, sparsity=0.0, r
     """compress_function.py:213-220 (GEAR, K): outliers + quant + low-rank of the residual."""
     B, H, T, D = input.shape
     k = C.outlier_count(B, H, T, D, sparsity)
+    if group_size == T and group_size not in (32, 64):
+        return _gear_whole(input, "k", quantize_bit, k, rank, loop, P0)
     p = C.compress_key(_half(input), quantize_bit, group_size, k_out=k, rank=rank, loop=loop, mode="fp32", P0=P0)
     return C.decompress(p)
 
@@ -91,8 +139,10 @@ def gearslkivi_channelQ_new(input, quantize_bit, group_size=128, sparsity=0.0, r
 def gearslkivi_tokenQ_new(input, quantize_bit, group_size=128, sparsity=0.0, rank=0, loop=1, P0=None):
     """compress_function.py:204-211 (GEAR, V)."""
     B, H, T, D = input.shape
-    _need_head_local(group_size, D, "token quantization")
     k = C.outlier_count(B, H, T, D, sparsity)
+    if group_size == H * D and H > 1:
+        return _gear_whole(input, "v", quantize_bit, k, rank, loop, P0)
+    _need_head_local(group_size, D, "token quantization")
     p = C.compress_value(_half(input), quantize_bit, group_size, k_out=k, rank=rank, loop=loop, mode="fp32", P0=P0)
     return C.decompress(p)
 
@@ -100,16 +150,46 @@ def gearslkivi_tokenQ_new(input, quantize_bit, group_size=128, sparsity=0.0, ran
 def tokenwise_gearlkivi_channelQ(input, quantize_bit, group_size=128, r=0, loop=1, P0=None):
     """compress_function.py:334-357 (GEARL, K): input-dtype channel quantization + low-rank."""
     mode = "fp16" if input.dtype == torch.float16 else "fp32"
+    B, H, T, D = input.shape
+    if group_size == T and group_size not in (32, 64):
+        return _gearl_whole(input, "k", quantize_bit, mode, r, loop, P0)
     p = C.compress_key(_half(input), quantize_bit, group_size, rank=r, loop=loop, mode=mode, P0=P0)
     return C.decompress(p).type(input.dtype)
+
+
+def _gearl_whole(input, layout, bits, mode, r, loop, P0):
+    """tokenwise_gearlkivi_*Q with a whole-row group: quantized tensor + rank-r approximation of the error, both in the input
+    dtype (fp16 in -> the sum is one fp16 add, as torch computes `output + error_lr` on fp16 tensors, :357)."""
+    y, err = C.quant_whole_rows(_half(input), layout, bits, mode, want_err=True)
+    if r <= 0:
+        return y.type(input.dtype)
+    B, H, T, D = y.shape
+    if P0 is None:
+        P0 = C.draw_p0(B, H, T, D, r, y.device)
+    P, Q = C.lowrank(err, r, loop, P0, out_dtype=torch.float32)
+    lr = torch.matmul(Q, P.transpose(2, 3))
+    if input.dtype == torch.float16:
+        return y + lr.half()
+    return (y.float() + lr).type(input.dtype)
 
 
 def tokenwise_gearlkivi_tokenQ(input, quantize_bit, group_size=128, r=0, loop=1, P0=None):
     """compress_function.py:399-418 (GEARL, V): fp32 token quantization + low-rank."""
     B, H, T, D = input.shape
+    if group_size == H * D and H > 1:
+        return _gearl_whole(input, "v", quantize_bit, "fp32", r, loop, P0)
     _need_head_local(group_size, D, "token quantization")
     p = C.compress_value(_half(input), quantize_bit, group_size, rank=r, loop=loop, mode="fp32", P0=P0)
     return C.decompress(p).type(input.dtype)
+
+
+def _kcvt_key(t, bits, seq_len_full):
+    """KCVT key branch (:441-446): the group size is the FULL sequence length; the reshape inside
+    fake_groupwise_channel_asymmetric_quantization_new only works when the (windowed) tensor is exactly that long."""
+    if t.shape[2] != seq_len_full:
+        raise ValueError(f"KCVT with a token_preserving window: the reference reshapes a {t.shape[2]}-token window into groups "
+                         f"of {seq_len_full} tokens and fails (compress_function.py:49-52)")
+    return C.quant_whole_rows(_half(t), "k", bits, "fp16" if t.dtype == torch.float16 else "fp32").type(t.dtype)
 
 
 def compress_insert_function(previous_key, previous_value, compress_config, layer_idx, pbase1=None, qbase1=None,
@@ -117,20 +197,40 @@ def compress_insert_function(previous_key, previous_value, compress_config, laye
     """compress_function.py:421-584.  previous_key / previous_value fp16 [B,H,T,D] -> (key, value) lossy fp16.
 
     compress_config: gear_amd.simulated.CompressionConfig after copy_for_all_attention() (per-layer lists), or any
-    object with the same attributes.  Methods: KIVI_V2, GEAR, GEARL (the others named in the reference's dispatcher
-    raise NotImplementedError; unknown names are a no-op exactly like the reference).
+    object with the same attributes.  Methods: KIVI_V2, KCVT, GEAR, GEAR-KCVT, GEARL, GEARL-KCVT; unknown names are a no-op
+    exactly like the reference.  token_preserving: the window applies to the KCVT / KIVI_V2 branches only, as in the reference.
     pbase1 / pbase2 (unused by the reference's body): optional initial bases [B,H,D,rank] for K / V, so that callers
     can make runs reproducible; by default they are drawn like the reference (CPU generator, K first)."""
     batch, num_head, seq_len, sep_dim = previous_key.shape
-    if compress_config.token_preserving[layer_idx] == True:  # noqa: E712
-        raise NotImplementedError("token_preserving windows are not built")
+    if compress_config.token_preserving[layer_idx] == True:  # noqa: E712      (:431-438)
+        starting_idx = int(compress_config.start_saving[layer_idx] * seq_len)
+        locality_idx = int(compress_config.locality_saving[layer_idx] * seq_len)
+    else:
+        starting_idx, locality_idx = 0, -seq_len
+    # the window the KCVT / KIVI_V2 branches quantize: previous[:, :, starting_idx:-locality_idx] with Python's slice semantics
+    # (locality_idx == 0 gives the EMPTY slice [s:-0], i.e. nothing is compressed -- reproduced as is)
+    w0, w1, _ = slice(starting_idx, -locality_idx).indices(seq_len)
     method = compress_config.compress_method[layer_idx]
     bits = compress_config.quantize_bit[layer_idx]
     group = compress_config.group_size[layer_idx]
-    if method == "KIVI_V2":
-        previous_key = fake_groupwise_channel_asymmetric_quantization_new(previous_key, bits, group)
-        previous_value = fake_groupwise_token_asymmetric_quantization(previous_value, bits, group)
-    elif method in ("GEAR", "GEARL"):
+
+    def windowed(t, fn):
+        if w1 <= w0:
+            return t
+        if w0 == 0 and w1 == seq_len:
+            return fn(t)
+        t = t.clone()
+        t[:, :, w0:w1] = fn(t[:, :, w0:w1].contiguous())
+        return t
+
+    if method == "KCVT":       # :441-452 (note: the group sizes are those of the FULL tensor, also for a window)
+        previous_key = windowed(previous_key, lambda t: _kcvt_key(t, bits, seq_len))
+        if previous_value is not None:
+            previous_value = windowed(previous_value, lambda t: fake_groupwise_token_asymmetric_quantization(t, bits, num_head * sep_dim))
+    elif method == "KIVI_V2":  # :454-464
+        previous_key = windowed(previous_key, lambda t: fake_groupwise_channel_asymmetric_quantization_new(t, bits, group))
+        previous_value = windowed(previous_value, lambda t: fake_groupwise_token_asymmetric_quantization(t, bits, group))
+    elif method in ("GEAR", "GEARL", "GEAR-KCVT", "GEARL-KCVT"):
         if prefill is True:
             rank_used = int(compress_config.prefill_rank[layer_idx])
             rankv_used = int(compress_config.prefill_rankv[layer_idx])
@@ -138,13 +238,12 @@ def compress_insert_function(previous_key, previous_value, compress_config, laye
             rank_used = int(compress_config.rank[layer_idx])
             rankv_used = int(compress_config.rankv[layer_idx])
         loop = compress_config.loop[layer_idx]
-        if method == "GEAR":
+        gk, gv = (seq_len, num_head * sep_dim) if method.endswith("-KCVT") else (group, group)   # :501, :515, :560, :573
+        if method.startswith("GEAR-") or method == "GEAR":
             left = compress_config.left[layer_idx]
-            previous_key = gearslkivi_channelQ_new(previous_key, bits, group, left, rank_used, loop, P0=pbase1)
-            previous_value = gearslkivi_tokenQ_new(previous_value, bits, group, left, rankv_used, loop, P0=pbase2)
+            previous_key = gearslkivi_channelQ_new(previous_key, bits, gk, left, rank_used, loop, P0=pbase1)
+            previous_value = gearslkivi_tokenQ_new(previous_value, bits, gv, left, rankv_used, loop, P0=pbase2)
         else:
-            previous_key = tokenwise_gearlkivi_channelQ(previous_key, bits, group, rank_used, loop, P0=pbase1)
-            previous_value = tokenwise_gearlkivi_tokenQ(previous_value, bits, group, rankv_used, loop, P0=pbase2)
-    elif method in ("KCVT", "GEAR-KCVT", "GEARL-KCVT"):
-        raise NotImplementedError(f"{method}: groups spanning the whole sequence / all heads are not built")
+            previous_key = tokenwise_gearlkivi_channelQ(previous_key, bits, gk, rank_used, loop, P0=pbase1)
+            previous_value = tokenwise_gearlkivi_tokenQ(previous_value, bits, gv, rankv_used, loop, P0=pbase2)
     return previous_key, previous_value

@@ -129,7 +129,9 @@ int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t ou
  *   rank  0: no low-rank part.  P0 float [BH, 128, rank]; P_out fp16, head bh at element offset
  *         (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * rank;  Q_out fp16 [BH, q_tcap, rank], rows q_toff ..
  *   variant: bit 0 = element-by-element tile arithmetic, bit 1 = always the exact slow selection, bit 2 = 16-bit LDS reads
- *         instead of the transposing ones for the matrix-core operands (cross-checks)
+ *         instead of the transposing ones for the matrix-core operands (cross-checks); measurement hooks (bench.py times
+ *         the kernels of the chain one by one with them): bit 3 = reuse the selection a previous identical call left in the
+ *         workspace, bit 4 = return after the fused quantize + Gram kernel, bit 5 = return after the selection
  *   workspace: gear_compress_key_fused_workspace(BH, T, k, rank) bytes of device scratch.
  * With t_off / ldc / lds / q_tcap / kcap the call appends a block to a pre-allocated streaming cache in place.
  */
@@ -150,6 +152,19 @@ int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group,
                               void* scale, void* mn, int tcap, int t_off, int rank, int loop, const void* P0, void* P_out,
                               int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, void* oidx,
                               void* oval, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a12 (KCVT variants): ONE quantization group per row -------------------------------------------------------------
+ * Replaces fake_groupwise_channel_asymmetric_quantization_new(key, bits, seq_len) and
+ * fake_groupwise_token_asymmetric_quantization(value, bits, num_head * sep_dim) of the KCVT / GEAR-KCVT / GEARL-KCVT branches
+ * (GenerationBench/.../Simulated/compress_function.py:441-452, :496-525, :555-582), optionally around the row's sparse outliers
+ * (gears_channelQ / gears_tokenQ with that group size).  Geometry as gear_compress_rows; len = nseg * seglen <= 16384, any
+ * length.  oidx: uint16 [n_rows, 2k] as gear_compress_rows writes it (k == 0: none, k <= 128).
+ *   y   fp16, same geometry: quantize -> dequantize, outliers keep their original value
+ *   err optional fp16 x - y (0 at the outliers)
+ */
+int gear_quant_rows_whole(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride, int nseg,
+                          int seglen, int64_t seg_stride, int bits, int mode, const void* oidx, int k, void* y, void* err,
+                          void* stream);
 
 /* ---- a4 / a10: low-rank power iteration ---------------------------------------------------------------------
  * Replaces headwise_lrap (cuda_supported_gear/quant/new_pack.py:291-311) and fake_poweriteration_group

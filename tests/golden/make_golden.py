@@ -14,6 +14,7 @@ Fixture map:
   f4_fakequant.npz    a9     token / channel fake quantizers (fp16 and fp32 arithmetic)
   f5_outlier.npz      a11    gears_channelQ / gears_tokenQ (+ an explicit tie case)
   f6_insert.npz       a12    compress_insert_function for KIVI_V2 / GEARL / GEAR
+  f9_kcvt.npz         a12    compress_insert_function for KCVT / GEAR-KCVT / GEARL-KCVT and the token_preserving window
   f7_gemv.npz         a6     inp @ dequant_weight_outer recipe of CSG/quant/gemv.py:93-126 (MHA + MQA)
 """
 import importlib.util
@@ -326,7 +327,40 @@ def f7():
     save("f7_gemv.npz", **d)
 
 
+# ------------------------------------------------------------------------------------------- F9
+def f9():
+    """The dispatcher's remaining methods: groups spanning the whole sequence (K) / all heads (V), and the token_preserving
+    window of the KIVI_V2 branch.  T = 192 (not a power of two) on purpose."""
+    d = {}
+    B, H, T, D = 1, 4, 192, 128
+    ks = [outlier_k(B * H * T * D, B, T, 0.02)]
+    k = torch.from_numpy(detie(npy(randn_half(18, (B, H, T, D))), ks, chan=True, tok=False))
+    v = torch.from_numpy(detie(npy(randn_half(19, (B, H, T, D))), ks, chan=False, tok=True))
+    d["k"], d["v"] = npy(k), npy(v)
+    cases = [("KCVT", 4, 0, 0.0), ("KCVT", 2, 0, 0.0), ("GEAR-KCVT", 2, 8, 0.02), ("GEAR-KCVT", 4, 4, 0.0),
+             ("GEARL-KCVT", 4, 4, 0.0), ("GEARL-KCVT", 2, 8, 0.0)]
+    for (m, b, r, left) in cases:
+        tag = f"{m}_b{b}_r{r}"
+        torch.manual_seed(900 + b + r)
+        with RandCapture() as rc:
+            ko, vo = cf.compress_insert_function(k.clone(), v.clone(), _cfg(m, b, 64, r, 3, left), 0, prefill=True)
+        d[tag + "_k"], d[tag + "_v"] = npy(ko), npy(vo)
+        if rc.drawn:
+            d[tag + "_P0k"], d[tag + "_P0v"] = npy(rc.drawn[0]), npy(rc.drawn[2])
+    # token_preserving: KIVI_V2 on the window [int(0.25 T) : -int(0.25 T)] (T = 256 -> tokens 64..191) and the empty window
+    k2, v2 = randn_half(20, (1, 2, 256, 128)), randn_half(21, (1, 2, 256, 128))
+    d["k_tp"], d["v_tp"] = npy(k2), npy(v2)
+    for name, ss, ls in (("tp_25_25", 0.25, 0.25), ("tp_50_0", 0.5, 0.0)):
+        c = _cfg("KIVI_V2", 4, 64, 0, 0, 0.0)
+        c.token_preserving, c.start_saving, c.locality_saving = [True], [ss], [ls]
+        ko, vo = cf.compress_insert_function(k2.clone(), v2.clone(), c, 0, prefill=True)
+        d[name + "_k"], d[name + "_v"] = npy(ko), npy(vo)
+    save("f9_kcvt.npz", **d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for fn in (f1, f2, f3, f4, f5, f6, f7):
-        fn()
+    only = sys.argv[1:]
+    for fn in (f1, f2, f3, f4, f5, f6, f7, f9):
+        if not only or fn.__name__ in only:
+            fn()

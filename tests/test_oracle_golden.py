@@ -164,6 +164,39 @@ def test_f6_compress_insert_function(golden, case):
         assert rel_fro(v, f[case + "_v"]) < 1e-3
 
 
+F9_CASES = ["KCVT_b4_r0", "KCVT_b2_r0", "GEAR-KCVT_b2_r8", "GEAR-KCVT_b4_r4", "GEARL-KCVT_b4_r4", "GEARL-KCVT_b2_r8"]
+
+
+@pytest.mark.parametrize("case", F9_CASES)
+def test_f9_kcvt_methods(golden, case):
+    """The dispatcher's whole-row variants (group = seq_len for K, num_head * head_dim for V), T = 192: the oracle vs the
+    reference-executed fixture.  KCVT is a pure quantize / dequantize: bit-exact."""
+    f = golden("f9_kcvt.npz")
+    method, b, r = case.split("_b")[0], int(case.split("_b")[1][0]), int(case.split("_r")[1])
+    left = 0.02 if case == "GEAR-KCVT_b2_r8" else 0.0
+    P0k = f[case + "_P0k"] if (case + "_P0k") in f.files else None
+    P0v = f[case + "_P0v"] if (case + "_P0v") in f.files else None
+    k, v = orc.compress_insert_function(f["k"], f["v"], method, b, 64, rank=r, rankv=r, loop=3, left=left, P0k=P0k, P0v=P0v)
+    if method == "KCVT":
+        assert np.array_equal(k.view(np.uint16), f[case + "_k"].view(np.uint16))
+        assert np.array_equal(v.view(np.uint16), f[case + "_v"].view(np.uint16))
+    else:
+        assert rel_fro(k, f[case + "_k"]) < 1e-3
+        assert rel_fro(v, f[case + "_v"]) < 1e-3
+
+
+@pytest.mark.parametrize("name,ss,ls", [("tp_25_25", 0.25, 0.25), ("tp_50_0", 0.5, 0.0)])
+def test_f9_token_preserving_window(golden, name, ss, ls):
+    """token_preserving (compress_function.py:431-464): only tokens [int(ss T), T - int(ls T)) are quantized; locality 0 makes
+    the slice [s:-0] empty, i.e. the call is a no-op -- the reference's behaviour, kept."""
+    f = golden("f9_kcvt.npz")
+    k, v = orc.compress_insert_function(f["k_tp"], f["v_tp"], "KIVI_V2", 4, 64, start_saving=ss, locality_saving=ls)
+    assert np.array_equal(k.view(np.uint16), f[name + "_k"].view(np.uint16))
+    assert np.array_equal(v.view(np.uint16), f[name + "_v"].view(np.uint16))
+    if ls == 0.0:
+        assert np.array_equal(k, f["k_tp"]) and np.array_equal(v, f["v_tp"])
+
+
 @pytest.mark.parametrize("name", ("mha", "mqa"))
 @pytest.mark.parametrize("b", BITS)
 def test_f7_gemv(golden, name, b):
