@@ -47,6 +47,8 @@ def _trace(attn, cfg, prefill_len, n_decode, seed):
     vcap = []
     h2 = attn.v_proj.register_forward_hook(lambda m, i, o: vcap.append(o))
     M.apply_rotary_pos_emb = spy
+    import gear_amd.modeling_llama_kivi as MK      # (imports the function by name: patch its reference too)
+    MK.apply_rotary_pos_emb = spy
     try:
         g = torch.Generator().manual_seed(seed)
         x = (torch.randn(1, prefill_len, cfg.hidden_size, generator=g) * 0.5).half().cuda()
@@ -61,6 +63,7 @@ def _trace(attn, cfg, prefill_len, n_decode, seed):
             caches.append(cache)
     finally:
         M.apply_rotary_pos_emb = orig
+        MK.apply_rotary_pos_emb = orig
         h1.remove()
         h2.remove()
     return caps, vcap, pre, mask, caches
@@ -174,3 +177,67 @@ def test_generate_runs_and_is_deterministic():
     out2 = model.generate(ids, max_length=180)
     assert out1.shape == (2, 180) and torch.equal(out1, out2)
     assert torch.equal(out1[:, :100], ids)
+
+
+# ------------------------------------------------------------------------------------------ f4: the KIVI state machine
+@pytest.mark.parametrize("bits,n_heads,n_kv,Tp", [(2, 2, 2, 200), (4, 4, 2, 130), (2, 2, 2, 40)])
+def test_kivi_decode_trace_vs_oracle(bits, n_heads, n_kv, Tp):
+    """LlamaAttention_KIVI (cuda_supported_gear/modeling_llama_kivi.py:81-289): K block compression every `residual` tokens,
+    V sliding window with per-token quantization of its oldest token -- the 9-slot cache and the attention output over a
+    130-step trace vs the numpy restatement oracle/kivi_oracle.py."""
+    from gear_amd.modeling_llama_kivi import LlamaAttention_KIVI
+    from gear_amd.modeling_llamagear import LlamaConfigLite
+    from oracle.kivi_oracle import KiviAttentionOracle
+    D, steps = 128, 130
+    cfg = LlamaConfigLite(hidden_size=n_heads * D, num_attention_heads=n_heads, num_key_value_heads=n_kv, num_hidden_layers=1,
+                          k_bits=bits, v_bits=bits, group_size=64, residual_length=64)
+    torch.manual_seed(5)
+    attn = LlamaAttention_KIVI(0, cfg, None).half().cuda()
+    caps, vcap, pre, mask, caches = _trace(attn, cfg, Tp, steps, seed=78)
+
+    def heads(t, n):
+        return np.ascontiguousarray(host(t).reshape(1, -1, n, D).transpose(0, 2, 1, 3))
+
+    o = KiviAttentionOracle(n_heads, n_kv, D, 64, bits, 64)
+    ref = o.prefill(host(caps[0][0]), host(caps[0][1]), heads(vcap[0], n_kv), host(mask))
+    assert rel_fro(heads(pre[0], n_heads), ref) < 3e-3
+    worst = 0.0
+    for i in range(steps):
+        ref = o.decode(host(caps[i + 1][0]), host(caps[i + 1][1]), heads(vcap[i + 1], n_kv))
+        worst = max(worst, rel_fro(heads(pre[i + 1], n_heads), ref))
+    assert worst < 5e-3, worst
+    # ---- the 9-slot tuple (:268) and the two different window disciplines
+    fpi = 32 // bits
+    T = Tp + steps
+    last = caches[-1]
+    assert len(last) == 9 and last[8] == T
+    nk = T - T % 64
+    assert last[0].shape[-1] == nk // fpi and (last[1] is None or last[1].shape[2] == T % 64)
+    assert last[5].shape[2] == 64 and last[4].shape[2] == T - 64          # V: the 64 most recent tokens stay fp16
+    assert tuple(last[6].shape) == (1, n_kv, T - 64, D // 64)
+    # packed payloads == the oracle's, bit for bit (same fp16-stepwise quantizer on the same tokens)
+    assert np.array_equal(host(last[0]), o.c["kc"]) and np.array_equal(host(last[4]), o.c["vc"])
+    assert np.array_equal(host(last[2]).view(np.uint16), o.c["ks"].view(np.uint16))
+    assert np.array_equal(host(last[6]).view(np.uint16), o.c["vs"].view(np.uint16))
+
+
+def test_kivi_and_mistral_shaped_models_generate():
+    from gear_amd.modeling_llama_kivi import LlamaForCausalLM_KIVI, MistralConfigLite, MistralForCausalLM_GEAR, MistralForCausalLM_KIVI
+    from gear_amd.modeling_llamagear import LlamaConfigLite
+    cfg = LlamaConfigLite(vocab_size=500, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                          num_key_value_heads=2, k_bits=2, v_bits=2)
+    torch.manual_seed(0)
+    m = LlamaForCausalLM_KIVI(cfg).half().cuda().eval()
+    ids = torch.randint(0, 500, (2, 70)).cuda()
+    a, b = m.generate(ids, 150), m.generate(ids, 150)
+    assert a.shape == (2, 150) and torch.equal(a, b) and torch.equal(a[:, :70], ids)
+    mc = MistralConfigLite(vocab_size=500, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                           num_key_value_heads=2, k_bits=2, v_bits=2, sliding_window=256)
+    cc = dict(compress_method="gearlKIVI", group_size=64, residual=64, quantize_bit=2, rank=2, rankv=2, loop=3)
+    torch.manual_seed(0)
+    for model in (MistralForCausalLM_GEAR(mc, cc), MistralForCausalLM_KIVI(mc)):
+        model = model.half().cuda().eval()
+        out = model.generate(ids, 200)
+        assert out.shape == (2, 200) and torch.equal(out[:, :70], ids)
+        with pytest.raises(NotImplementedError):
+            model.generate(ids, 300)

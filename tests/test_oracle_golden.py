@@ -164,6 +164,27 @@ def test_f6_compress_insert_function(golden, case):
         assert rel_fro(v, f[case + "_v"]) < 1e-3
 
 
+@pytest.mark.parametrize("case", ["gearl_b2_mha", "gearl_b4_gqa", "kivi_b2_mha"])
+def test_f8_attention_state_machine_trace(golden, case):
+    """Fixture F8: the committed 130-step decode trace of the attention cache state machine (oracle/attention_oracle.py,
+    restating modeling_llamagear.py:177-484).  The trace was produced by this oracle (the reference's forward is not importable),
+    so the test pins the ORACLE: an edit that changes what the restatement computes -- and with it what the GPU tests compare
+    the product against -- fails here.  Bit-exact (same numpy arithmetic)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_f8", os.path.join(os.path.dirname(__file__), "golden", "make_f8.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    f = golden("f8_trace.npz")
+    out, state = mk.run(case, load=f)
+    assert out.shape == f[case + "_out"].shape == (1, mk.CASES[case][2], 131, 128)
+    assert np.array_equal(out.view(np.uint16), f[case + "_out"].view(np.uint16))
+    assert np.array_equal(state, f[case + "_state"])
+    # 330 tokens: 320 compressed in 1 prefill segment + 2 decode blocks, 10 in the fp16 window
+    fpi = 32 // mk.CASES[case][1]
+    assert list(f[case + "_state"][:4]) == [330, 320 // fpi, 10, 320]
+
+
 F9_CASES = ["KCVT_b4_r0", "KCVT_b2_r0", "GEAR-KCVT_b2_r8", "GEAR-KCVT_b4_r4", "GEARL-KCVT_b4_r4", "GEARL-KCVT_b2_r8"]
 
 
