@@ -29,7 +29,9 @@ SIGNATURES = {
     "gear_compress_value_fused_workspace": (_sz, [_i64, _i, _i, _i]),
     "gear_compress_value_fused": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _i64,
                                        _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "gear_attn_decode_stream": (_i, [_vp] * 17 + [_i] * 23 + [_vp, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "gear_attn_decode_cache": (_i, [_vp, _vp, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "gear_cache_tiles_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "gear_outlier_chunk_index_ex": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
     "gear_quant_rows_whole": (_i, [_vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "gear_quant_pack_lastdim": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_quant_pack_k": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -97,6 +99,15 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().gear_last_error()
         raise GearError(f"{what}: status {rc}: {msg.decode() if msg else ''}")
+
+
+class CacheView(C.Structure):
+    """ctypes mirror of `gear_cache_view` (include/gear_hip.h): same field order, pointers then ints."""
+    _PTRS = ("kcode", "kscale", "kmn", "kP", "kQ", "koidx", "koval", "vcode", "vscale", "vmn", "vP", "vQ", "voidx", "voval",
+             "kwin", "vwin", "kochunk", "vochunk", "ktile", "kcnt", "vtile", "vcnt")
+    _INTS = ("B", "Hkv", "D", "tcap", "ldk", "lsk", "group", "bits", "mode", "rk", "rv", "kk_cap", "kk0", "kkb", "kv", "seg0",
+             "seglen", "wcap", "nbk_pitch", "ktile_cap", "nck", "vtile_cap", "nblk")
+    _fields_ = [(n, C.c_void_p) for n in _PTRS] + [(n, C.c_int) for n in _INTS]
 
 
 def stream_ptr(t=None) -> int:

@@ -8,7 +8,7 @@ tokens; when it fills, the block is compressed IN PLACE behind the already compr
 rank-r factors and -- when the config carries a sparsity (`left`, the simulated path's name,
 GenerationBench/.../Simulated/compress_config.py) -- the sparse outliers of the block, which is what the reference's
 streaming hook applies to every new block (Simulated/modeling_llama_new.py:979-1019 -> compress_function.py:261-333).
-Layout = what gear_attn_decode_stream streams: K channel-major with a fixed row pitch (a block append is 128 short row
+Layout = what gear_attn_decode_cache streams: K channel-major with a fixed row pitch (a block append is 128 short row
 segments, never a re-layout), V token-major, token-side factors per token, channel-side factors per segment (segment 0 =
 the prompt, then one per block), K outlier lists per (channel, side) that grow by `kk_blk` entries per block (later blocks
 hold later tokens, so the lists stay sorted), V outlier lists per token row.
@@ -29,6 +29,7 @@ applies; both are rank-r power-iteration approximations of the same error matrix
 """
 from __future__ import annotations
 
+import ctypes as C_
 import math
 
 import torch
@@ -72,15 +73,55 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=Non
     if lowrank:
         shapes.update(kPseg=((nseg, B, H, D, rk), torch.float16), kQtok=((B, H, T, rk), torch.float16),
                       vPseg=((nseg, B, H, D, rv), torch.float16), vQtok=((B, H, T, rv), torch.float16))
+    nbk = Tmax // 128 + 2                 # pitch of the K chunk index: bounds 0, 128, ... over the prompt segment
     if kk_blk > 0:
         shapes.update(koidx=((B, H, D, 2, kcap), torch.int16), koval=((B, H, D, 2, kcap), torch.float16))
+        if kk0_max <= 255:
+            shapes.update(kochunk=((B, H, D, 2, nbk), torch.uint8))
     if kv > 0:
         shapes.update(voidx=((B, T, 2 * kv), torch.int16), voval=((B, T, 2 * kv), torch.float16))
+        if kv <= 255:
+            shapes.update(vochunk=((B, T, 2, H + 1), torch.uint8))
+    # sparse tiles (gear_cache_tiles_build): the outlier corrections of a 128-token K chunk / 64-token V block as a flat list,
+    # sized for the expected count plus slack; a chunk that overflows falls back to the lists (count -1)
+    nck, nblk = Tmax // 128 + 1, 2 * (Tmax // 128 + 1)
+    ktile_cap = vtile_cap = 0
+    if kk_blk > 0:
+        per_chunk = D * 2 * max(2 * kk_blk, math.ceil(128 * kk0_max / max(Tmax, 1)))
+        ktile_cap = (int(per_chunk * 1.25) + 64 + 255) // 256 * 256
+        ktile_cap = max(ktile_cap, 512)
+        shapes.update(ktile=((B, H, nck, ktile_cap), torch.int32), kcnt=((B, H, nck), torch.int32))
+    if kv > 0:
+        per_blk = 64 * 2 * kv / H
+        vtile_cap = max(256, (int(per_blk * 1.25) + 32 + 255) // 256 * 256)
+        shapes.update(vtile=((B, H, nblk, vtile_cap), torch.int32), vcnt=((B, H, nblk), torch.int32))
     return shapes, dict(bits=bits, group=group, R=R, lowrank=lowrank, rk=rk, rv=rv, fpi=fpi, Tmax=Tmax, nseg=nseg,
-                        kv=kv, kk0_max=kk0_max, kk_blk=kk_blk, kcap=kcap)
+                        kv=kv, kk0_max=kk0_max, kk_blk=kk_blk, kcap=kcap, nbk=nbk, nck=nck, nblk=nblk, ktile_cap=ktile_cap,
+                        vtile_cap=vtile_cap)
 
 
-def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_off, loop, gen):
+def _view(bufs, d, NB, H, D, kk0, seg0, kwin=True):
+    """The gear_cache_view of a set of cache tensors (NB = leading batch dimension: layers * batch for pooled storage)."""
+    v = L.CacheView()
+    p = L.ptr
+    for f, n in (("kcode", "kcode"), ("kscale", "kscale"), ("kmn", "kmn"), ("kP", "kPseg"), ("kQ", "kQtok"), ("koidx", "koidx"),
+                 ("koval", "koval"), ("vcode", "vcode"), ("vscale", "vscale"), ("vmn", "vmn"), ("vP", "vPseg"), ("vQ", "vQtok"),
+                 ("voidx", "voidx"), ("voval", "voval"), ("vochunk", "vochunk"), ("ktile", "ktile"), ("kcnt", "kcnt"),
+                 ("vtile", "vtile"), ("vcnt", "vcnt")):
+        setattr(v, f, p(bufs.get(n)))
+    v.kochunk = p(bufs.get("kochunk")) if kk0 else None
+    if kwin:
+        v.kwin, v.vwin = p(bufs["kwin"]), p(bufs["vwin"])
+    v.B, v.Hkv, v.D, v.tcap = NB, H, D, d["Tmax"]
+    v.ldk, v.lsk, v.group, v.bits, v.mode = d["Tmax"] // d["fpi"], d["Tmax"] // d["group"], d["group"], d["bits"], 0
+    v.rk, v.rv = d["rk"], d["rv"]
+    v.kk_cap, v.kk0, v.kkb, v.kv = (d["kcap"] if d["kk_blk"] else 0), kk0, d["kk_blk"], d["kv"]
+    v.seg0, v.seglen, v.wcap = seg0, (d["R"] if (d["lowrank"] or d["kk_blk"]) else 0), d["R"]
+    v.nbk_pitch, v.ktile_cap, v.nck, v.vtile_cap, v.nblk = d["nbk"], d["ktile_cap"], d["nck"], d["vtile_cap"], d["nblk"]
+    return v
+
+
+def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_off, loop, gen, kk0=0, seg0=0):
     """Compress K / V [lead*B, H, T, 128] (lead = layers riding in the batch dimension of pooled storage) and write the
     payload behind token t_off of the cache tensors in `bufs` (same leading dimension), factors into segment `seg`, K outlier
     lists at position o_off.  fp16-stepwise arithmetic (the fused path's mode)."""
@@ -116,6 +157,21 @@ def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_of
         loop, p(P0v), p(vP), B * H, vP_stride, p(bufs.get("vQtok")), Tmax, t_off, p(bufs.get("voidx")), p(bufs.get("voval")),
         p(ws), ws.numel(), st)
     L.check(rc, "gear_compress_value_fused")
+    # chunk indices of the sparse lists (what lets a 128-token attention chunk find its outliers without a search):
+    # V: one row of H + 1 head bounds per new (token row, side); K: the prompt segment's entries, once, at prefill
+    if d["kv"] and "vochunk" in bufs:
+        rc = lib.gear_outlier_chunk_index_ex(p(bufs["voidx"]), NB, 2 * T, 2 * Tmax, 2 * t_off, d["kv"], d["kv"], 128, H + 1,
+                                             p(bufs["vochunk"]), H + 1, st)
+        L.check(rc, "gear_outlier_chunk_index_ex(V)")
+    if kk and seg == 0 and t_off == 0 and "kochunk" in bufs:
+        rc = lib.gear_outlier_chunk_index_ex(p(bufs["koidx"]), 1, NB * H * D * 2, 0, 0, kk, d["kcap"], 128, (T + 127) // 128 + 1,
+                                             p(bufs["kochunk"]), d["nbk"], st)
+        L.check(rc, "gear_outlier_chunk_index_ex(K)")
+    if "ktile" in bufs or "vtile" in bufs:      # sparse tiles of the chunks / blocks the new tokens lie in
+        view = _view(bufs, d, NB, H, D, kk0, seg0, kwin=False)
+        rc = lib.gear_cache_tiles_build(C_.byref(view), t_off + T, t_off // 128, (t_off + T + 127) // 128, t_off // 64,
+                                        (t_off + T) // 64, st)
+        L.check(rc, "gear_cache_tiles_build")
 
 
 class GearKVCachePool:
@@ -150,7 +206,7 @@ class GearKVCachePool:
         assert t0 + R <= d["Tmax"], "cache capacity exceeded"
         o_off = c0.kk0 + ((t0 - c0.seg0) // R) * d["kk_blk"]
         _compress_into(b, d, self.L, self.B, self.H, self.D, b["kwin"], b["vwin"], R, t0, seg, d["kk_blk"], o_off, self.loop,
-                       self.gen)
+                       self.gen, c0.kk0, c0.seg0)
         for c in self.caches:
             c.n_comp += R
             c.n_win = 0
@@ -172,7 +228,7 @@ class GearKVCache:
         self.kv, self.kk_blk, self.kcap = d["kv"], d["kk_blk"], d["kcap"]
         self.bufs = {}
         for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn", "kPseg", "kQtok", "vPseg", "vQtok", "kwin", "vwin",
-                     "koidx", "koval", "voidx", "voval"):
+                     "koidx", "koval", "voidx", "voval", "kochunk", "vochunk", "ktile", "kcnt", "vtile", "vcnt"):
             if name not in shapes:
                 t = None
             elif pool is not None:          # this layer's slice of the pooled storage (contiguous, same layout)
@@ -192,6 +248,9 @@ class GearKVCache:
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
         self._ws = None
+        self.use_tiles = True     # tests switch these off to compare the list paths
+        self.use_chunk_index = True
+        self._views = {}
         # optional device-side {pos, slot, T, W} shared by all layers (the _dyn methods read it: hipGraph replay)
         self.state = state
 
@@ -206,7 +265,7 @@ class GearKVCache:
     def _store(self, k_src, v_src, T, seg, kk, o_off):
         assert self.n_comp + T <= self.Tmax, "cache capacity exceeded"
         _compress_into(self.bufs, self.dims, 1, self.B, self.H, self.D, k_src, v_src, T, self.n_comp, seg, kk, o_off, self.loop,
-                       self.gen)
+                       self.gen, self.kk0, self.seg0)
         self.n_comp += T
 
     def prefill(self, k: torch.Tensor, v: torch.Tensor):
@@ -246,16 +305,18 @@ class GearKVCache:
         wsb = lib.gear_attn_decode_workspace(B, Hq, self.Tmax, self.bits)
         if self._ws is None or self._ws.numel() < wsb:
             self._ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
-        p = L.ptr
-        rc = lib.gear_attn_decode_stream(
-            p(q), p(self.kcode), p(self.kscale), p(self.kmn), p(self.kPseg), p(self.kQtok), p(self.koidx), p(self.koval),
-            p(self.vcode), p(self.vscale), p(self.vmn), p(self.vPseg), p(self.vQtok), p(self.voidx), p(self.voval),
-            p(self.kwin) if (W or dyn is not None) else None, p(self.vwin) if (W or dyn is not None) else None,
-            B, Hq, self.H, self.D, T, W, self.Tmax // self.fpi, self.Tmax // self.group, self.Tmax, self.Tmax, self.Tmax,
-            self.group, self.bits, 0, self.rk, self.rv, self.kcap if self.kk_blk else 0, self.kk0, self.kk_blk, self.kv,
-            self.seg0, self.R if (self.lowrank or self.kk_blk) else 0, self.R, p(dyn), 1.0 / math.sqrt(self.D), p(out), None,
-            p(self._ws), self._ws.numel(), L.stream_ptr(q))
-        L.check(rc, "gear_attn_decode_stream")
+        key = (self.kk0, self.seg0, bool(W or dyn is not None), self.use_tiles, self.use_chunk_index)
+        view = self._views.get(key)
+        if view is None:      # the view is a function of the prompt split only: built once per cache, not per token
+            view = _view(self.bufs, self.dims, B, self.H, self.D, self.kk0, self.seg0, kwin=key[2])
+            if not self.use_tiles:
+                view.ktile = view.vtile = None
+            if not self.use_chunk_index:
+                view.kochunk = view.vochunk = None
+            self._views[key] = view
+        rc = lib.gear_attn_decode_cache(C_.byref(view), L.ptr(q), Hq, T, W, L.ptr(dyn), 1.0 / math.sqrt(self.D), L.ptr(out), None,
+                                        L.ptr(self._ws), self._ws.numel(), L.stream_ptr(q))
+        L.check(rc, "gear_attn_decode_cache")
         return out
 
     def attend(self, q: torch.Tensor) -> torch.Tensor:

@@ -51,6 +51,12 @@ struct AttnArgs {
     // kk0 + kkb * (blocks appended so far) are valid -- kk0 from the prompt segment, kkb per `seglen` tokens after seg0.
     // Plain payloads: kk_stride == kk, kkb == 0.
     int kk_stride, kk0, kkb;
+    // chunk-major sparse tiles of a streaming cache (gear_cache_tiles_build): per (KV head, 128-token chunk) up to ktile_cap
+    // entries (channel | token-in-chunk << 7 | fp16(value - dequant) << 16), kcnt = their number (-1: too many, use the lists);
+    // per (KV head, 64-token block) up to vtile_cap entries (token-in-block | channel << 6 | fp16 delta << 16).  The attention
+    // chunk then adds its outlier corrections from entries whose position is known at launch: no search, no dependent loads.
+    const uint32_t* ktile; const int* kcnt; int ktile_cap, nck;
+    const uint32_t* vtile; const int* vcnt; int vtile_cap, nblk;
     int seg0, seglen;        // low-rank factor segments: tokens [0, seg0) use channel factors #0, then one set per `seglen`
                              // tokens (seglen == 0: a single segment).  kP / vP are [nseg, B*Hkv, 128, r].
     int64_t kP_seg_stride, vP_seg_stride;
@@ -67,13 +73,6 @@ struct AttnArgs {
     const uint8_t* vochunk;
     int nbk, nbv;
 };
-
-// valid entries of a K outlier list when the cache holds Tc compressed tokens
-__device__ __forceinline__ int k_list_len(const AttnArgs& a, int Tc) {
-    if (a.kkb == 0) return a.kk;
-    const int nblk = (a.seglen > 0 && Tc > a.seg0) ? (Tc - a.seg0) / a.seglen : 0;
-    return min(a.kk_stride, a.kk0 + nblk * a.kkb);
-}
 
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
 #pragma unroll
@@ -101,6 +100,38 @@ __device__ __forceinline__ int lower_bound_u16(const uint16_t* a, int n, int key
     }
     return lo;
 }
+
+// valid entries of a K outlier list when the cache holds Tc compressed tokens
+__device__ __forceinline__ int k_list_len(const AttnArgs& a, int Tc) {
+    if (a.kkb == 0) return a.kk;
+    const int nblk = (a.seglen > 0 && Tc > a.seg0) ? (Tc - a.seg0) / a.seglen : 0;
+    return min(a.kk_stride, a.kk0 + nblk * a.kkb);
+}
+
+// Positions of a K outlier list that can hold tokens of the chunk [t0, t0 + tn).  Plain payload: one range (binary search to the
+// first entry >= t0, the caller stops at the first entry past the chunk).  Streaming cache: the prompt segment's kk0 entries are
+// searched the same way; the entries of the 64-token blocks need no search -- block j of the cache wrote positions
+// kk0 + j * kkb .. of every list, so the chunk's blocks map to a fixed position range.
+__device__ __forceinline__ void k_list_ranges(const AttnArgs& a, const uint16_t* oi, int Tc, int t0, int tn, int (&r0)[2], int (&r1)[2],
+                                              bool search = true) {
+    r0[0] = r1[0] = r0[1] = r1[1] = 0;
+    if (a.kkb == 0) {
+        r1[0] = a.kk;
+        r0[0] = lower_bound_u16(oi, a.kk, t0);
+        return;
+    }
+    if (t0 < a.seg0 && a.kk0 > 0 && search) {
+        r1[0] = a.kk0;
+        r0[0] = lower_bound_u16(oi, a.kk0, t0);
+    }
+    const int te = min(t0 + tn, Tc);
+    if (te > a.seg0 && a.seglen > 0) {
+        const int b0 = max(t0 - a.seg0, 0) / a.seglen, b1 = (te - a.seg0 + a.seglen - 1) / a.seglen;
+        r0[1] = a.kk0 + b0 * a.kkb;
+        r1[1] = min(a.kk0 + b1 * a.kkb, a.kk_stride);
+    }
+}
+
 
 template <int BITS, typename ST>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
@@ -250,19 +281,23 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     if (a.kk > 0 && tid < AD) {
         const int d = tid;
         const float qd = qs[d];
-        const int klen = k_list_len(a, Tc);
         for (int side = 0; side < 2; side++) {
             const uint16_t* oi = a.koidx + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk_stride;
             const uint16_t* ov = a.koval + ((bhk * AD + d) * 2 + side) * (int64_t)a.kk_stride;
-            for (int i = lower_bound_u16(oi, klen, t0); i < klen; i++) {
-                const int t = oi[i];
-                if (t >= t0 + tn) break;
-                const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + t / CPW];
-                const int g = t / a.group;
-                const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
-                const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
-                const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & MASK), mnv);
-                atomicAdd(&s[t - t0], qd * (h2f_bits(ov[i]) - deq));
+            int r0[2], r1[2];
+            k_list_ranges(a, oi, Tc, t0, tn, r0, r1);
+            for (int rg = 0; rg < 2; rg++) {
+                for (int i = r0[rg]; i < r1[rg]; i++) {
+                    const int t = oi[i];
+                    if (t >= t0 + tn) break;
+                    if (t < t0) continue;
+                    const uint32_t word = a.kcode[(bhk * AD + d) * (int64_t)a.ldk + t / CPW];
+                    const int g = t / a.group;
+                    const float sc = ld_st<ST>(kscale + (bhk * AD + d) * (int64_t)a.lsk + g);
+                    const float mnv = ld_st<ST>(kmn + (bhk * AD + d) * (int64_t)a.lsk + g);
+                    const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & MASK), mnv);
+                    atomicAdd(&s[t - t0], qd * (h2f_bits(ov[i]) - deq));
+                }
             }
         }
     }
@@ -562,7 +597,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     // outlier list ranges of this chunk (chunk index present): K list (channel dq, side tid >> 7), V list (token tid & 127,
     // side tid >> 7) -- two byte loads each, issued with everything else
     int ki0 = 0, ki1 = 0, vi0 = 0, vi1 = 0;
-    if (a.kochunk) {
+    if (a.kochunk && (a.kkb == 0 || t0 < a.seg0)) {
         const int64_t list = (bhk * AD + dq) * 2 + (tid >> 7);
         ki0 = a.kochunk[list * a.nbk + split];
         ki1 = a.kochunk[list * a.nbk + split + 1];
@@ -571,6 +606,23 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         const int64_t list = ((int64_t)b * a.tcap_v + t0 + (tid & (SC - 1))) * 2 + (tid >> 7);
         vi0 = a.vochunk[list * a.nbv + hkv];
         vi1 = a.vochunk[list * a.nbv + hkv + 1];
+    }
+
+    // sparse tiles of this chunk: counts + the first two K entries / one V entry per 64-token block and thread, position known
+    int kc_n = -1, vc_n0 = -1, vc_n1 = -1;
+    uint32_t ke0 = 0u, ke1 = 0u, ve0 = 0u, ve1 = 0u;
+    if (a.ktile && a.kk > 0) {
+        kc_n = a.kcnt[bhk * a.nck + split];
+        const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
+        ke0 = kt[tid];
+        ke1 = kt[tid + 256];
+    }
+    if (a.vtile && a.kv > 0) {
+        const int64_t vb = bhk * a.nblk + 2 * split;
+        vc_n0 = a.vcnt[vb];
+        vc_n1 = (tn > 64) ? a.vcnt[vb + 1] : 0;
+        ve0 = a.vtile[vb * a.vtile_cap + tid];
+        ve1 = (tn > 64) ? a.vtile[(vb + 1) * a.vtile_cap + tid] : 0u;
     }
 
     // ------------------------------------------------------------------ 1. scores
@@ -630,15 +682,28 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     if (a.kk > 0) {   // K outliers inside the chunk: s[t] += q[d] (val - dequant(t, d))
         if (tid < SC) s[tid] = sv;
         __syncthreads();
-        {   // one sorted list per (channel, side) = per thread; its entries inside the chunk are [i0, i1)
+        if (kc_n >= 0) {   // chunk-major tile: s[t] += q[d] * (value - dequant), entries prefetched above
+            if (tid < kc_n) atomicAdd(&s[(ke0 >> 7) & 127u], qs[ke0 & 127u] * h2f_bits((uint16_t)(ke0 >> 16)));
+            if (tid + 256 < kc_n) atomicAdd(&s[(ke1 >> 7) & 127u], qs[ke1 & 127u] * h2f_bits((uint16_t)(ke1 >> 16)));
+            const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
+            for (int e = tid + 512; e < kc_n; e += 256) {
+                const uint32_t ke = kt[e];
+                atomicAdd(&s[(ke >> 7) & 127u], qs[ke & 127u] * h2f_bits((uint16_t)(ke >> 16)));
+            }
+        } else {   // one sorted list per (channel, side) = per thread; its entries inside the chunk are [i0, i1)
             const int side = tid >> 7;
             const int64_t list = (bhk * AD + dq) * 2 + side;
             const uint16_t* oi = a.koidx + list * (int64_t)a.kk_stride;
             const uint16_t* ov = a.koval + list * (int64_t)a.kk_stride;
-            int i0, i1 = k_list_len(a, Tc);
-            if (a.kochunk) { i0 = ki0; i1 = ki1; }
-            else i0 = lower_bound_u16(oi, i1, t0);
+            int r0[2], r1[2];
+            if (a.kochunk && a.kkb == 0) { r0[0] = ki0; r1[0] = ki1; r0[1] = r1[1] = 0; }
+            else {
+                k_list_ranges(a, oi, Tc, t0, tn, r0, r1, a.kochunk == nullptr);
+                if (a.kochunk && t0 < a.seg0) { r0[0] = ki0; r1[0] = ki1; }        // prompt segment through its chunk index
+            }
             const int64_t ch = bhk * AD + dq;
+            for (int rg = 0; rg < 2; rg++) {
+            const int i0 = r0[rg], i1 = r1[rg];
             for (int base = i0; base < i1; base += 4) {   // 4 entries per trip: their loads fly together
                 int tt[4];
                 float val[4];
@@ -652,7 +717,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
                 float sc[4], mnv[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const bool ok = tt[j] < t0 + tn;
+                    const bool ok = tt[j] < t0 + tn && tt[j] >= t0;
                     const int t = ok ? tt[j] : t0;
                     word[j] = a.kcode[ch * (int64_t)a.ldk + t / CPW];
                     sc[j] = ld_st<ST>(kscale + ch * (int64_t)a.lsk + t / a.group);
@@ -660,13 +725,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (tt[j] < t0 + tn) {
+                    if (tt[j] < t0 + tn && tt[j] >= t0) {
                         const int t = tt[j];
                         const float deq = fmaf(sc[j], (float)((word[j] >> (BITS * (t % CPW))) & MASK), mnv[j]);
                         atomicAdd(&s[t - t0], qv * (val[j] - deq));
                     }
                 }
-                if (tt[3] >= t0 + tn) break;   // (without the chunk index i1 = kk: stop at the first entry past the chunk)
+                if (tt[3] >= t0 + tn) break;   // (without the chunk index: stop at the first entry past the chunk)
+            }
             }
         }
         __syncthreads();
@@ -734,7 +800,18 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         if (tid < AD) oacc[tid] = o;
         __syncthreads();
         const int tok = tid & (SC - 1), side = tid >> 7;   // one sorted list per (token, side) = per thread
-        if (tok < tn) {
+        if (vc_n0 >= 0 && vc_n1 >= 0) {   // block tiles: o[d] += p[t] * (value - dequant)
+            if (tid < vc_n0) atomicAdd(&oacc[(ve0 >> 6) & 127u], s[ve0 & 63u] * h2f_bits((uint16_t)(ve0 >> 16)));
+            if (tid < vc_n1) atomicAdd(&oacc[(ve1 >> 6) & 127u], s[64 + (ve1 & 63u)] * h2f_bits((uint16_t)(ve1 >> 16)));
+            for (int hb = 0; hb < 2; hb++) {   // tiles longer than one entry per thread (rare)
+                const int n = hb ? vc_n1 : vc_n0;
+                const uint32_t* vt = a.vtile + (bhk * a.nblk + 2 * split + hb) * (int64_t)a.vtile_cap;
+                for (int e = tid + 256; e < n; e += 256) {
+                    const uint32_t ve = vt[e];
+                    atomicAdd(&oacc[(ve >> 6) & 127u], s[64 * hb + (ve & 63u)] * h2f_bits((uint16_t)(ve >> 16)));
+                }
+            }
+        } else if (tok < tn) {
             const int c_lo = hkv * AD, c_hi = c_lo + AD;
             const int ngv = AD / a.group;
             const int64_t orow = (int64_t)b * a.tcap_v + t0 + tok;
@@ -898,6 +975,36 @@ __global__ __launch_bounds__(256) void outlier_chunk_index_kernel(const uint16_t
 
 }  // namespace
 
+namespace {
+// lists (o, i), o < n_outer, i < inner: list id = o * outer_pitch + first + i; source oidx + id * list_stride (k valid entries),
+// destination out + id * out_pitch
+__global__ __launch_bounds__(256) void outlier_chunk_index_ex_kernel(const uint16_t* __restrict__ oidx, int64_t inner,
+                                                                     int64_t outer_pitch, int64_t first, int64_t total, int k,
+                                                                     int list_stride, int step, int n_bounds,
+                                                                     uint8_t* __restrict__ out, int out_pitch) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total * n_bounds) return;
+    const int64_t l = i / n_bounds;
+    const int bnd = (int)(i % n_bounds);
+    const int64_t id = (l / inner) * outer_pitch + first + (l % inner);
+    out[id * out_pitch + bnd] = (uint8_t)lower_bound_u16(oidx + id * list_stride, k, bnd * step);
+}
+}  // namespace
+
+extern "C" int gear_outlier_chunk_index_ex(const void* oidx, int64_t n_outer, int64_t inner, int64_t outer_pitch, int64_t first,
+                                           int k, int list_stride, int step, int n_bounds, void* out, int out_pitch,
+                                           void* stream) {
+    GEAR_CHECK_ARG(oidx && out && n_outer > 0 && inner > 0 && n_bounds > 0 && step > 0 && out_pitch >= n_bounds && list_stride >= k,
+                   "gear_outlier_chunk_index_ex: bad arguments");
+    GEAR_CHECK_ARG(k >= 0 && k <= 255, "gear_outlier_chunk_index_ex: list length %d must be in [0,255]", k);
+    const int64_t total = n_outer * inner, n = total * n_bounds;
+    hipLaunchKernelGGL(outlier_chunk_index_ex_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)oidx, inner, outer_pitch, first, total, k, list_stride, step, n_bounds, (uint8_t*)out,
+                       out_pitch);
+    GEAR_CHECK_LAUNCH("gear_outlier_chunk_index_ex");
+    return 0;
+}
+
 extern "C" int gear_outlier_chunk_index(const void* oidx, int64_t n_lists, int k, int step, int n_bounds, void* out,
                                         void* stream) {
     GEAR_CHECK_ARG(oidx && out && n_lists > 0 && n_bounds > 0 && step > 0, "gear_outlier_chunk_index: bad arguments");
@@ -912,6 +1019,12 @@ extern "C" int gear_outlier_chunk_index(const void* oidx, int64_t n_lists, int k
 
 namespace {
 
+struct StreamExtras {
+    int kk_stride, kk0, kkb, nbk_pitch;
+    const void *ktile, *kcnt, *vtile, *vcnt;
+    int ktile_cap, nck, vtile_cap, nblk;
+};
+
 int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
                                 const void* kQ, const void* koidx, const void* koval, const void* vcode,
                                 const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
@@ -919,7 +1032,8 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
                                 int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode,
                                 int rk, int rv, int kk, int kv, int seg0, int seglen, int wcap, const void* dyn_state,
                                 float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream,
-                     const void* kochunk, const void* vochunk, int kk_stride = 0, int kk0 = 0, int kkb = 0) {
+                     const void* kochunk, const void* vochunk, const StreamExtras* ex = nullptr) {
+    const int kk_stride = ex ? ex->kk_stride : 0, kk0 = ex ? ex->kk0 : 0, kkb = ex ? ex->kkb : 0, nbk_pitch = ex ? ex->nbk_pitch : 0;
     GEAR_CHECK_ARG(wcap >= W, "gear_attn_decode: window pitch %d smaller than the window %d", wcap, W);
     GEAR_CHECK_ARG(seglen == 0 || (seglen % 64 == 0 && seg0 % 64 == 0 && seg0 >= 0),
                    "gear_attn_decode: factor segments must be multiples of 64 tokens (seg0=%d seglen=%d)", seg0, seglen);
@@ -955,9 +1069,16 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     a.seg0 = seg0; a.seglen = seglen;
     a.dyn = (const int*)dyn_state;
     // chunk index of the outlier lists: only with 128-token bounds (K) / one bound per KV head (V), the small kernel's chunks
-    a.kochunk = (a.kk && a.kkb == 0 && a.kk_stride == a.kk) ? (const uint8_t*)kochunk : nullptr;
+    a.kochunk = (a.kk && (a.kkb > 0 ? nbk_pitch > 0 : a.kk_stride == a.kk)) ? (const uint8_t*)kochunk : nullptr;
     a.vochunk = a.kv ? (const uint8_t*)vochunk : nullptr;
-    a.nbk = (T + SC - 1) / SC + 1;
+    a.nbk = nbk_pitch > 0 ? nbk_pitch : (T + SC - 1) / SC + 1;
+    a.ktile = nullptr; a.kcnt = nullptr; a.vtile = nullptr; a.vcnt = nullptr; a.ktile_cap = a.nck = a.vtile_cap = a.nblk = 0;
+    if (ex && ex->ktile && ex->kcnt && a.kk && ex->ktile_cap >= 512) {
+        a.ktile = (const uint32_t*)ex->ktile; a.kcnt = (const int*)ex->kcnt; a.ktile_cap = ex->ktile_cap; a.nck = ex->nck;
+    }
+    if (ex && ex->vtile && ex->vcnt && a.kv && ex->vtile_cap >= 256) {
+        a.vtile = (const uint32_t*)ex->vtile; a.vcnt = (const int*)ex->vcnt; a.vtile_cap = ex->vtile_cap; a.nblk = ex->nblk;
+    }
     a.nbv = Hkv + 1;
     a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
     a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
@@ -1040,24 +1161,169 @@ extern "C" int gear_attn_decode_seg(const void* q, const void* kcode, const void
                                 seg0, seglen, wcap, nullptr, qscale, out, lse, workspace, workspace_bytes, stream);
 }
 
-// The streaming cache's entry point: as gear_attn_decode_dyn, with growing K outlier lists (see include/gear_hip.h).
-extern "C" int gear_attn_decode_stream(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
-                                       const void* kQ, const void* koidx, const void* koval, const void* vcode,
-                                       const void* vscale, const void* vmn, const void* vP, const void* vQ, const void* voidx,
-                                       const void* voval, const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D,
-                                       int T, int W, int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits,
-                                       int mode, int rk, int rv, int kk_cap, int kk0, int kkb, int kv, int seg0, int seglen,
-                                       int wcap, const void* dyn_state, float qscale, void* out, void* lse, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
-    // kk (the argument the kernels treat as "there are K outliers") = the current length when it is known on the host
-    int kk_now = kk_cap;
-    if (!dyn_state && kkb > 0) {
-        const int nblk = (seglen > 0 && T > seg0) ? (T - seg0) / seglen : 0;
-        kk_now = kk0 + nblk * kkb;
-        if (kk_now > kk_cap) kk_now = kk_cap;
+// ------------------------------------------------------------------------------------------------------------------
+// Sparse tiles of a streaming cache: re-derive, for K chunks [c0, c1) and V blocks [b0, b1), every outlier entry from the
+// sorted lists, with the correction value - dequant(code) precomputed (the codes of compressed tokens never change).
+namespace {
+
+__device__ __forceinline__ int block_excl_scan_i32(int v, int* lds, int nthreads, int* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
     }
-    return attn_decode_impl(q, kcode, kscale, kmn, kP, kQ, koidx, koval, vcode, vscale, vmn, vP, vQ, voidx, voval, kwin, vwin,
-                            B, Hq, Hkv, D, T, W, ldk, lsk, tcap_v, tf_k, tf_v, group, bits, mode, rk, rv,
-                            kkb > 0 ? kk_cap : kk_now, kv, seg0, seglen, wcap, dyn_state, qscale, out, lse, workspace,
-                            workspace_bytes, stream, nullptr, nullptr, kk_cap, kk0, kkb);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < (nthreads + 63) / 64; w++) {
+        const int t = lds[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+template <int BITS, typename ST>
+__global__ __launch_bounds__(256) void ktile_build_kernel(AttnArgs a, int T, int c0, uint32_t* __restrict__ ktile,
+                                                          int* __restrict__ kcnt) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    __shared__ int wl[4];
+    const int c = c0 + blockIdx.x, tid = threadIdx.x;
+    const int64_t bhk = blockIdx.y;
+    const int d = tid & 127, side = tid >> 7;
+    const int t0 = c * 128, tn = min(128, T - t0);
+    const int64_t list = (bhk * AD + d) * 2 + side;
+    const uint16_t* oi = a.koidx + list * (int64_t)a.kk_stride;
+    const uint16_t* ov = a.koval + list * (int64_t)a.kk_stride;
+    int r0[2] = {0, 0}, r1[2] = {0, 0};
+    if (tn > 0) k_list_ranges(a, oi, T, t0, tn, r0, r1);
+    int n = 0;
+    for (int rg = 0; rg < 2; rg++)
+        for (int i = r0[rg]; i < r1[rg]; i++) {
+            const int t = oi[i];
+            if (t >= t0 + tn) break;
+            if (t >= t0) n++;
+        }
+    int total;
+    int pos = block_excl_scan_i32(n, wl, 256, &total);
+    if (tid == 0) kcnt[bhk * a.nck + c] = (total <= a.ktile_cap) ? total : -1;
+    if (total > a.ktile_cap) return;
+    const ST* kscale = (const ST*)a.kscale;
+    const ST* kmn = (const ST*)a.kmn;
+    uint32_t* kt = ktile + (bhk * a.nck + c) * (int64_t)a.ktile_cap;
+    const int64_t ch = bhk * AD + d;
+    for (int rg = 0; rg < 2; rg++)
+        for (int i = r0[rg]; i < r1[rg]; i++) {
+            const int t = oi[i];
+            if (t >= t0 + tn) break;
+            if (t < t0) continue;
+            const uint32_t word = a.kcode[ch * (int64_t)a.ldk + t / CPW];
+            const float sc = ld_st<ST>(kscale + ch * (int64_t)a.lsk + t / a.group), mv = ld_st<ST>(kmn + ch * (int64_t)a.lsk + t / a.group);
+            const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & MASK), mv);
+            kt[pos++] = (uint32_t)d | ((uint32_t)(t - t0) << 7) | ((uint32_t)f2h_bits(h2f_bits(ov[i]) - deq) << 16);
+        }
+}
+
+template <int BITS, typename ST>
+__global__ __launch_bounds__(128) void vtile_build_kernel(AttnArgs a, int b0, uint32_t* __restrict__ vtile, int* __restrict__ vcnt) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    constexpr int NWV = AD / CPW;
+    __shared__ int wl[4];
+    const int blk = b0 + blockIdx.x, hkv = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int tok = tid & 63, side = tid >> 6;
+    const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    const int t = blk * 64 + tok;
+    const int c_lo = hkv * AD, c_hi = c_lo + AD;
+    const uint16_t* oi = a.voidx + (((int64_t)b * a.tcap_v + t) * 2 + side) * a.kv;
+    const uint16_t* ov = a.voval + (((int64_t)b * a.tcap_v + t) * 2 + side) * a.kv;
+    const int i0 = lower_bound_u16(oi, a.kv, c_lo);
+    int n = 0;
+    for (int i = i0; i < a.kv && (int)oi[i] < c_hi; i++) n++;
+    int total;
+    int pos = block_excl_scan_i32(n, wl, 128, &total);
+    if (tid == 0) vcnt[bhk * a.nblk + blk] = (total <= a.vtile_cap) ? total : -1;
+    if (total > a.vtile_cap) return;
+    const ST* vscale = (const ST*)a.vscale;
+    const ST* vmn = (const ST*)a.vmn;
+    const int ngv = AD / a.group;
+    const int64_t row = bhk * a.tcap_v + t;
+    uint32_t* vt = vtile + (bhk * a.nblk + blk) * (int64_t)a.vtile_cap;
+    for (int i = i0; i < i0 + n; i++) {
+        const int d = (int)oi[i] - c_lo;
+        const uint32_t word = a.vcode[row * NWV + d / CPW];
+        const float sc = ld_st<ST>(vscale + row * ngv + d / a.group), mv = ld_st<ST>(vmn + row * ngv + d / a.group);
+        const float deq = fmaf(sc, (float)((word >> (BITS * (d % CPW))) & MASK), mv);
+        vt[pos++] = (uint32_t)tok | ((uint32_t)d << 6) | ((uint32_t)f2h_bits(h2f_bits(ov[i]) - deq) << 16);
+    }
+}
+
+void view_to_args(const gear_cache_view* c, AttnArgs& a, StreamExtras& ex) {
+    a = AttnArgs{};
+    a.kcode = (const uint32_t*)c->kcode; a.kscale = c->kscale; a.kmn = c->kmn;
+    a.koidx = (const uint16_t*)c->koidx; a.koval = (const uint16_t*)c->koval;
+    a.vcode = (const uint32_t*)c->vcode; a.vscale = c->vscale; a.vmn = c->vmn;
+    a.voidx = (const uint16_t*)c->voidx; a.voval = (const uint16_t*)c->voval;
+    a.B = c->B; a.Hkv = c->Hkv; a.ldk = c->ldk; a.lsk = c->lsk; a.tcap_v = c->tcap; a.group = c->group;
+    a.kk = (c->koidx && c->koval) ? (c->kkb ? c->kk_cap : c->kk0) : 0; a.kv = (c->voidx && c->voval) ? c->kv : 0;
+    a.kk_stride = c->kk_cap; a.kk0 = c->kk0; a.kkb = c->kkb; a.seg0 = c->seg0; a.seglen = c->seglen;
+    a.ktile_cap = c->ktile_cap; a.nck = c->nck; a.vtile_cap = c->vtile_cap; a.nblk = c->nblk;
+    ex.kk_stride = c->kk_cap; ex.kk0 = c->kk0; ex.kkb = c->kkb; ex.nbk_pitch = c->kochunk ? c->nbk_pitch : 0;
+    ex.ktile = c->ktile; ex.kcnt = c->kcnt; ex.vtile = c->vtile; ex.vcnt = c->vcnt;
+    ex.ktile_cap = c->ktile_cap; ex.nck = c->nck; ex.vtile_cap = c->vtile_cap; ex.nblk = c->nblk;
+}
+
+}  // namespace
+
+extern "C" int gear_cache_tiles_build(const gear_cache_view* c, int T, int k_chunk0, int k_chunk1, int v_blk0, int v_blk1,
+                                      void* stream) {
+    GEAR_CHECK_ARG(c && c->D == AD && (c->bits == 2 || c->bits == 4), "gear_cache_tiles_build: bad cache view");
+    GEAR_CHECK_ARG(T >= 0 && T <= c->tcap && T % 64 == 0, "gear_cache_tiles_build: T must be a multiple of 64 within the capacity");
+    AttnArgs a;
+    StreamExtras ex;
+    view_to_args(c, a, ex);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t BH = (int64_t)c->B * c->Hkv;
+    if (c->ktile && c->kcnt && a.kk > 0 && k_chunk1 > k_chunk0) {
+        GEAR_CHECK_ARG(k_chunk0 >= 0 && k_chunk1 <= c->nck && c->ktile_cap >= 512, "gear_cache_tiles_build: bad K chunk range");
+        const dim3 grid((unsigned)(k_chunk1 - k_chunk0), (unsigned)BH);
+#define KT(B, STT) hipLaunchKernelGGL((ktile_build_kernel<B, STT>), grid, dim3(256), 0, st, a, T, k_chunk0, (uint32_t*)c->ktile, (int*)c->kcnt)
+        if (c->mode == 0) { if (c->bits == 2) KT(2, uint16_t); else KT(4, uint16_t); }
+        else { if (c->bits == 2) KT(2, float); else KT(4, float); }
+#undef KT
+    }
+    if (c->vtile && c->vcnt && a.kv > 0 && v_blk1 > v_blk0) {
+        GEAR_CHECK_ARG(v_blk0 >= 0 && v_blk1 <= c->nblk && v_blk1 * 64 <= T && c->vtile_cap >= 256, "gear_cache_tiles_build: bad V block range");
+        const dim3 grid((unsigned)(v_blk1 - v_blk0), (unsigned)c->Hkv, (unsigned)c->B);
+#define VT(B, STT) hipLaunchKernelGGL((vtile_build_kernel<B, STT>), grid, dim3(128), 0, st, a, v_blk0, (uint32_t*)c->vtile, (int*)c->vcnt)
+        if (c->mode == 0) { if (c->bits == 2) VT(2, uint16_t); else VT(4, uint16_t); }
+        else { if (c->bits == 2) VT(2, float); else VT(4, float); }
+#undef VT
+    }
+    GEAR_CHECK_LAUNCH("gear_cache_tiles_build");
+    return 0;
+}
+
+// The streaming cache's attention entry point: as gear_attn_decode_dyn over a cache view (see include/gear_hip.h).
+extern "C" int gear_attn_decode_cache(const gear_cache_view* c, const void* q, int Hq, int T, int W, const void* dyn_state,
+                                      float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    GEAR_CHECK_ARG(c, "gear_attn_decode_cache: null cache view");
+    AttnArgs tmp;
+    StreamExtras ex;
+    view_to_args(c, tmp, ex);
+    // kk (the argument the kernels treat as "there are K outliers"): with growing lists the capacity, the length follows T
+    int kk = 0;
+    if (c->koidx && c->koval) {
+        kk = c->kk_cap;
+        if (c->kkb == 0) kk = c->kk0;
+    }
+    return attn_decode_impl(q, c->kcode, c->kscale, c->kmn, c->kP, c->kQ, c->koidx, c->koval, c->vcode, c->vscale, c->vmn, c->vP,
+                            c->vQ, c->voidx, c->voval, c->kwin, c->vwin, c->B, Hq, c->Hkv, c->D, T, W, c->ldk, c->lsk, c->tcap,
+                            c->tcap, c->tcap, c->group, c->bits, c->mode, c->rk, c->rv, kk, c->kv, c->seg0, c->seglen, c->wcap,
+                            dyn_state, qscale, out, lse, workspace, workspace_bytes, stream, c->kochunk, c->vochunk, &ex);
 }

@@ -81,11 +81,18 @@ def fake_poweriteration_group(input: torch.Tensor, loop, rank, device, p_base, q
 def gears_channelQ(input, quantize_bit, group_size=128, sparsity=0.0):
     """compress_function.py:261-296: K outliers per channel row + fp32 channel quantization -> fp16."""
     B, H, T, D = input.shape
-    k = C.outlier_count(B, H, T, D, sparsity)
+    k = _k_rows(B, H, T, D, sparsity)
     if group_size == T and group_size not in (32, 64):
         return _gears_whole(input, "k", quantize_bit, k)[0]
     p = C.compress_key(_half(input), quantize_bit, group_size, k_out=k, mode="fp32")
     return C.decompress(p)
+
+
+def _k_rows(B, H, T, D, sparsity):
+    """Outliers per side of a K channel row.  The reference's count (compress_function.py:264-267) is H*D*s/2 whatever the row
+    length T (defect B7); for short rows it exceeds T/2, torch.topk then returns overlapping sets and EVERY element is restored.
+    Capping at T // 2 gives exactly that result (all elements outliers) within the kernels' 2k <= T contract."""
+    return min(C.outlier_count(B, H, T, D, sparsity), T // 2)
 
 
 def _gears_whole(input, layout, bits, k, want_err=False):
@@ -129,7 +136,7 @@ def gears_tokenQ(input, quantize_bit, group_size=128, sparsity=0.0):
 def gearslkivi_channelQ_new(input, quantize_bit, group_size=128, sparsity=0.0, rank=0, loop=1, P0=None):
     """compress_function.py:213-220 (GEAR, K): outliers + quant + low-rank of the residual."""
     B, H, T, D = input.shape
-    k = C.outlier_count(B, H, T, D, sparsity)
+    k = _k_rows(B, H, T, D, sparsity)
     if group_size == T and group_size not in (32, 64):
         return _gear_whole(input, "k", quantize_bit, k, rank, loop, P0)
     p = C.compress_key(_half(input), quantize_bit, group_size, k_out=k, rank=rank, loop=loop, mode="fp32", P0=P0)

@@ -275,17 +275,42 @@ int gear_attn_decode_idx(const void* q, const void* kcode, const void* kscale, c
                          int ldk, int lsk, int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv,
                          int kk, int kv, float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes,
                          void* stream);
-/* Decode attention over a streaming cache whose K outlier lists grow block by block: koidx / koval are
- * [B*Hkv, 128, 2, kk_cap]; of every (channel, side) list the first kk0 + kkb * ((T - seg0) / seglen) entries are valid (kk0 from
- * the prompt segment, kkb appended per block, ascending token order is kept because later blocks hold later tokens).  With
- * dyn_state the length follows the device-side T.  Everything else as gear_attn_decode_dyn. */
-int gear_attn_decode_stream(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
-                            const void* kQ, const void* koidx, const void* koval, const void* vcode, const void* vscale,
-                            const void* vmn, const void* vP, const void* vQ, const void* voidx, const void* voval,
-                            const void* kwin, const void* vwin, int B, int Hq, int Hkv, int D, int T, int W, int ldk, int lsk,
-                            int tcap_v, int tf_k, int tf_v, int group, int bits, int mode, int rk, int rv, int kk_cap, int kk0,
-                            int kkb, int kv, int seg0, int seglen, int wcap, const void* dyn_state, float qscale, void* out,
-                            void* lse, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- the streaming cache as one view --------------------------------------------------------------------------------
+ * A pre-allocated cache of one layer (or of several layers riding in the batch dimension) that blocks are appended to in place
+ * by gear_compress_key_fused / gear_compress_value_fused.  tcap = token capacity of every per-token tensor.
+ *   K outlier lists koidx / koval [B*Hkv, 128, 2, kk_cap]: of every (channel, side) list the first kk0 + kkb * ((T - seg0) / seglen)
+ *   entries are valid (kk0 from the prompt segment, kkb appended per block; later blocks hold later tokens, so the lists stay
+ *   sorted); V lists voidx / voval [B, tcap, 2 kv].  Optional accelerators, all derived from the lists:
+ *   kochunk uint8 [B*Hkv*128*2][nbk_pitch] / vochunk uint8 [B*tcap*2][Hkv+1]   chunk indices (gear_outlier_chunk_index_ex)
+ *   ktile uint32 [B*Hkv][nck][ktile_cap] + kcnt int32 [B*Hkv][nck], vtile uint32 [B*Hkv][nblk][vtile_cap] + vcnt   sparse tiles
+ *   (gear_cache_tiles_build): the outlier corrections value - dequant of a 128-token chunk / 64-token block as a flat list.
+ */
+typedef struct gear_cache_view {
+    const void *kcode, *kscale, *kmn, *kP, *kQ, *koidx, *koval;
+    const void *vcode, *vscale, *vmn, *vP, *vQ, *voidx, *voval;
+    const void *kwin, *vwin;
+    const void *kochunk, *vochunk;
+    void *ktile, *kcnt, *vtile, *vcnt;
+    int B, Hkv, D, tcap, ldk, lsk, group, bits, mode, rk, rv;
+    int kk_cap, kk0, kkb, kv, seg0, seglen, wcap, nbk_pitch;
+    int ktile_cap, nck, vtile_cap, nblk;
+} gear_cache_view;
+
+/* Single-token decode attention over a cache view: gear_attn_decode_dyn's arithmetic (segment factors, fp16 window of W <= 64
+ * tokens with row pitch wcap, optional device-side {pos, slot, T, W}), outliers through the tiles when present (no search, no
+ * dependent loads), else through the chunk indices, else by binary search in the lists. */
+int gear_attn_decode_cache(const gear_cache_view* c, const void* q, int Hq, int T, int W, const void* dyn_state, float qscale,
+                           void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream);
+/* (Re)build the sparse tiles of K chunks [k_chunk0, k_chunk1) (128 tokens each) and V blocks [v_blk0, v_blk1) (64 tokens each) of a
+ * cache that holds T compressed tokens: called after the prompt and after every appended block (the chunk the block lies in). */
+int gear_cache_tiles_build(const gear_cache_view* c, int T, int k_chunk0, int k_chunk1, int v_blk0, int v_blk1, void* stream);
+/* Chunk index over lists that live inside larger tensors (the streaming cache keeps its tables up to date block by block):
+ * lists (o, i), o < n_outer, i < inner, list id = o * outer_pitch + first + i; list `id` is oidx + id * list_stride with k valid
+ * entries; out[id * out_pitch + b] = first position whose index is >= b * step, b < n_bounds.
+ *   kochunk of a gear_cache_view: the prompt segment's entries of the K lists (k = kk0, list_stride = kk_cap, pitch nbk_pitch)
+ *   vochunk: one row of H + 1 bounds per (token row, side) of the V lists. */
+int gear_outlier_chunk_index_ex(const void* oidx, int64_t n_outer, int64_t inner, int64_t outer_pitch, int64_t first, int k,
+                                int list_stride, int step, int n_bounds, void* out, int out_pitch, void* stream);
 int gear_rope_append_dyn(const void* qkv, int B, int Hq, int Hkv, int D, const void* dyn_state, float theta, void* q_out,
                          void* kwin, void* vwin, int W, void* stream);
 int gear_decode_state_advance(void* state, void* stream);

@@ -79,14 +79,19 @@ def attn_option():
                                                         ("KIVI", 2, 2, 2, 30, 0.0), ("gearlKIVI", 2, 2, 2, 2304, 0.0),
                                                         ("gearlKIVI", 2, 4, 4, 200, 0.02), ("gearslKIVI", 4, 8, 2, 320, 0.05),
                                                         ("KIVI", 2, 2, 2, 130, 0.02)])
-@pytest.mark.parametrize("kernel", ["planned", "generic"])
+@pytest.mark.parametrize("kernel", ["planned", "lists", "generic"])
 def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, Hq, Hkv, T0, left):
+    """planned = the chunk kernel with the outliers through the sparse tiles, lists = the same kernel walking the sorted lists,
+    generic = the any-shape kernel."""
     from gear_amd.cache import GearKVCache
+    if kernel == "lists" and not left:
+        pytest.skip("no outliers: same launch as planned")
     attn_option(kernel == "generic")
     torch.manual_seed(71)
     cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3, left=left)
     B, D, steps = 2, 128, 150
     c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
+    c.use_tiles = kernel == "planned"
     c.prefill(torch.randn(B, Hkv, T0, D).half().cuda(), torch.randn(B, Hkv, T0, D).half().cuda())
     assert c.n_comp == T0 - T0 % 64 and c.n_win == T0 % 64
     worst = 0.0
@@ -102,6 +107,17 @@ def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, 
         assert c.seq_len == T0 + i + 1 and c.n_win < 64
     assert worst < 2e-3, worst
     assert c.n_comp == (T0 + steps) - (T0 + steps) % 64
+    if left:   # the tiles hold every list entry of their chunk exactly once (-1: more entries than the tile holds -> list path)
+        nblk = (c.n_comp - c.seg0) // 64
+        kcnt, vcnt = host(c.kcnt), host(c.vcnt)
+        nck = (c.n_comp + 127) // 128
+        valid = host(c.koidx)[..., :c.kk0 + nblk * c.kk_blk].astype(np.int64) & 0xFFFF          # [B,H,D,2,n]
+        want = np.stack([(valid // 128 == ch).sum(axis=(2, 3, 4)) for ch in range(nck)], axis=-1)      # [B,H,nck]
+        got = kcnt[:, :, :nck]
+        assert ((got == want) | ((got == -1) & (want > c.dims["ktile_cap"]))).all()
+        assert (got >= 0).any()
+        assert (vcnt[:, :, :c.n_comp // 64] >= 0).all()
+        assert int(vcnt[:, :, :c.n_comp // 64].sum()) == B * c.n_comp * 2 * c.kv
 
 
 def _oracle_block(x, layout, k, g, bits):
@@ -440,7 +456,7 @@ def test_pooled_block_compress_matches_per_layer(left):
             cs.maybe_compress()
         for cp, cs in zip(pooled, single):
             assert cp.n_comp == cs.n_comp == 64 * (blk + 1) and cp.n_win == cs.n_win == 0
-            for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn") + (("koidx", "koval", "voidx", "voval") if left else ()):
+            for name in ("kcode", "kscale", "kmn", "vcode", "vscale", "vmn") + (("koidx", "koval", "voidx", "voval", "kcnt", "vcnt") if left else ()):
                 assert torch.equal(getattr(cp, name), getattr(cs, name)), name
     q = torch.randn(B, 4, 1, D).half().cuda()
     a, b_ = pooled[1].attend(q), single[1].attend(q)

@@ -6,7 +6,7 @@ from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKI
 from gear_amd.fast_decode import FastGearDecoder
 dev = "cuda"
 mcfg = LlamaConfigLite(k_bits=2, v_bits=2)
-cc = dict(compress_method="gearlKIVI", group_size=64, residual=64, quantize_bit=2, rank=8, rankv=8, loop=3)
+cc = dict(compress_method="gearslKIVI", group_size=64, residual=64, quantize_bit=2, rank=8, rankv=8, loop=3, left=float(os.environ.get("LEFT", "0.02")))
 torch.set_default_dtype(torch.float16)
 with torch.device(dev):
     model = LlamaForCausalLM_GEARKIVI(mcfg, cc).eval()
