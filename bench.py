@@ -162,7 +162,7 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
         best = max(best, res["graph_replay_tokens_per_s"])
     # headline = the faster launch mode of the same token step (both reported)
     res.update({"tokens_per_s": best, "ms_per_token": 1e3 / best,
-                "path": "FastGearDecoder (GearKVCache with in-place block compress + fused GEMVs + gear_attn_decode_stream)",
+                "path": "FastGearDecoder (GearKVCache with in-place block compress + fused GEMVs + gear_attn_decode_cache)",
                 "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20})
     del fast
     torch.cuda.empty_cache()

@@ -567,7 +567,7 @@ __device__ __forceinline__ float sub_mix(uint32_t w, float one, float negmn) {
 
 template <int BITS, typename ST>
 __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
-                                          float rlen,
+                                          float rlen, int expf,
                                           uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
                                           uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
                                           uint16_t* __restrict__ oval, float* __restrict__ omean) {
@@ -657,17 +657,21 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             const float thi = mean + zthr * sd, tlo = mean - zthr * sd;
             const uint32_t th = f2h_bits(thi), tl = f2h_bits(tlo);
             const half2v thi2 = __builtin_bit_cast(half2v, th | (th << 16)), tlo2 = __builtin_bit_cast(half2v, tl | (tl << 16));
+            // sign bits of x - thi / tlo - x gathered in element order: bit 2w <- element 2w, bit 16 + 2w <- element 2w + 1
             uint32_t sg_hi = 0u, sg_lo = 0u;
 #pragma unroll
             for (int w = 0; w < 8; w++) {
                 const half2v xv = __builtin_bit_cast(half2v, rw[w]);
                 const uint32_t dh = __builtin_bit_cast(uint32_t, (half2v)(xv - thi2));
                 const uint32_t dl = __builtin_bit_cast(uint32_t, (half2v)(tlo2 - xv));
-                sg_hi |= (dh & 0x80008000u) >> w;
-                sg_lo |= (dl & 0x80008000u) >> w;
-                rawlds[tid * 8 + w] = rw[w];
+                sg_hi |= (dh >> (15 - 2 * w)) & (0x00010001u << (2 * w));
+                sg_lo |= (dl >> (15 - 2 * w)) & (0x00010001u << (2 * w));
             }
-            uint32_t mh = active ? (~sg_hi & 0xFF00FF00u) : 0u, ml = active ? (~sg_lo & 0xFF00FF00u) : 0u;
+            *(uint4*)&rawlds[tid * 8] = ra;
+            *(uint4*)&rawlds[tid * 8 + 4] = rb;
+            // candidates (sign clear: x >= thi / x <= tlo), one bit per element: large side in bits 0..15, small side in 16..31
+            const uint32_t mh = active ? (~(sg_hi | (sg_hi >> 15)) & 0xFFFFu) : 0u;
+            const uint32_t ml = active ? (~(sg_lo | (sg_lo >> 15)) & 0xFFFFu) : 0u;
             // Candidates are compacted IN INDEX ORDER into one region per wave (wave-level prefix sum of the lane counts on
             // DPP, no returning LDS atomics): the selecting wave then sees them sorted by index, so ties at the threshold
             // value resolve "lower index first" by position and the outputs come out sorted without a sort.
@@ -676,26 +680,44 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             const uint32_t incl = wave_incl_scan_u32(cntp);
             const uint32_t excl = incl - cntp;
             if (lane == 63) wave_thr[1][wave] = incl;
-            // smallest element index left in a mask (bit 15-w <-> element 2w, bit 31-w <-> element 2w+1), removed from it
-            auto next_j = [](uint32_t& msk) {   // (branch-free: __clz(0) = 32 makes an empty half lose the comparison)
-                const int we = __clz(msk & 0xFFFFu) - 16, wo = __clz(msk >> 16) - 16;   // w = 15 - msb; 16 when the half is empty
-                const bool ev = we <= wo;
-                msk &= ~(ev ? (0x8000u >> we) : (0x80000000u >> wo));
-                return ev ? 2 * we : 2 * wo + 1;
+            if (expf & 1) {
+            auto next_j = [](uint32_t& msk) {
+                const int j = __builtin_ctz(msk);
+                msk &= msk - 1u;
+                return j;
             };
+            uint32_t mh2 = mh, ml2 = ml;
             int slot = (int)(excl & 0xFFFFu);
-            while (mh) {
-                const int j = next_j(mh);
+            while (mh2) {
+                const int j = next_j(mh2);
                 const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
                 if (slot < wcap) cand[0][wave * wcap + slot] = (bits << 16) | (uint32_t)(j0 + j);
                 slot++;
             }
             slot = (int)(excl >> 16);
-            while (ml) {
-                const int j = next_j(ml);
+            while (ml2) {
+                const int j = next_j(ml2);
                 const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
                 if (slot < wcap) cand[1][wave * wcap + slot] = (bits << 16) | (uint32_t)(j0 + j);
                 slot++;
+            }
+            } else
+            {   // one loop over the lane's candidate bits, lowest first (a wave runs as many trips as its busiest lane has bits)
+                uint32_t cm = mh | (ml << 16);
+                uint32_t slot_h = excl & 0xFFFFu, slot_l = excl >> 16;
+                const uint16_t* rawh = (const uint16_t*)rawlds + tid * 16;
+                uint32_t* cbase = cand[0] + wave * wcap;
+                const uint32_t side_off = (uint32_t)(nw_ * wcap_);
+                while (cm) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(cm);
+                    cm &= cm - 1u;
+                    const uint32_t side = b >> 4, j = b & 15u;
+                    const uint32_t bits = rawh[j];
+                    const uint32_t slot = side ? slot_l : slot_h;
+                    if (slot < (uint32_t)wcap) cbase[side * side_off + slot] = (bits << 16) | (uint32_t)(j0 + (int)j);
+                    slot_l += side;
+                    slot_h += 1u - side;
+                }
             }
             // the raw copy is dead now: the lane clears its slot, which becomes its half-word outlier marks
             *(uint4*)&rawlds[tid * 8] = make_uint4(0, 0, 0, 0);
@@ -711,6 +733,60 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             }
             use_hist = over || (nh < (uint32_t)k) || (nl < (uint32_t)k) || (nh > 128u) || (nl > 128u);   // block-uniform
             if (!use_hist) {
+                if (nw <= 4 && !(expf & 2)) {
+                    // Rows of up to 4096 elements: the selecting wave reads slot `lane` of every wave's region, so that
+                    // (region, lane) order IS index order -- no mapping from a concatenated position to a region.
+                    for (int side = 0; side < 2; side++) {
+                        if (wave != ((nw > 1) ? side : 0)) continue;
+                        uint32_t cv[4], xk[4];
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const uint32_t cw_ = (w < nw) ? wave_thr[1][w] : 0u;
+                            const uint32_t cnt_w = side == 0 ? (cw_ & 0xFFFFu) : (cw_ >> 16);
+                            const bool v = (uint32_t)lane < cnt_w;
+                            cv[w] = v ? cand[side][w * wcap + lane] : 0u;
+                            const uint32_t ky = sort_key(cv[w] >> 16);
+                            // order key, larger = selected first; +1 so that 0 means "no candidate"
+                            xk[w] = v ? (side == 0 ? ky : 0xFFFFu - ky) + 1u : 0u;
+                        }
+                        uint32_t lo_b = 1u, hi_b = 0x10000u;   // largest Kt with count(x >= Kt) >= k   (count(x >= 1) = n >= k)
+                        for (int it = 0; it < 17; it++) {
+                            const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                            const int cnt = __popcll(__ballot(xk[0] >= mid)) + __popcll(__ballot(xk[1] >= mid)) +
+                                            __popcll(__ballot(xk[2] >= mid)) + __popcll(__ballot(xk[3] >= mid));
+                            if (cnt >= k) lo_b = mid; else hi_b = mid - 1u;
+                        }
+                        int above = 0;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) above += __popcll(__ballot(xk[w] > lo_b));
+                        const int need = k - above;                  // how many of the ties at the threshold value are taken
+                        uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                        uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
+                        // rank of a lane among the set lanes of a ballot, started at a wave-uniform base: v_mbcnt_lo / _hi
+                        auto rank_in = [](unsigned long long bal, int base) {
+                            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)base));
+                        };
+                        int tie_before = 0, sel_before = 0;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const bool tw = xk[w] == lo_b;
+                            const unsigned long long bt = __ballot(tw);
+                            const bool sw = xk[w] > lo_b || (tw && rank_in(bt, tie_before) < need);
+                            const unsigned long long bs = __ballot(sw);
+                            if (sw) {
+                                const int pw = rank_in(bs, sel_before);
+                                const uint32_t idx = cv[w] & 0xFFFFu;
+                                oi[pw] = (uint16_t)idx;
+                                ov[pw] = (uint16_t)(cv[w] >> 16);
+                                atomicOr(&omask[side][idx >> 5], 1u << (idx & 31));
+                                ((uint16_t*)rawlds)[idx] = (uint16_t)0xFFFFu;
+                            }
+                            tie_before += __popcll(bt);
+                            sel_before += __popcll(bs);
+                        }
+                    }
+                } else
                 for (int side = 0; side < 2; side++) {
                     if (wave != ((nw > 1) ? side : 0)) continue;
                     const uint32_t n = side == 0 ? nh : nl;
@@ -916,16 +992,25 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
 #pragma unroll
     for (int j = 0; j < 16; j++) rq[j] = __builtin_amdgcn_fmed3f(rq[j], 0.0f, (float)LEVELS);
     // ---------------- pack: Horner chains in fp32 over the HC codes of each 16-bit half (exact: < 2^16)
+    // (even, odd) element pairs ride one v_pk_fma_f32: A = sum 4^BITS^i code[2i], B = the same over the odd elements,
+    // half word = A + 2^BITS B
     uint32_t words[WPL];
 #pragma unroll
     for (int w = 0; w < WPL; w++) {
-        float hl = rq[w * CPW + HC - 1], hh = rq[w * CPW + 2 * HC - 1];
+        uint32_t hw[2];
 #pragma unroll
-        for (int i = HC - 2; i >= 0; i--) {
-            hl = fmaf(hl, (float)(1 << BITS), rq[w * CPW + i]);
-            hh = fmaf(hh, (float)(1 << BITS), rq[w * CPW + HC + i]);
+        for (int hf = 0; hf < 2; hf++) {
+            const int e0 = w * CPW + hf * HC;
+            float2v ab = {rq[e0 + HC - 2], rq[e0 + HC - 1]};
+            const float2v base2 = {(float)(1 << (2 * BITS)), (float)(1 << (2 * BITS))};
+#pragma unroll
+            for (int i = HC / 2 - 2; i >= 0; i--) {
+                const float2v dg = {rq[e0 + 2 * i], rq[e0 + 2 * i + 1]};
+                ab = __builtin_elementwise_fma(ab, base2, dg);
+            }
+            hw[hf] = (uint32_t)fmaf(ab.y, (float)(1 << BITS), ab.x);
         }
-        words[w] = (uint32_t)hl | ((uint32_t)hh << 16);
+        words[w] = hw[0] | (hw[1] << 16);
     }
     if (outl) {   // filled positions: every outlier of the group carries quant(mean)
         const float cq = (mean - qmn) * inv;
@@ -1022,7 +1107,7 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
     const int uwh = (768 > threads * 8 + 2 * nwh * wcaph) ? 768 : threads * 8 + 2 * nwh * wcaph;
     const size_t lds2 = ((size_t)uwh + 2 * (size_t)((len + 31) / 32)) * 4;
 #define GO2(B)                                                                                                         \
-    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, 1.0f / (float)len, \
+    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, 1.0f / (float)len, gear_options().rows_exp, \
                        (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,   \
                        (float*)omean)
     if (mode == 0) {

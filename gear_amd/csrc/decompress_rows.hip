@@ -77,15 +77,23 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     uint16_t pf_idx[PF], pf_val[PF];
     const int per_row_t = 2 * g.k, fill_n = g.trows * per_row_t;
     const bool pf_ok = fill_n <= PF * (int)blockDim.x;
+    // entry e = tid + q * blockDim of a fill is entry pf_c[q] of table row pf_r[q]: the same for every fill (one division here,
+    // none per fill)
+    int pf_r[PF], pf_c[PF];
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int e = tid + q * (int)blockDim.x;
+        pf_r[q] = (g.k > 0 && e < fill_n) ? e / per_row_t : -1;
+        pf_c[q] = (g.k > 0 && e < fill_n) ? e - pf_r[q] * per_row_t : 0;
+    }
     auto prefetch_entries = [&](int rbase) {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            const int e = tid + q * (int)blockDim.x;
-            const int64_t row = row0 + rbase + e / per_row_t;
+            const int64_t row = row0 + rbase + pf_r[q];
             pf_idx[q] = 0; pf_val[q] = 0;
-            if (e < fill_n && row < g.n_rows && rbase < g.rpb) {
-                pf_idx[q] = oidx[row * per_row_t + e % per_row_t];
-                pf_val[q] = oval[row * per_row_t + e % per_row_t];
+            if (pf_r[q] >= 0 && row < g.n_rows && rbase < g.rpb) {
+                pf_idx[q] = oidx[row * per_row_t + pf_c[q]];
+                pf_val[q] = oval[row * per_row_t + pf_c[q]];
             }
         }
     };
@@ -95,10 +103,8 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         __syncthreads();
         if (pf_ok) {
 #pragma unroll
-            for (int q = 0; q < PF; q++) {
-                const int e = tid + q * (int)blockDim.x;
-                if (e < fill_n && row0 + rbase + e / per_row_t < g.n_rows) lval[(size_t)(e / per_row_t) * g.len + pf_idx[q]] = pf_val[q];
-            }
+            for (int q = 0; q < PF; q++)
+                if (pf_r[q] >= 0 && row0 + rbase + pf_r[q] < g.n_rows) lval[(size_t)pf_r[q] * g.len + pf_idx[q]] = pf_val[q];
             prefetch_entries(rbase + g.trows);
         } else {
             for (int e = tid; e < fill_n; e += blockDim.x) {
@@ -140,39 +146,41 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     }
 
     // software pipeline over the block's rows: the loads of row i+1 are issued before row i is computed and stored
+    // Row ri of the block: all rows share the outer index and rpb divides rows_inner, so everything is the first row's
+    // offset plus ri times a stride -- no integer division inside the row loop (a run-time 64-bit quotient is > 100 VALU
+    // instructions, and the loop had three of them per row).
     struct RowIn { uint32_t words[WPL]; float s, m; uint4 fv0, fv1; int64_t off; };
-    auto row_offset = [&](int ri) -> int64_t {
-        const int rin = (int)((row0 + ri) % g.rows_inner);
-        return (int64_t)ro * g.outer_stride + (int64_t)rin * g.inner_stride + (int64_t)seg * g.seg_stride + pos;
-    };
+    const int rin0 = (int)(row0 % g.rows_inner);
+    const int64_t off0 = (int64_t)ro * g.outer_stride + (int64_t)rin0 * g.inner_stride + (int64_t)seg * g.seg_stride + pos;
+    const int64_t gi0 = off0 / g.group;
+    const int gstep = (int)(g.inner_stride / g.group);          // (the host checks inner_stride % group == 0)
+    const uint16_t* fv0p = nullptr;
+    if (RV > 0 && r > 0)
+        fv0p = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin0) * r : P + ((int64_t)ro * g.D + rin0) * r;
     auto fetch = [&](int ri, RowIn& in) {
-        const int rin = (int)((row0 + ri) % g.rows_inner);
-        in.off = row_offset(ri);
-        const int64_t gi = in.off / g.group;
+        in.off = off0 + (int64_t)ri * g.inner_stride;
+        const int64_t gi = gi0 + (int64_t)ri * gstep;
         in.s = ld_st<ST>(scale + gi);
         in.m = ld_st<ST>(mn + gi);
 #pragma unroll
         for (int w = 0; w < WPL; w++) in.words[w] = code[in.off / CPW + w];
         if (RV > 0 && r > 0) {
-            const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r
-                                              : P + ((int64_t)ro * g.D + rin) * r;
+            const uint16_t* fvp = fv0p + (int64_t)ri * r;
             if (RV == 4) { uint2 t = *(const uint2*)fvp; in.fv0 = make_uint4(t.x, t.y, 0, 0); }
             else in.fv0 = *(const uint4*)fvp;
             if (RV == 16) in.fv1 = ((const uint4*)fvp)[1];
         }
     };
     const int nrows = active ? (int)((g.n_rows - row0) < g.rpb ? (g.n_rows - row0) : g.rpb) : 0;
-    RowIn cur = {}, nxt = {};
-    if (nrows > 0) fetch(0, cur);
     const bool table = g.k > 0 && !g.patch;
     const int nrows_blk = (int)((g.n_rows - row0) < g.rpb ? (g.n_rows - row0) : g.rpb);   // (block-uniform)
-    for (int ri = 0; ri < nrows_blk; ri++) {
-        if (table && ri % g.trows == 0) {
+    auto before_row = [&](int ri) {
+        if (table && (ri & (g.trows - 1)) == 0) {     // (trows is a power of two)
             if (ri) __syncthreads();        // everyone is done reading the previous fill
             fill_table(ri);
         }
-        if (!active) continue;
-        if (ri + 1 < nrows) fetch(ri + 1, nxt);
+    };
+    auto compute_row = [&](int ri, const RowIn& cur) {
         float f[16];
 #pragma unroll
         for (int w = 0; w < WPL; w++) {
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             // outlier elements: the stored value replaces the dequantized one (the low-rank term still adds).  Branch-free:
             // the lane's 32 bytes of the table row, half-words that are not the sentinel select the table value
             // (per word: xor, min(x, 1), 0 - x, v_bfi -- the first version walked 16 branchy ds_read_u16 blocks)
-            const int rt = ri % g.trows;
+            const int rt = ri & (g.trows - 1);
             const uint4 t0 = *(const uint4*)&lval[(size_t)rt * g.len + j0], t1 = *(const uint4*)&lval[(size_t)rt * g.len + j0 + 8];
             auto sel = [](uint32_t tw, uint32_t dw) {
                 uint32_t x = ~tw, mk, rr;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                     f[j] = acc;
                 }
             } else {
-                const int rin = (int)((row0 + ri) % g.rows_inner);
+                const int rin = rin0 + ri;
                 const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r
                                                   : P + ((int64_t)ro * g.D + rin) * r;
                 float fv[16];
@@ -235,7 +243,25 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             op[0] = d0;
             op[1] = d1;
         }
-        cur = nxt;
+    };
+    // Two named row buffers in ping-pong (no register copies between them: a copy of a buffer whose loads are still in flight
+    // makes the compiler wait for them on the spot, which is what a rotating "cur = next" pipeline did): the loads of row
+    // i + 1 are issued before row i is computed and stored.
+    RowIn bufA = {}, bufB = {};
+    if (nrows > 0) fetch(0, bufA);
+    for (int ri = 0; ri < nrows_blk; ri += 2) {
+        before_row(ri);
+        if (active) {
+            if (ri + 1 < nrows) fetch(ri + 1, bufB);
+            compute_row(ri, bufA);
+        }
+        if (ri + 1 < nrows_blk) {
+            before_row(ri + 1);
+            if (active) {
+                if (ri + 2 < nrows) fetch(ri + 2, bufA);
+                compute_row(ri + 1, bufB);
+            }
+        }
     }
     if (g.k > 0 && g.patch) {
         // Sparse pass over the rows this block has just written: the lines are still dirty in L2, so the 2-byte stores
@@ -332,6 +358,8 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(k >= 0 && (k == 0 || (oidx && oval)), "gear_decompress_rows: outlier buffers missing");
     GEAR_CHECK_ARG(code && scale && mn && out, "gear_decompress_rows: null pointer");
     GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
+    GEAR_CHECK_ARG(inner_stride % group == 0 && outer_stride % group == 0 && (nseg == 1 || seg_stride % group == 0),
+                   "gear_decompress_rows: strides must be multiples of the group size");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
     const int patch = 0;   // (an in-kernel global patch pass measured 0.81 ms vs 0.72 ms for the LDS table: not used)

@@ -1,0 +1,44 @@
+"""Turn the PMC passes of tools/collect_profiles.sh into profiles/<tag>_traffic.json + a markdown table.
+HBM bytes per launch = FETCH_SIZE x 2 x 1024 / ... : on gfx950 rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB and FETCH_SIZE
+counts half of what is read (MI355X_MICROARCH.md, HBM / rocprofv3 section), calibrated here on a 1 GiB copy in the same run.
+usage: python tools/make_traffic.py gpurun_out/<tag> profiles/<tag> <config>"""
+import csv, json, re, sys, collections
+
+src, dst, config = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def table(path):
+    tab = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        n = re.sub(r"\(.*", "", n)
+        tab.setdefault(n, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return tab
+
+
+fetch, write = table(f"{src}/pmc_p3.csv"), table(f"{src}/pmc_p4.csv")
+GiB = float(1 << 30)
+# calibration: the copy kernel of the 1 GiB y.copy_(x)
+cal = [n for n in fetch if "copy" in n.lower() or "elementwise" in n.lower()]
+cal_f = max(max(fetch[n]["FETCH_SIZE"]) for n in cal)
+cal_w = max(max(write[n]["WRITE_SIZE"]) for n in cal)
+kf, kw = GiB / cal_f, GiB / cal_w       # bytes per counter unit, from the copy
+out = {"lib_sha256": open(f"{src}/lib.sha256").read().split()[0], "config": config, "kernels": {},
+       "how": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/prof_step.py; bytes per counter unit calibrated on a "
+              f"1 GiB copy in the same run (read {kf:.1f}, write {kw:.1f} B / unit: KB units, FETCH_SIZE counts half the bytes)"}
+rows = []
+for n in fetch:
+    if not any(t in n for t in ("compress_rows", "k_select", "k_main", "k_solve", "lr_", "transpose")):
+        continue
+    f = sorted(fetch[n]["FETCH_SIZE"])[len(fetch[n]["FETCH_SIZE"]) // 2] * kf
+    w = sorted(write[n]["WRITE_SIZE"])[len(write[n]["WRITE_SIZE"]) // 2] * kw
+    rows.append((n, f, w))
+    short = re.sub(r"<.*", "", n)
+    out["kernels"][n[:60]] = f + w
+json.dump(out, open(f"{dst}_traffic.json", "w"), indent=1)
+with open(f"{dst}_pmc_traffic.md", "w") as fmd:
+    fmd.write(f"# HBM traffic per launch (PMC), config {config}, library {out['lib_sha256'][:12]}\n\n{out['how']}\n\n"
+              "| kernel | read GB | written GB | total GB |\n|---|---:|---:|---:|\n")
+    for n, f, w in rows:
+        fmd.write(f"| `{n[:80]}` | {f / 1e9:.3f} | {w / 1e9:.3f} | {(f + w) / 1e9:.3f} |\n")
+print(open(f"{dst}_pmc_traffic.md").read())

@@ -1,0 +1,28 @@
+"""PMC / kernel-trace target (GPU box): the compress kernels of one bench step at BASELINE config 3 size, 3 launches each, after a
+1 GiB copy as calibration (1 GiB read + 1 GiB written).  usage: python tools/prof_step.py [layers]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gear_amd import compress as C
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+H, T, D, g, bits, rank, k = 32, 4096, 128, 64, 2, 8, 40
+torch.manual_seed(0)
+x = torch.empty((L, H, T, D), dtype=torch.float16, device="cuda")
+for l in range(L):
+    x[l] = torch.randn((H, T, D), device="cuda").half()
+y = torch.empty_like(x)
+for _ in range(3):
+    y.copy_(x)
+torch.cuda.synchronize()
+del y
+P0 = torch.rand((L, H, D, rank), device="cuda")
+for _ in range(3):
+    pv = C.compress_value(x, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0)
+    del pv
+torch.cuda.synchronize()
+for path in ("fused", "rows"):
+    for _ in range(3):
+        pk = C.compress_key(x, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0, path=path)
+        del pk
+    torch.cuda.synchronize()
