@@ -567,7 +567,7 @@ __device__ __forceinline__ float sub_mix(uint32_t w, float one, float negmn) {
 
 template <int BITS, typename ST>
 __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
-                                          float rlen, int expf,
+                                          float rlen,
                                           uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
                                           uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
                                           uint16_t* __restrict__ oval, float* __restrict__ omean) {
@@ -578,7 +578,7 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     __shared__ unsigned long long wave_tot[16];
     __shared__ float wave_sum[16];
     __shared__ int sh[8];
-    __shared__ uint32_t wave_thr[2][16];
+    __shared__ __attribute__((aligned(16))) uint32_t wave_thr[2][16];
     // Dynamic LDS, sized by the host for the row length (a 512-element row of an 8-way head shard needs 3.2 KB, not the
     // 20 KB of the 16384-element worst case: LDS is what bounds the number of resident one-wave workgroups):
     //   [ rawlds: blockDim x 8 words (raw copy during the emission, then the half-word outlier marks)
@@ -590,7 +590,7 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     uint32_t* cand0 = dynlds + blockDim.x * 8;
     uint32_t* cand[2] = {cand0, cand0 + nw_ * wcap_};
     uint32_t (*hist)[256] = (uint32_t (*)[256])dynlds;
-    const int uw = max(768, (int)blockDim.x * 8 + 2 * nw_ * wcap_), mw = (len + 31) >> 5;
+    const int uw = max(768, (int)blockDim.x * 8 + 2 * nw_ * wcap_ + 256), mw = (len + 31) >> 5;   // + 2 x 128 packed candidates
     uint32_t* omask[2] = {dynlds + uw, dynlds + uw + mw};
 
     const int64_t r = blockIdx.x;
@@ -680,28 +680,6 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             const uint32_t incl = wave_incl_scan_u32(cntp);
             const uint32_t excl = incl - cntp;
             if (lane == 63) wave_thr[1][wave] = incl;
-            if (expf & 1) {
-            auto next_j = [](uint32_t& msk) {
-                const int j = __builtin_ctz(msk);
-                msk &= msk - 1u;
-                return j;
-            };
-            uint32_t mh2 = mh, ml2 = ml;
-            int slot = (int)(excl & 0xFFFFu);
-            while (mh2) {
-                const int j = next_j(mh2);
-                const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
-                if (slot < wcap) cand[0][wave * wcap + slot] = (bits << 16) | (uint32_t)(j0 + j);
-                slot++;
-            }
-            slot = (int)(excl >> 16);
-            while (ml2) {
-                const int j = next_j(ml2);
-                const uint32_t bits = (rawlds[tid * 8 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
-                if (slot < wcap) cand[1][wave * wcap + slot] = (bits << 16) | (uint32_t)(j0 + j);
-                slot++;
-            }
-            } else
             {   // one loop over the lane's candidate bits, lowest first (a wave runs as many trips as its busiest lane has bits)
                 uint32_t cm = mh | (ml << 16);
                 uint32_t slot_h = excl & 0xFFFFu, slot_l = excl >> 16;
@@ -725,6 +703,18 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             __syncthreads();
             uint32_t nh = 0, nl = 0;
             bool over = false;
+            if (nw <= 4) {   // one 16-byte LDS read, the rest on the scalar unit (the counts are wave-uniform)
+                const uint4 c4 = *(const uint4*)&wave_thr[1][0];
+                const uint32_t cs[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)c4.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)c4.y),
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)c4.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)c4.w)};
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t c = (w < nw) ? cs[w] : 0u;
+                    nh += c & 0xFFFFu;
+                    nl += c >> 16;
+                    over |= ((c & 0xFFFFu) > (uint32_t)wcap) || ((c >> 16) > (uint32_t)wcap);
+                }
+            } else
             for (int w = 0; w < nw; w++) {
                 const uint32_t c = wave_thr[1][w];
                 nh += c & 0xFFFFu;
@@ -733,73 +723,27 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
             }
             use_hist = over || (nh < (uint32_t)k) || (nl < (uint32_t)k) || (nh > 128u) || (nl > 128u);   // block-uniform
             if (!use_hist) {
-                if (nw <= 4 && !(expf & 2)) {
-                    // Rows of up to 4096 elements: the selecting wave reads slot `lane` of every wave's region, so that
-                    // (region, lane) order IS index order -- no mapping from a concatenated position to a region.
-                    for (int side = 0; side < 2; side++) {
-                        if (wave != ((nw > 1) ? side : 0)) continue;
-                        uint32_t cv[4], xk[4];
-#pragma unroll
-                        for (int w = 0; w < 4; w++) {
-                            const uint32_t cw_ = (w < nw) ? wave_thr[1][w] : 0u;
-                            const uint32_t cnt_w = side == 0 ? (cw_ & 0xFFFFu) : (cw_ >> 16);
-                            const bool v = (uint32_t)lane < cnt_w;
-                            cv[w] = v ? cand[side][w * wcap + lane] : 0u;
-                            const uint32_t ky = sort_key(cv[w] >> 16);
-                            // order key, larger = selected first; +1 so that 0 means "no candidate"
-                            xk[w] = v ? (side == 0 ? ky : 0xFFFFu - ky) + 1u : 0u;
-                        }
-                        uint32_t lo_b = 1u, hi_b = 0x10000u;   // largest Kt with count(x >= Kt) >= k   (count(x >= 1) = n >= k)
-                        for (int it = 0; it < 17; it++) {
-                            const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
-                            const int cnt = __popcll(__ballot(xk[0] >= mid)) + __popcll(__ballot(xk[1] >= mid)) +
-                                            __popcll(__ballot(xk[2] >= mid)) + __popcll(__ballot(xk[3] >= mid));
-                            if (cnt >= k) lo_b = mid; else hi_b = mid - 1u;
-                        }
-                        int above = 0;
-#pragma unroll
-                        for (int w = 0; w < 4; w++) above += __popcll(__ballot(xk[w] > lo_b));
-                        const int need = k - above;                  // how many of the ties at the threshold value are taken
-                        uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
-                        uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k) + (side == 0 ? k : 0);
-                        // rank of a lane among the set lanes of a ballot, started at a wave-uniform base: v_mbcnt_lo / _hi
-                        auto rank_in = [](unsigned long long bal, int base) {
-                            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)base));
-                        };
-                        int tie_before = 0, sel_before = 0;
-#pragma unroll
-                        for (int w = 0; w < 4; w++) {
-                            const bool tw = xk[w] == lo_b;
-                            const unsigned long long bt = __ballot(tw);
-                            const bool sw = xk[w] > lo_b || (tw && rank_in(bt, tie_before) < need);
-                            const unsigned long long bs = __ballot(sw);
-                            if (sw) {
-                                const int pw = rank_in(bs, sel_before);
-                                const uint32_t idx = cv[w] & 0xFFFFu;
-                                oi[pw] = (uint16_t)idx;
-                                ov[pw] = (uint16_t)(cv[w] >> 16);
-                                atomicOr(&omask[side][idx >> 5], 1u << (idx & 31));
-                                ((uint16_t*)rawlds)[idx] = (uint16_t)0xFFFFu;
-                            }
-                            tie_before += __popcll(bt);
-                            sel_before += __popcll(bs);
-                        }
-                    }
-                } else
                 for (int side = 0; side < 2; side++) {
                     if (wave != ((nw > 1) ? side : 0)) continue;
                     const uint32_t n = side == 0 ? nh : nl;
-                    // candidate g of the concatenated (index-ordered) list lives in region w at offset g - sum of the counts before
-                    int w0 = 0, o0 = lane, w1 = 0, o1 = lane + 64;
-                    for (int w = 0; w + 1 < nw; w++) {
-                        const uint32_t c = wave_thr[1][w];
-                        const int cw = (int)(side == 0 ? (c & 0xFFFFu) : (c >> 16));
-                        if (w0 == w && o0 >= cw) { o0 -= cw; w0++; }
-                        if (w1 == w && o1 >= cw) { o1 -= cw; w1++; }
+                    // The regions hold the candidates in index order, wave after wave.  The selecting wave first packs them
+                    // into one contiguous list (slot `lane` of every region -> list position prefix + lane: wave-uniform
+                    // prefixes, no per-lane search for "which region holds position g"), then takes positions lane, lane + 64.
+                    uint32_t* packed = cand0 + 2 * nw * wcap + side * 128;     // (behind the regions of both sides)
+                    {
+                        uint32_t pre = 0u;
+                        for (int w = 0; w < nw; w++) {
+                            const uint32_t c = wave_thr[1][w];
+                            const uint32_t cw = side == 0 ? (c & 0xFFFFu) : (c >> 16);
+                            if ((uint32_t)lane < cw) packed[pre + lane] = cand[side][w * wcap + lane];
+                            pre += cw;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     const bool v0 = (uint32_t)lane < n, v1 = (uint32_t)(lane + 64) < n;
-                    const uint32_t c0 = v0 ? cand[side][w0 * wcap + o0] : 0u, c1 = v1 ? cand[side][w1 * wcap + o1] : 0u;
+                    const uint32_t c0 = v0 ? packed[lane] : 0u, c1 = v1 ? packed[lane + 64] : 0u;
                     // order key, larger = selected first (large side: the value key; small side: its complement); +1 so that
                     // 0 means "no candidate"
                     const uint32_t ka = sort_key(c0 >> 16), kb = sort_key(c1 >> 16);
@@ -1104,10 +1048,10 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
                        (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,       \
                        (float*)omean)
     const int nwh = threads / 64, wcaph = (64 < CAND_CAP / nwh) ? 64 : CAND_CAP / nwh;
-    const int uwh = (768 > threads * 8 + 2 * nwh * wcaph) ? 768 : threads * 8 + 2 * nwh * wcaph;
+    const int uwh = (768 > threads * 8 + 2 * nwh * wcaph + 256) ? 768 : threads * 8 + 2 * nwh * wcaph + 256;
     const size_t lds2 = ((size_t)uwh + 2 * (size_t)((len + 31) / 32)) * 4;
 #define GO2(B)                                                                                                         \
-    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, 1.0f / (float)len, gear_options().rows_exp, \
+    hipLaunchKernelGGL((compress_rows_fp32_kernel<B, float>), grid, block, lds2, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, 1.0f / (float)len, \
                        (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval,   \
                        (float*)omean)
     if (mode == 0) {
