@@ -105,6 +105,47 @@ def cpu_baseline(cfg):
     }
 
 
+def attn_decode_by_batch(cfg, dev):
+    """One layer's decode attention over the streaming cache (GearKVCache: 2-bit codes + per-block factors + outlier tiles + fp16
+    window) at batch 1, 4, 16: time per call and compressed bytes per second.  The decode leg runs batch 1; this shows how far
+    from the HBM rate the kernel is when a launch has more than one sequence's worth of chunks to spread over the chip."""
+    from gear_amd.cache import GearKVCache
+    H, Hq, T, bits, group, rnk, loop, s = (cfg["kv_heads"], cfg["q_heads"], cfg["T"], cfg["bits"], cfg["group"], cfg["rank"],
+                                           cfg["loop"], cfg["s"])
+    cc = dict(compress_method="gearslKIVI" if s > 0 else "gearlKIVI", group_size=group, residual=64, quantize_bit=bits,
+              rank=rnk, rankv=rnk, loop=loop, left=s)
+    out = {}
+    for B in (1, 4, 16):
+        torch.manual_seed(B)
+        k = torch.randn((B, H, T - 32, D), device=dev, dtype=torch.float16)
+        v = torch.randn((B, H, T - 32, D), device=dev, dtype=torch.float16)
+        c = GearKVCache(B, H, T + 64, cc, dev)
+        c.prefill(k, v)
+        q = torch.randn((B, Hq, 1, D), device=dev, dtype=torch.float16)
+        for _ in range(10):
+            c.attend(q)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 200
+        e0.record()
+        for _ in range(reps):
+            c.attend(q)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        nc = c.n_comp
+        # bytes the kernels read per call: codes + scale / mn + token factors of the compressed tokens, the outlier tiles' entries
+        nbytes = B * H * nc * D * bits / 8 * 2 + B * H * (nc // group) * D * 2 * 2 * 2 + B * H * nc * rnk * 2 * 2
+        if s > 0:
+            nbytes += int(c.kcnt[:, :, :(nc + 127) // 128].clamp(min=0).sum()) * 4 + int(c.vcnt[:, :, :nc // 64].clamp(min=0).sum()) * 4
+        nbytes += B * H * c.n_win * D * 2 * 2
+        out[f"B{B}"] = {"us_per_call": us, "compressed_GBps": nbytes / (us * 1e-6) / 1e9,
+                        "fp16_equiv_GBps": B * H * (nc + c.n_win) * D * 2 * 2 / (us * 1e-6) / 1e9}
+        del c, k, v, q
+        torch.cuda.empty_cache()
+    return out
+
+
 def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
     """a14 counterpart (cuda_supported_gear/test.py:95-102): random-weight model of the named shapes through the GEAR cache
     (packed cache with per-block low-rank factors and sparse outliers, fused decode attention, block compression every 64
@@ -464,6 +505,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg)
     del K, V, kr, vr, pk, pv, out, qv
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.layers and not args.emulate_world:
+        res["attn_decode"]["one_layer_streaming_cache_by_batch"] = attn_decode_by_batch(cfg, dev)
     if not args.no_decode and not args.layers and not args.emulate_world:
         dec = decode_tokens_per_s(cfg, dev, world, rank, args.decode_tokens)     # (every rank takes part when sharded)
         if dist is not None:

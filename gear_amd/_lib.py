@@ -64,24 +64,50 @@ SIGNATURES = {
 }
 
 
+def _source_hash() -> str:
+    """sha256 over the kernel sources (names + contents): what the built library is checked against."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile gear_amd/csrc/*.hip for gfx950 into gear_amd/libgear_hip.so (hipcc cross-compiles without a GPU)."""
+    """Compile gear_amd/csrc/*.hip for gfx950 into gear_amd/libgear_hip.so (hipcc cross-compiles without a GPU) and record
+    the hash of the sources it was built from next to it."""
     cmd = ["make", "-C", CSRC, "-j8"]
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    with open(LIB_PATH + ".src", "w") as f:
+        f.write(_source_hash())
     return LIB_PATH
 
 
 def load():
-    """Load the HIP library; raise if it has not been built."""
+    """Load the HIP library.  A library that is missing or was built from other sources than the ones in the tree is rebuilt
+    first (make is incremental); without a compiler that is an error -- gear_amd has no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C gear_amd/csrc). "
-            "gear_amd has no CPU fallback.")
+    stale = not os.path.exists(LIB_PATH)
+    if not stale:
+        try:
+            with open(LIB_PATH + ".src") as f:
+                stale = f.read().strip() != _source_hash()
+        except OSError:
+            stale = True
+    if stale:
+        try:
+            build()
+        except (OSError, subprocess.CalledProcessError) as e:
+            raise RuntimeError(
+                f"{LIB_PATH} is missing or older than gear_amd/csrc and could not be rebuilt ({e}): run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C gear_amd/csrc). gear_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and the library disagree
