@@ -436,9 +436,11 @@ def main():
     if os.path.exists(tp) and world == 1 and not args.layers and not args.emulate_world:
         prof = json.load(open(tp))
         if prof.get("lib_sha256") == lib_sha256() and prof.get("config") == args.config:
-            for kname, tb in prof.get("kernels", {}).items():
-                if dom["kernel"].startswith(kname):
-                    traffic, tnote = tb, f"profiles/r2_traffic.json ({prof.get('how', '')})"
+            base = dom["kernel"].split(" ")[0].split("<")[0]       # compress_rows_fp32_kernel / k_select_kernel / k_main_kernel
+            hit = [tb for kname, tb in prof.get("kernels", {}).items()
+                   if kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")]
+            if hit:
+                traffic, tnote = float(sum(hit)), f"profiles/r2_traffic.json ({prof.get('how', '')})"
         else:
             tnote = "profiles/r2_traffic.json was measured on a different library build / config"
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -6,8 +6,12 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r1_final_bench_line.json")))
+import pytest
+
+
+@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json"])
+def test_committed_bench_line_has_the_contract_fields(line):
+    d = json.load(open(os.path.join(ROOT, "profiles", line)))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -25,6 +29,24 @@ def test_committed_bench_line_has_the_contract_fields():
     # value = fp16 KV bytes through compress + decompress per second, whole job
     n = 32 * 32 * 4096 * 128
     assert abs(d["value"] - 2 * (2 * n * 2) / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    if line.startswith("r2"):
+        # round 2: per-kernel and per-chain rooflines on SURVEY 8(d) bytes (no error term), traffic tied to the library build
+        assert "no error term" in r["bytes_definition"] and "traffic_source" in r
+        for name in ("k_compress", "v_compress", "k_decompress", "v_decompress"):
+            ch = d["roofline_chain"][name]
+            assert abs(ch["frac"] - ch["alg_bytes"] / (ch["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        assert len(d["kernels"]) >= 3 and r["kernel"] in [kx["kernel"] for kx in d["kernels"]]
+        assert abs(r["ms_per_launch"] - max(kx["ms"] for kx in d["kernels"][:3])) < 1e-12
+        # 8(d) bytes of the V rows launch: read 2n + codes n/4 + scale / mn 8n/64 + 131072 rows x 80 entries x 4 bytes
+        v = d["kernels"][0]
+        assert v["kernel"].startswith("compress_rows_fp32_kernel") and v["alg_bytes"] == 2 * n + n / 4 + 8 * n / 64 + 131072 * 80 * 4
+        assert d["decode"]["outliers_per_side"]["v_row"] == 40 and "2% outliers" in d["decode"]["method"]
+
+
+def test_traffic_profile_names_the_library_it_was_measured_on():
+    t = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+    assert len(t["lib_sha256"]) == 64 and t["config"] == "c3" and t["kernels"] and "FETCH_SIZE" in t["how"]
+    assert all(v > 0 for v in t["kernels"].values())
 
 
 def test_bench_parses_and_defaults_to_one_gpu():
