@@ -149,16 +149,6 @@ def compress_rows_once(x, geom, group, bits, mode, k, want_err, err=None):
     return out + (err,)
 
 
-def _batches_per_chunk(B: int, bytes_per_batch: int) -> int:
-    """Cache blocking over the leading (batch / layer) dimension: the error matrix a chunk writes (and the K^T re-layout
-    it reads) is consumed again by the low-rank kernels right away, so a chunk is sized to stay in the 256 MB Infinity
-    Cache instead of making two more trips through HBM.  GEAR_CHUNK_MB overrides (0 = one chunk)."""
-    mb = int(os.environ.get("GEAR_CHUNK_MB", "0"))
-    if mb <= 0:
-        return B
-    return max(1, min(B, (mb << 20) // max(1, bytes_per_batch)))
-
-
 def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
                    mode="fp32", P0: Optional[torch.Tensor] = None) -> Payload:
     """V [B,H,T,D] fp16 -> Payload (per-token groups along D; outliers per token row across heads)."""
@@ -174,8 +164,7 @@ def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank:
     if rank > 0:
         if P0 is None:
             P0 = draw_p0(B, H, T, D, rank, dev)
-        nb = _batches_per_chunk(B, H * T * D * 2)
-        err = torch.empty((nb, H, T, D), dtype=torch.float16, device=dev)   # reused by every chunk: stays cache-resident
+        err = torch.empty((nb, H, T, D), dtype=torch.float16, device=dev)
         P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
         Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
     for b0 in range(0, B, nb):
@@ -262,15 +251,15 @@ def _compress_key_impl(src: torch.Tensor, src_is_transposed: bool, bits, group, 
     dev = src.device
     code, scale, mn, oidx, oval = _alloc_rows((B, H, D, T), B * H * D, group, bits, m, k_out, dev)
     P = Q = err = ktb = None
-    nb = _batches_per_chunk(B, H * T * D * 2) if (rank > 0 or not src_is_transposed) else B
+    nb = B
     if rank > 0:
         if P0 is None:
             P0 = draw_p0(B, H, T, D, rank, dev)
-        err = torch.empty((nb, H, D, T), dtype=torch.float16, device=dev)   # E^T of one chunk, reused
+        err = torch.empty((nb, H, D, T), dtype=torch.float16, device=dev)   # E^T
         P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
         Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
     if not src_is_transposed:
-        ktb = torch.empty((nb, H, D, T), dtype=torch.float16, device=dev)   # K^T of one chunk, reused
+        ktb = torch.empty((nb, H, D, T), dtype=torch.float16, device=dev)   # K^T
     lib = L.load()
     for b0 in range(0, B, nb):
         b1 = min(B, b0 + nb)
