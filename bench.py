@@ -422,9 +422,9 @@ def main():
         b_main = 2 * n + n / 8 * (1 if k_key else 0) + n * bits / 8 + 8 * n / group
         kernels.append({"kernel": "k_select_kernel + k_select_fix_kernel (K: per-channel outlier selection over T, token-major input)",
                         "ms": ms_sel, "alg_bytes": b_sel})
-        kernels.append({"kernel": f"k_main_kernel<{bits}, 1, {group}, float, ...> (K: fused quantize + pack + error + Gram on the matrix cores)",
+        kernels.append({"kernel": f"k_main_kernel<{bits}, 1, {group}, float, ...> (K: fused fill + quantize + pack + Gram on the matrix cores)",
                         "ms": ms_main, "alg_bytes": b_main,
-                        "not_counted": "the fp16 error written once for the Q pass (2n bytes) and the partial Gram matrices"})
+                        "not_counted": "the partial Gram matrices (64 KB per head and slab); no error matrix is written: the Q pass rebuilds it"})
         kernels.append({"kernel": "fused K chain (select, main, per-head solve, Q pass)", "ms": ms_full, "alg_bytes": alg["k_compress"]})
     for kx in kernels:
         kx["achieved"] = kx["alg_bytes"] / (kx["ms"] * 1e-3) / 1e9 if kx["ms"] else None

@@ -16,22 +16,23 @@
 //                     quantize, bit-pack along T (straight into the channel-major K^T payload layout the decode
 //                     attention streams, with a row pitch / token offset so that the streaming cache is written in
 //                     place) and the fp16 error, which goes into the wave's LDS tile and from there into
-//                     v_mfma_f32_32x32x16_f16 for the per-head Gram matrix G = E^T E.  The error matrix is additionally
-//                     written ONCE token-major for the Q pass (no E^T, no transpose kernel, no Gram pass over HBM).
+//                     v_mfma_f32_32x32x16_f16 for the per-head Gram matrix G = E^T E.  The error matrix never reaches HBM
+//                     (no E^T, no transpose kernel, no Gram pass over HBM).
 //   k_solve_kernel    per head: sum the slabs' partial Gram matrices, power iteration + CholeskyQR2 in LDS
 //                     (lowrank_solve.h) -> W, P.
-//   Q pass            Q' = E W, lowrank_gram.hip's token-major MFMA kernel.
+//   k_qpass_kernel    Q' = E W with E rebuilt on the fly: x tile + the codes / scale / mn k_main_kernel just stored + the
+//                     outlier bitmap -> the same E bits -> LDS tile -> matrix cores (W as fp16 head + remainder).
 //
-// HBM traffic per K tensor of n elements: read 2n (select) + read 2n, write n*b/8 + 8n/g + 2n (main) + read 2n (Q pass)
-// = 8.3n bytes against 12.6n for the round-1 chain (transpose r+w 4n, rows r 2n + w 2.3n, Gram 2n, Q 2n + ...).
+// HBM traffic per K tensor of n elements: read 2n (select) + read 2n, write n*b/8 + 8n/g (main) + read 2n + n*b/8 + 8n/g
+// (Q pass) = 6.9n bytes against 12.6n for the round-1 chain (transpose r+w 4n, rows r 2n + w 2.3n, Gram 2n, Q 2n + ...) and
+// 8.3n with the error written once and read back (measured: k_main 0.60 -> 0.47 ms, Q pass 0.22 -> 0.34 ms).
 #include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
 #include "lowrank_solve.h"
 
-int gear_qpass_tm(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_dtype, int q_tcap, int q_toff,
-                  hipStream_t st);
+
 int gear_lowrank_gram_ex(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
                          int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, int out_dtype,
                          void* workspace, hipStream_t st);
@@ -529,7 +530,6 @@ struct MainArgs {
     void* mn;
     int64_t ldc, lds;
     int t_off;               // token offset of this call inside the payload rows (multiple of 64)
-    uint16_t* err;           // [BH][T][128] fp16 error, token-major (null: not needed)
     float* gpart;            // [BH][nslab][128][128] partial Gram matrices (blocks on / above the block diagonal), or null
 };
 
@@ -833,11 +833,6 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
                 st_st<ST>(sA + a.lds + gi, scB[gi]);
                 st_st<ST>(nA + a.lds + gi, mnB[gi]);
             }
-            if (a.err) {   // (4-byte stores straight from the registers: re-reading the LDS tile for 16-byte stores measured slower)
-                uint32_t* ep = (uint32_t*)(a.err + (bh * T + (int64_t)tile * 64) * KD) + lane;
-#pragma unroll
-                for (int i = 0; i < 64; i++) ep[i * 64] = ew[i];
-            }
             if (LR) {   // error tile -> LDS (row = token, conflict-free 4-byte stores)
 #pragma unroll
                 for (int i = 0; i < 64; i++) ((uint32_t*)(etile + i * ET_PITCH))[lane] = ew[i];
@@ -897,6 +892,156 @@ __global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict
                           out_f16 ? (void*)((uint16_t*)P_out + po) : (void*)((float*)P_out + po), out_f16);
 }
 
+
+// ================================================================================================ Q pass by recomputation
+// Q' = E W without an error matrix in HBM: the wave loads its 64-token tile of x exactly as k_main_kernel does (lane = channel
+// pair), reads back the codes / scale / mn that kernel stored (channel-major rows: 16 contiguous bytes per channel and tile at
+// 2 bits) and the outlier bitmap, rebuilds E = x - fp16(dequant), 0 at the outliers (the same arithmetic, so the same bits),
+// puts the tile into LDS and multiplies by W on the matrix cores like lr_qpass_tm_mfma_kernel (W as fp16 head + remainder).
+// ~10 VALU instructions per element pair against 2 bytes per element written by k_main_kernel and read back here.
+struct QpArgs {
+    const uint16_t* x;       // [BH][T][128]
+    const uint32_t* obits;   // [BH][T/64][128][2] or null
+    int T, tiles_per_wg;
+    const uint32_t* code;    // as MainArgs
+    const void* scale;
+    const void* mn;
+    int64_t ldc, lds;
+    int t_off;
+    const float* W;          // [BH][128][RP]
+    int r;
+    uint16_t* Q;             // [BH][q_tcap][r] fp16, tokens from q_toff
+    int q_tcap, q_toff;
+};
+
+template <int BITS, int MODE, int G, typename ST, int RP>
+__global__ __launch_bounds__(256, 2) void k_qpass_kernel(QpArgs a) {
+    constexpr int CPW = 32 / BITS;
+    constexpr int NW = 64 / CPW;
+    constexpr int NG = 64 / G;
+    constexpr uint32_t CMASK = (1u << BITS) - 1u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* etiles = (uint16_t*)smem;                                   // [4][64][ET_PITCH]
+    uint16_t* Ah = etiles + 4 * 64 * ET_PITCH;                            // [16][RP][8]: W as fp16, [k / 8][m][k % 8]
+    uint16_t* Al = Ah + 16 * RP * 8;                                      // w - fp16(w)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bh = blockIdx.y;
+    const int T = a.T, ntiles = T >> 6;
+    uint16_t* etile = etiles + wave * 64 * ET_PITCH;
+    for (int idx = tid; idx < KD * RP; idx += 256) {
+        const int k = idx / RP, m = idx % RP;
+        const float w = a.W[(bh * KD + k) * RP + m];
+        const uint16_t hi = f2h_bits(w);
+        const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
+        Ah[pos] = hi;
+        Al[pos] = f2h_bits(w - h2f_bits(hi));
+    }
+    __syncthreads();
+    const int tile_lo = blockIdx.x * a.tiles_per_wg, tile_hi = min(ntiles, tile_lo + a.tiles_per_wg);
+    const ST* srow = (const ST*)a.scale + (bh * KD + 2 * lane) * a.lds;
+    const ST* mrow = (const ST*)a.mn + (bh * KD + 2 * lane) * a.lds;
+    const uint32_t* crow = a.code + (bh * KD + 2 * lane) * a.ldc;
+
+    uint32_t xr[64], cw[2][NW];
+    uint4 mk = make_uint4(0, 0, 0, 0);
+    float sc[2][NG], zp[2][NG];
+    auto load_tile = [&](int tile) {
+        const uint32_t* xw = (const uint32_t*)(a.x + (bh * T + (int64_t)tile * 64) * KD) + lane;
+#pragma unroll
+        for (int i = 0; i < 64; i++) xr[i] = xw[i * 64];
+        mk = make_uint4(0, 0, 0, 0);
+        if (a.obits) mk = *(const uint4*)&a.obits[((bh * ntiles + tile) * KD + 2 * lane) * 2];
+        const int tok = a.t_off + tile * 64;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int w = 0; w < NW; w += 4) {
+                const uint4 c = *(const uint4*)(crow + h * a.ldc + tok / CPW + w);
+                cw[h][w] = c.x; cw[h][w + 1] = c.y; cw[h][w + 2] = c.z; cw[h][w + 3] = c.w;
+            }
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                sc[h][gi] = ld_st<ST>(srow + h * a.lds + tok / G + gi);
+                zp[h][gi] = ld_st<ST>(mrow + h * a.lds + tok / G + gi);
+            }
+        }
+    };
+    const int n = lane & 31, kg = lane >> 5;
+    union U { uint4 u; half8_t h; };
+    if (tile_lo + wave < tile_hi) load_tile(tile_lo + wave);
+#pragma unroll 1
+    for (int tile = tile_lo + wave; tile < tile_hi; tile += 4) {
+        // ---- E tile -> LDS (row = token)
+        const uint32_t D[4] = {(mk.x & 0xFFFFu) | (mk.z << 16), (mk.x >> 16) | (mk.z & 0xFFFF0000u),
+                               (mk.y & 0xFFFFu) | (mk.w << 16), (mk.y >> 16) | (mk.w & 0xFFFF0000u)};
+#pragma unroll
+        for (int tk = 0; tk < 64; tk++) {
+            const int gi = tk / G;
+            const int qa = (int)((cw[0][tk / CPW] >> (BITS * (tk % CPW))) & CMASK), qb = (int)((cw[1][tk / CPW] >> (BITS * (tk % CPW))) & CMASK);
+            const float da = dequant_one<MODE>(qa, sc[0][gi], zp[0][gi]), db = dequant_one<MODE>(qb, sc[1][gi], zp[1][gi]);
+            const uint32_t dw = (uint32_t)f2h_bits(da) | ((uint32_t)f2h_bits(db) << 16);
+            uint32_t e2;
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tk]), "v"(dw));
+            ((uint32_t*)(etile + tk * ET_PITCH))[lane] = vbfi(mask_of(D[tk >> 4], tk & 15), 0u, e2);
+        }
+        if (tile + 4 < tile_hi) load_tile(tile + 4);      // the next tile's loads fly during the matrix-core phase
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float16_t acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                U ah, al, b;
+                ah.u = al.u = make_uint4(0, 0, 0, 0);
+                if (n < RP) {
+                    ah.u = *(const uint4*)&Ah[((2 * ks + kg) * RP + n) * 8];
+                    al.u = *(const uint4*)&Al[((2 * ks + kg) * RP + n) * 8];
+                }
+                b.u = *(const uint4*)(etile + (32 * half + n) * ET_PITCH + 16 * ks + 8 * kg);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, acc, 0, 0, 0);
+            }
+            const int64_t token = (int64_t)tile * 64 + 32 * half + n;
+#pragma unroll
+            for (int qb = 0; qb < (RP + 7) / 8; qb++) {   // register block qb holds rank columns 8 qb + 4 kg + (0..3)
+                const int c0 = 8 * qb + 4 * kg;
+                if (c0 >= RP) continue;
+                if (a.r == RP) {
+                    uint2 v;
+                    v.x = (uint32_t)f2h_bits(acc[4 * qb]) | ((uint32_t)f2h_bits(acc[4 * qb + 1]) << 16);
+                    v.y = (uint32_t)f2h_bits(acc[4 * qb + 2]) | ((uint32_t)f2h_bits(acc[4 * qb + 3]) << 16);
+                    *(uint2*)(a.Q + (bh * a.q_tcap + a.q_toff + token) * (int64_t)RP + c0) = v;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (c0 + i < a.r) a.Q[(bh * (int64_t)a.q_tcap + a.q_toff + token) * a.r + c0 + i] = f2h_bits(acc[4 * qb + i]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                  // the tile is read before the next one overwrites it
+    }
+}
+
+template <int BITS, int MODE, int G, typename ST>
+void launch_qpass(const QpArgs& a, int64_t BH, int RP, hipStream_t st) {
+    const int ntiles = a.T / 64;
+    const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)BH);
+    const size_t shmem = (size_t)4 * 64 * ET_PITCH * 2 + (size_t)2 * 16 * RP * 8 * 2;
+#define KQ_GO(RPV)                                                                                                     \
+    do {                                                                                                               \
+        auto kfn = k_qpass_kernel<BITS, MODE, G, ST, RPV>;                                                             \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);           \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), shmem, st, a);                                                        \
+    } while (0)
+    if (RP == 4) KQ_GO(4); else if (RP == 8) KQ_GO(8); else KQ_GO(16);
+#undef KQ_GO
+}
+
 double inv_norm_cdf(double p) {  // Acklam's rational approximation (relative error 1.2e-9), 0 < p < 1
     static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
                                1.383577518672690e+02,  -3.066479806614716e+01, 2.506628277459239e+00};
@@ -922,7 +1067,7 @@ double inv_norm_cdf(double p) {  // Acklam's rational approximation (relative er
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KfWs {       // workspace carve-up
-    size_t obits, omean, err, gpart, W, todo, total;
+    size_t obits, omean, gpart, W, todo, total;
     int nslab, tiles_per_slab;
 };
 KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
@@ -937,7 +1082,6 @@ KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
     size_t off = 0;
     w.obits = off; off += align256(k > 0 ? (size_t)BH * ntiles * KD * 8 : 0);
     w.omean = off; off += align256(k > 0 ? (size_t)BH * KD * 4 : 0);
-    w.err = off;   off += align256(rank > 0 ? (size_t)BH * T * KD * 2 : 0);
     w.gpart = off; off += align256(rank > 0 ? (size_t)BH * nslab * KD * KD * 4 : 0);
     w.W = off;     off += align256(rank > 0 ? (size_t)BH * KD * RP * 4 : 0);
     w.todo = off;  off += align256(k > 0 ? 256 + (size_t)BH * 256 * 4 : 0);   // counter (first 256 bytes) + list ids
@@ -1003,7 +1147,6 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     uint32_t* obits = k > 0 ? (uint32_t*)(base + ws.obits) : nullptr;
     float* omean = k > 0 ? (float*)(base + ws.omean) : nullptr;
-    uint16_t* err = rank > 0 ? (uint16_t*)(base + ws.err) : nullptr;
     float* gpart = rank > 0 ? (float*)(base + ws.gpart) : nullptr;
     float* Wws = rank > 0 ? (float*)(base + ws.W) : nullptr;
 
@@ -1037,7 +1180,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     ma.x = (const uint16_t*)x; ma.obits = obits; ma.omean = omean; ma.T = T;
     ma.tiles_per_slab = ws.tiles_per_slab; ma.nslab = ws.nslab;
     ma.code = (uint32_t*)code; ma.scale = scale; ma.mn = mn; ma.ldc = ldc; ma.lds = lds; ma.t_off = t_off;
-    ma.err = err; ma.gpart = gpart;
+    ma.gpart = gpart;                        // no error matrix in HBM: the Q pass rebuilds it (k_qpass_kernel)
     const bool fast = (variant & 1) == 0 && !gear_options().kfused_generic, lr = rank > 0;
     const bool tr = (variant & 4) == 0 && !gear_options().kfused_no_tr;
 #define KF_DISPATCH(B, M, GG, STT) launch_main<B, M, GG, STT>(ma, BH, fast, lr, tr, st)
@@ -1065,7 +1208,21 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         if (RP == 4) KF_SOLVE(4); else if (RP == 8) KF_SOLVE(8); else KF_SOLVE(16);
 #undef KF_SOLVE
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
-        return gear_qpass_tm(err, Wws, BH, T, rank, Q_out, GEAR_DTYPE_F16, q_tcap, q_toff, st);
+        QpArgs qa;
+        qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T; qa.tiles_per_wg = 16;
+        qa.code = (const uint32_t*)code; qa.scale = scale; qa.mn = mn; qa.ldc = ldc; qa.lds = lds; qa.t_off = t_off;
+        qa.W = Wws; qa.r = rank; qa.Q = (uint16_t*)Q_out; qa.q_tcap = q_tcap; qa.q_toff = q_toff;
+#define KQ_DISPATCH(B, M, GG, STT) launch_qpass<B, M, GG, STT>(qa, BH, RP, st)
+        if (mode == GEAR_MODE_FP32) {
+            if (bits == 2) { if (group == 64) KQ_DISPATCH(2, 1, 64, float); else KQ_DISPATCH(2, 1, 32, float); }
+            else { if (group == 64) KQ_DISPATCH(4, 1, 64, float); else KQ_DISPATCH(4, 1, 32, float); }
+        } else {
+            if (bits == 2) { if (group == 64) KQ_DISPATCH(2, 0, 64, uint16_t); else KQ_DISPATCH(2, 0, 32, uint16_t); }
+            else { if (group == 64) KQ_DISPATCH(4, 0, 64, uint16_t); else KQ_DISPATCH(4, 0, 32, uint16_t); }
+        }
+#undef KQ_DISPATCH
+        GEAR_CHECK_LAUNCH("gear_compress_key_fused(Q pass)");
+        return 0;
     }
     return 0;
 }

@@ -367,17 +367,3 @@ int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, i
                       void* Q_out, int out_dtype, void* workspace, hipStream_t st) {
     return gear_lowrank_gram_ex(E, transposed, bh, S, r, loop, P0, P_out, bh, 0, Q_out, S, 0, out_dtype, workspace, st);
 }
-
-// Q' = E W for a token-major fp16 error E [bh][S][128] with the token-side factor written at row q_toff of a [bh][q_tcap][r]
-// tensor (the streaming cache's layout); W fp32 [bh][128][RP] as gram_solve_phase2 leaves it.  Used by kfused.hip.
-int gear_qpass_tm(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_dtype, int q_tcap, int q_toff,
-                  hipStream_t st) {
-    const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
-    const int of16 = out_dtype == GEAR_DTYPE_F16;
-    const dim3 grid((S + 511) / 512, (unsigned)bh);
-    if (RP == 4) hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<4>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, of16, q_tcap, q_toff);
-    else if (RP == 8) hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<8>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, of16, q_tcap, q_toff);
-    else hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<16>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, of16, q_tcap, q_toff);
-    GEAR_CHECK_LAUNCH("gear_qpass_tm");
-    return 0;
-}

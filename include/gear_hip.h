@@ -118,8 +118,9 @@ int gear_compress_rows(const void* x, int64_t n_rows, int rows_inner, int64_t ou
  * :403) -> gears_channelQ (GenerationBench/.../Simulated/compress_function.py:261-296) -> fake_poweriteration_group
  * (:69-98) / key_compression (modeling_llamagear.py:23-38):  per-channel outlier selection over the T tokens, mean fill,
  * group quantization along T, bit-packing into the channel-major K^T payload layout, the fp16 error and its rank-r
- * power iteration -- in four launches (select, fused quantize + pack + error + Gram on the matrix cores, per-head solve,
- * Q pass) that read x three times and write the error once (the round-1 chain moved 12.6 bytes per element, this 8.3).
+ * power iteration -- in four launches (select, fused quantize + pack + Gram on the matrix cores, per-head solve, Q pass)
+ * that read x three times and never write the error matrix: the Q pass rebuilds E = x - dequant from x, the stored codes /
+ * scale / mn and the outlier bitmap (the round-1 chain moved 12.6 bytes per element through HBM, this 6.9).
  *   x     fp16 [BH, T, 128] token-major                       T % 64 == 0, 64 <= T <= 16384; group in {32, 64}; bits in {2, 4}
  *   code  int32 [BH, 128, ldc]   words  t_off / fpi ..  of every channel row are written (ldc = row pitch in words)
  *   scale, mn [BH, 128, lds]     fp16 (mode 0) / float (mode 1), groups t_off / group ..
