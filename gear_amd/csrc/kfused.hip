@@ -915,20 +915,20 @@ struct QpArgs {
 };
 
 template <int BITS, int MODE, int G, typename ST, int RP>
-__global__ __launch_bounds__(256, 2) void k_qpass_kernel(QpArgs a) {
+__global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
     constexpr int CPW = 32 / BITS;
     constexpr int NW = 64 / CPW;
     constexpr int NG = 64 / G;
     constexpr uint32_t CMASK = (1u << BITS) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* etiles = (uint16_t*)smem;                                   // [4][64][ET_PITCH]
-    uint16_t* Ah = etiles + 4 * 64 * ET_PITCH;                            // [16][RP][8]: W as fp16, [k / 8][m][k % 8]
+    uint16_t* etiles = (uint16_t*)smem;                                   // [4][32][ET_PITCH]: half a tile per wave at a time
+    uint16_t* Ah = etiles + 4 * 32 * ET_PITCH;                            // [16][RP][8]: W as fp16, [k / 8][m][k % 8]
     uint16_t* Al = Ah + 16 * RP * 8;                                      // w - fp16(w)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t bh = blockIdx.y;
     const int T = a.T, ntiles = T >> 6;
-    uint16_t* etile = etiles + wave * 64 * ET_PITCH;
+    uint16_t* etile = etiles + wave * 32 * ET_PITCH;
     for (int idx = tid; idx < KD * RP; idx += 256) {
         const int k = idx / RP, m = idx % RP;
         const float w = a.W[(bh * KD + k) * RP + m];
@@ -972,25 +972,26 @@ __global__ __launch_bounds__(256, 2) void k_qpass_kernel(QpArgs a) {
     if (tile_lo + wave < tile_hi) load_tile(tile_lo + wave);
 #pragma unroll 1
     for (int tile = tile_lo + wave; tile < tile_hi; tile += 4) {
-        // ---- E tile -> LDS (row = token)
+        // ---- E half tile (32 tokens) -> LDS (row = token) -> matrix cores, twice
         const uint32_t D[4] = {(mk.x & 0xFFFFu) | (mk.z << 16), (mk.x >> 16) | (mk.z & 0xFFFF0000u),
                                (mk.y & 0xFFFFu) | (mk.w << 16), (mk.y >> 16) | (mk.w & 0xFFFF0000u)};
 #pragma unroll
-        for (int tk = 0; tk < 64; tk++) {
-            const int gi = tk / G;
-            const int qa = (int)((cw[0][tk / CPW] >> (BITS * (tk % CPW))) & CMASK), qb = (int)((cw[1][tk / CPW] >> (BITS * (tk % CPW))) & CMASK);
-            const float da = dequant_one<MODE>(qa, sc[0][gi], zp[0][gi]), db = dequant_one<MODE>(qb, sc[1][gi], zp[1][gi]);
-            const uint32_t dw = (uint32_t)f2h_bits(da) | ((uint32_t)f2h_bits(db) << 16);
-            uint32_t e2;
-            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tk]), "v"(dw));
-            ((uint32_t*)(etile + tk * ET_PITCH))[lane] = vbfi(mask_of(D[tk >> 4], tk & 15), 0u, e2);
-        }
-        if (tile + 4 < tile_hi) load_tile(tile + 4);      // the next tile's loads fly during the matrix-core phase
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
         for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int t2 = 0; t2 < 32; t2++) {
+                const int tk = 32 * half + t2;
+                const int gi = tk / G;
+                const int qa = (int)((cw[0][tk / CPW] >> (BITS * (tk % CPW))) & CMASK), qb = (int)((cw[1][tk / CPW] >> (BITS * (tk % CPW))) & CMASK);
+                const float da = dequant_one<MODE>(qa, sc[0][gi], zp[0][gi]), db = dequant_one<MODE>(qb, sc[1][gi], zp[1][gi]);
+                const uint32_t dw = (uint32_t)f2h_bits(da) | ((uint32_t)f2h_bits(db) << 16);
+                uint32_t e2;
+                asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tk]), "v"(dw));
+                ((uint32_t*)(etile + t2 * ET_PITCH))[lane] = vbfi(mask_of(D[tk >> 4], tk & 15), 0u, e2);
+            }
+            if (half == 1 && tile + 4 < tile_hi) load_tile(tile + 4);      // the next tile's loads fly during the matrix-core phase
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float16_t acc;
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[q] = 0.0f;
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void k_qpass_kernel(QpArgs a) {
                     ah.u = *(const uint4*)&Ah[((2 * ks + kg) * RP + n) * 8];
                     al.u = *(const uint4*)&Al[((2 * ks + kg) * RP + n) * 8];
                 }
-                b.u = *(const uint4*)(etile + (32 * half + n) * ET_PITCH + 16 * ks + 8 * kg);
+                b.u = *(const uint4*)(etile + n * ET_PITCH + 16 * ks + 8 * kg);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, acc, 0, 0, 0);
             }
@@ -1022,8 +1023,8 @@ __global__ __launch_bounds__(256, 2) void k_qpass_kernel(QpArgs a) {
                         if (c0 + i < a.r) a.Q[(bh * (int64_t)a.q_tcap + a.q_toff + token) * a.r + c0 + i] = f2h_bits(acc[4 * qb + i]);
                 }
             }
+            __builtin_amdgcn_wave_barrier();              // the half tile is read before it is overwritten
         }
-        __builtin_amdgcn_wave_barrier();                  // the tile is read before the next one overwrites it
     }
 }
 
@@ -1031,7 +1032,7 @@ template <int BITS, int MODE, int G, typename ST>
 void launch_qpass(const QpArgs& a, int64_t BH, int RP, hipStream_t st) {
     const int ntiles = a.T / 64;
     const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)BH);
-    const size_t shmem = (size_t)4 * 64 * ET_PITCH * 2 + (size_t)2 * 16 * RP * 8 * 2;
+    const size_t shmem = (size_t)4 * 32 * ET_PITCH * 2 + (size_t)2 * 16 * RP * 8 * 2;
 #define KQ_GO(RPV)                                                                                                     \
     do {                                                                                                               \
         auto kfn = k_qpass_kernel<BITS, MODE, G, ST, RPV>;                                                             \
