@@ -899,10 +899,11 @@ __global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict
 // 2 bits) and the outlier bitmap, rebuilds E = x - fp16(dequant), 0 at the outliers (the same arithmetic, so the same bits),
 // puts the tile into LDS and multiplies by W on the matrix cores like lr_qpass_tm_mfma_kernel (W as fp16 head + remainder).
 // ~10 VALU instructions per element pair against 2 bytes per element written by k_main_kernel and read back here.
+constexpr int QP_TPW = 16;    // tiles per workgroup of the recomputing Q pass
 struct QpArgs {
     const uint16_t* x;       // [BH][T][128]
     const uint32_t* obits;   // [BH][T/64][128][2] or null
-    int T, tiles_per_wg;
+    int T;
     const uint32_t* code;    // as MainArgs
     const void* scale;
     const void* mn;
@@ -924,6 +925,7 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
     uint16_t* etiles = (uint16_t*)smem;                                   // [4][32][ET_PITCH]: half a tile per wave at a time
     uint16_t* Ah = etiles + 4 * 32 * ET_PITCH;                            // [16][RP][8]: W as fp16, [k / 8][m][k % 8]
     uint16_t* Al = Ah + 16 * RP * 8;                                      // w - fp16(w)
+    ST* smz = (ST*)(Al + 16 * RP * 8);                                    // [2][128][QP_TPW * NG]: scale, mn of the workgroup's tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t bh = blockIdx.y;
@@ -937,10 +939,19 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
         Ah[pos] = hi;
         Al[pos] = f2h_bits(w - h2f_bits(hi));
     }
+    const int tile_lo = blockIdx.x * QP_TPW, tile_hi = min(ntiles, tile_lo + QP_TPW);
+    // scale / mn of the workgroup's tiles through LDS, read once as whole sectors: fetched per tile they are 4 bytes per channel
+    // row at a 256-byte pitch, and the x stream turns the L2 over in microseconds -- every one of those reads then cost a
+    // 64-byte sector from HBM (1 GB per launch instead of 0.07)
+    {
+        constexpr int NV = QP_TPW * NG;                                   // values per (array, channel)
+        const int arr = tid >> 7, ch = tid & 127;
+        const ST* src = (const ST*)(arr ? a.mn : a.scale) + (bh * KD + ch) * a.lds + (a.t_off + tile_lo * 64) / G;
+        const int nv = (tile_hi - tile_lo) * NG;
+#pragma unroll
+        for (int i = 0; i < NV; i++) smz[(arr * KD + ch) * NV + i] = i < nv ? src[i] : (ST)0;
+    }
     __syncthreads();
-    const int tile_lo = blockIdx.x * a.tiles_per_wg, tile_hi = min(ntiles, tile_lo + a.tiles_per_wg);
-    const ST* srow = (const ST*)a.scale + (bh * KD + 2 * lane) * a.lds;
-    const ST* mrow = (const ST*)a.mn + (bh * KD + 2 * lane) * a.lds;
     const uint32_t* crow = a.code + (bh * KD + 2 * lane) * a.ldc;
 
     uint32_t xr[64], cw[2][NW];
@@ -962,8 +973,8 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
             }
 #pragma unroll
             for (int gi = 0; gi < NG; gi++) {
-                sc[h][gi] = ld_st<ST>(srow + h * a.lds + tok / G + gi);
-                zp[h][gi] = ld_st<ST>(mrow + h * a.lds + tok / G + gi);
+                sc[h][gi] = ld_st<ST>(smz + (2 * lane + h) * (QP_TPW * NG) + (tile - tile_lo) * NG + gi);
+                zp[h][gi] = ld_st<ST>(smz + (KD + 2 * lane + h) * (QP_TPW * NG) + (tile - tile_lo) * NG + gi);
             }
         }
     };
@@ -1031,8 +1042,8 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
 template <int BITS, int MODE, int G, typename ST>
 void launch_qpass(const QpArgs& a, int64_t BH, int RP, hipStream_t st) {
     const int ntiles = a.T / 64;
-    const dim3 grid((unsigned)((ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg), (unsigned)BH);
-    const size_t shmem = (size_t)4 * 32 * ET_PITCH * 2 + (size_t)2 * 16 * RP * 8 * 2;
+    const dim3 grid((unsigned)((ntiles + QP_TPW - 1) / QP_TPW), (unsigned)BH);
+    const size_t shmem = (size_t)4 * 32 * ET_PITCH * 2 + (size_t)2 * 16 * RP * 8 * 2 + (size_t)2 * KD * QP_TPW * (64 / G) * sizeof(ST);
 #define KQ_GO(RPV)                                                                                                     \
     do {                                                                                                               \
         auto kfn = k_qpass_kernel<BITS, MODE, G, ST, RPV>;                                                             \
@@ -1210,7 +1221,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
 #undef KF_SOLVE
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
         QpArgs qa;
-        qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T; qa.tiles_per_wg = 16;
+        qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T;
         qa.code = (const uint32_t*)code; qa.scale = scale; qa.mn = mn; qa.ldc = ldc; qa.lds = lds; qa.t_off = t_off;
         qa.W = Wws; qa.r = rank; qa.Q = (uint16_t*)Q_out; qa.q_tcap = q_tcap; qa.q_toff = q_toff;
 #define KQ_DISPATCH(B, M, GG, STT) launch_qpass<B, M, GG, STT>(qa, BH, RP, st)
