@@ -752,15 +752,31 @@ __device__ __forceinline__ void gram_tile(const uint16_t* etile, int lane, float
 }
 
 template <int W>
-__device__ __forceinline__ void gram_store(float* __restrict__ gp, int lane, const float16_t (&acc)[3]) {
+__device__ __forceinline__ void gram_store(float* __restrict__ gp, int lane, const float16_t (&acc)[3], float* __restrict__ scratch) {
     typedef WaveBlocks<W> WB;
     const int x31 = lane & 31, kg = lane >> 5;
     // C layout of the 32x32 MFMA: lane l, reg q -> row (q & 3) + 8 (q >> 2) + 4 (l >> 5), col l & 31
 #pragma unroll
-    for (int b = 0; b < WB::n; b++)
+    for (int b = 0; b < WB::n; b++) {
 #pragma unroll
         for (int q = 0; q < 16; q++)
             gp[(32 * WB::I[b] + (q & 3) + 8 * (q >> 2) + 4 * kg) * KD + 32 * WB::J[b] + x31] = acc[b][q];
+        if (WB::I[b] != WB::J[b]) {
+            // the mirrored block G(J, I) = G(I, J)^T, transposed through LDS (scratch [32][33] floats of this wave) so that it is
+            // stored as rows too: the solve then reads whole rows of G and never a column
+#pragma unroll
+            for (int q = 0; q < 16; q++) scratch[((q & 3) + 8 * (q >> 2) + 4 * kg) * 33 + x31] = acc[b][q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = 2 * q + kg;                       // row of the mirrored block = column of the block
+                gp[(32 * WB::J[b] + row) * KD + 32 * WB::I[b] + x31] = scratch[x31 * 33 + row];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 // grid (nslab, BH), 256 threads = 4 waves.  A round = 4 tiles of the slab, one per wave: the wave quantizes its tile
@@ -855,41 +871,50 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
     }
     if (!LR) return;
     float* gp = a.gpart + (bh * a.nslab + slab) * (int64_t)(KD * KD);
-    if (wave == 0) gram_store<0>(gp, lane, acc);
-    else if (wave == 1) gram_store<1>(gp, lane, acc);
-    else if (wave == 2) gram_store<2>(gp, lane, acc);
-    else gram_store<3>(gp, lane, acc);
+    float* scratch = (float*)etile;                  // (this wave's error tile is dead: the last round's barrier has passed)
+    if (wave == 0) gram_store<0>(gp, lane, acc, scratch);
+    else if (wave == 1) gram_store<1>(gp, lane, acc, scratch);
+    else if (wave == 2) gram_store<2>(gp, lane, acc, scratch);
+    else gram_store<3>(gp, lane, acc, scratch);
 }
 
 // ================================================================================================ solve
 // grid (BH): G = sum of the slabs' partial Gram matrices, then the solve of lowrank_solve.h.
 // P_out head bh lives at (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * r elements.
 template <int RP>
-__global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict__ gpart, int nslab, int loop,
+__global__ __launch_bounds__(256, 3) void k_solve_kernel(const float* __restrict__ gpart, int nslab, int loop,
                                                          const float* __restrict__ P0, int r, float* __restrict__ Wout,
                                                          void* __restrict__ P_out, int out_f16, int64_t p_inner,
                                                          int64_t p_outer_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* G = (float*)smem;
-    float* Pa = (float*)(smem + GS_GD * GS_GP * 4);
+    float* Pa = (float*)smem;
     float* Pb = Pa + GS_GD * RP;
     double* Md = (double*)(Pb + GS_GD * RP);
     double* Rinv = Md + RP * RP;
     const int64_t bh = blockIdx.x;
     const int tid = threadIdx.x;
     const float* gp = gpart + bh * nslab * (int64_t)(KD * KD);
-    for (int idx = tid; idx < KD * KD; idx += 256) {
-        const int row = idx >> 7, col = idx & 127;
-        if ((col >> 5) >= (row >> 5)) {
-            float v = 0.0f;
-            for (int s = 0; s < nslab; s++) v += gp[s * (int64_t)(KD * KD) + idx];
-            G[row * GS_GP + col] = v;
+    // thread (d = tid / 2, h = tid & 1): columns e(i) = (i & 31) + 64 (i >> 5) + 32 h of row d, summed over the slabs (the partial
+    // matrices are complete: k_main_kernel stores the mirrored blocks too)
+    float greg[64];
+    {
+        const int d = tid >> 1, h = tid & 1;
+#pragma unroll
+        for (int i = 0; i < 64; i++) greg[i] = 0.0f;
+        for (int s = 0; s < nslab; s++) {
+            const float4* r0 = (const float4*)(gp + s * (int64_t)(KD * KD) + d * KD + 32 * h);
+            const float4* r1 = r0 + 16;                       // + 64 columns
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                const float4 a = r0[v], b = r1[v];
+                greg[4 * v] += a.x; greg[4 * v + 1] += a.y; greg[4 * v + 2] += a.z; greg[4 * v + 3] += a.w;
+                greg[32 + 4 * v] += b.x; greg[32 + 4 * v + 1] += b.y; greg[32 + 4 * v + 2] += b.z; greg[32 + 4 * v + 3] += b.w;
+            }
         }
     }
-    __syncthreads();
     const int64_t po = (bh / p_inner) * p_outer_stride + (bh % p_inner) * (int64_t)(KD * r);
-    gram_solve_phase2<RP>(G, Pa, Pb, Md, Rinv, P0 + bh * KD * r, r, loop, Wout + bh * KD * RP,
-                          out_f16 ? (void*)((uint16_t*)P_out + po) : (void*)((float*)P_out + po), out_f16);
+    gram_solve_phase2<RP, true>(nullptr, Pa, Pb, Md, Rinv, P0 + bh * KD * r, r, loop, Wout + bh * KD * RP,
+                                out_f16 ? (void*)((uint16_t*)P_out + po) : (void*)((float*)P_out + po), out_f16, greg);
 }
 
 
@@ -1209,7 +1234,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     if (rank > 0) {
         const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
         const int of16 = 1;
-        const size_t shmem = gram_solve_lds_bytes(RP);
+        const size_t shmem = gram_solve_lds_bytes(RP) - (size_t)GS_GD * GS_GP * 4;      // no G in LDS: it lives in registers
 #define KF_SOLVE(RPV)                                                                                                    \
         do {                                                                                                             \
             auto kfn = k_solve_kernel<RPV>;                                                                              \

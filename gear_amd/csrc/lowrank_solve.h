@@ -19,11 +19,15 @@ __host__ __device__ constexpr size_t gram_solve_lds_bytes(int RP) {
 }
 
 // Wout: fp32 [128][RP] of this head.  P_out: this head's [128][r] block (fp16 or fp32).
-template <int RP>
+// GREG: the thread's 64 values of G (row d = tid / 2, columns e(i) = (i & 31) + 64 (i >> 5) + 32 (tid & 1), i = 0..63, i.e. two
+// runs of 32 consecutive columns) are passed in registers and G in LDS is not used: 10 KB of LDS per workgroup instead of 76,
+// so all 1024 heads of a 32-layer call are resident at once instead of two rounds of 512.
+template <int RP, bool GREG = false>
 __device__ __forceinline__ void gram_solve_phase2(float* __restrict__ G, float* __restrict__ Pa, float* __restrict__ Pb,
                                                   double* __restrict__ Md, double* __restrict__ Rinv,
                                                   const float* __restrict__ P0h, int r, int loop,
-                                                  float* __restrict__ Wout, void* __restrict__ P_out, int out_f16) {
+                                                  float* __restrict__ Wout, void* __restrict__ P_out, int out_f16,
+                                                  const float* greg = nullptr) {
     constexpr int GD = GS_GD, GP = GS_GP;
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < GD * RP; i += 256) {
@@ -40,10 +44,10 @@ __device__ __forceinline__ void gram_solve_phase2(float* __restrict__ G, float* 
         float acc[RP];
 #pragma unroll
         for (int c = 0; c < RP; c++) acc[c] = 0.0f;
-#pragma unroll 4
+#pragma unroll
         for (int i = 0; i < 64; i++) {
             const int e = (i & 31) + 64 * (i >> 5) + 32 * h;
-            const float g = (e < dlow) ? G[e * GP + d] : G[d * GP + e];
+            const float g = GREG ? greg[i] : ((e < dlow) ? G[e * GP + d] : G[d * GP + e]);
 #pragma unroll
             for (int c4 = 0; c4 < RP; c4 += 4) {
                 const float4 xv = *(const float4*)&X[e * RP + c4];
