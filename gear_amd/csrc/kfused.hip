@@ -157,15 +157,17 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     // ---------------------------------------------------------------- phase A: sample statistics -> threshold guess
     {
         float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
-        for (int i0 = 0; i0 < per_stream; i0 += 8 * a.sstride) {      // 8 sampled tokens per trip: their loads fly together
-            uint32_t w[8];
+        constexpr int KS_A = 32;      // sampled tokens per trip: their loads fly together (8 per trip made this phase 8 dependent
+                                      // round trips per workgroup: 104 us of the kernel for a quarter of its bytes)
+        for (int i0 = 0; i0 < per_stream; i0 += KS_A * a.sstride) {
+            uint32_t w[KS_A];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < KS_A; j++) {
                 const int i = i0 + j * a.sstride, t = s + 16 * i;
                 w[j] = (i < per_stream && t < T) ? xw[(int64_t)t * 64] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < KS_A; j++) {
                 const float f0 = h2f_bits((uint16_t)(w[j] & 0xFFFFu)), f1 = h2f_bits((uint16_t)(w[j] >> 16));
                 s1a += f0; s2a = fmaf(f0, f0, s2a);
                 s1b += f1; s2b = fmaf(f1, f1, s2b);
