@@ -44,10 +44,8 @@ __device__ __forceinline__ void gram_solve_phase2(float* __restrict__ G, float* 
         float acc[RP];
 #pragma unroll
         for (int c = 0; c < RP; c++) acc[c] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
+        auto step = [&](int i, float g) {
             const int e = (i & 31) + 64 * (i >> 5) + 32 * h;
-            const float g = GREG ? greg[i] : ((e < dlow) ? G[e * GP + d] : G[d * GP + e]);
 #pragma unroll
             for (int c4 = 0; c4 < RP; c4 += 4) {
                 const float4 xv = *(const float4*)&X[e * RP + c4];
@@ -55,6 +53,16 @@ __device__ __forceinline__ void gram_solve_phase2(float* __restrict__ G, float* 
                 acc[c4 + 1] = fmaf(g, xv.y, acc[c4 + 1]);
                 acc[c4 + 2] = fmaf(g, xv.z, acc[c4 + 2]);
                 acc[c4 + 3] = fmaf(g, xv.w, acc[c4 + 3]);
+            }
+        };
+        if (GREG) {     // (fully unrolled: the register array needs compile-time indices)
+#pragma unroll
+            for (int i = 0; i < 64; i++) step(i, greg[i]);
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < 64; i++) {
+                const int e = (i & 31) + 64 * (i >> 5) + 32 * h;
+                step(i, (e < dlow) ? G[e * GP + d] : G[d * GP + e]);
             }
         }
 #pragma unroll
