@@ -403,100 +403,87 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     }
 }
 
-// The lists k_select_kernel could not decide: exact selection over the channel's whole column, one wave per list.  Bisection
-// on the 16-bit order key (17 rounds), then one pass in token order that takes everything above the threshold value plus the
-// first `need` ties, writes the sorted list and ORs the bits into the channel's bitmap.  T <= 4096: the column's keys are
-// gathered once into registers; longer columns are re-read every round (they come from L2).
+// The lists k_select_kernel could not decide (a handful per launch on ordinary data, all of them with option kselect_slow):
+// exact selection over the channel's whole column, one WORKGROUP per list -- the kernel's duration is the latency of one list,
+// so the list is spread over 256 threads (one wave per list took 75 us for 5 lists).  The column's order keys go to LDS once;
+// bisection on the 16-bit key (17 rounds: per-thread count over its keys, wave reduction, one LDS atomic per wave, one barrier);
+// then one pass in token order (thread = a contiguous run of tokens, block scan of the per-thread counts) that takes everything
+// above the threshold value plus the first `need` ties, writes the sorted list and ORs the bits into the channel's bitmap.
 __global__ __launch_bounds__(256) void k_select_fix_kernel(SelArgs a) {
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) uint32_t fkeys[];      // [T] order keys + 1 (0 = beyond T)
+    __shared__ int fcnt[2];
+    __shared__ uint32_t fscan[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntodo = *a.todo_cnt;
     const int T = a.T, k = a.k, ntiles = (T + 63) >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < ntodo; w += gridDim.x * 4) {
+    const int per = (T + 255) >> 8;                                   // tokens per thread in the ordered pass
+    for (uint32_t w = blockIdx.x; w < ntodo; w += gridDim.x) {
         const uint32_t e = a.todo[w];
         const int side = e & 1, ch = (e >> 1) & 127;
         const int64_t bh = e >> 8;
         const uint16_t* xc = a.x + bh * (int64_t)T * KD + ch;       // + t * 128
         const int64_t lbase = ((bh * KD + ch) * 2 + (side == 0 ? 1 : 0)) * (int64_t)a.kcap + a.o_off;
         uint32_t* ob = a.obits + ((bh * ntiles) * KD + ch) * 2;     // + tile * 256 words
-        if (T <= 4096) {
-            uint32_t kv[64];
+        __syncthreads();                                             // (the previous list's keys are dead)
+        for (int t = tid; t < per * 256; t += 256) fkeys[t] = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+        if (tid == 0) { fcnt[0] = 0; fcnt[1] = 0; }
+        __syncthreads();
+        auto count_ge = [&](uint32_t thr, int slot) {               // block-wide #{keys >= thr}; fcnt[slot] must be 0 on entry
+            int c = 0;
+            for (int t = tid; t < per * 256; t += 256) c += (fkeys[t] >= thr) ? 1 : 0;
 #pragma unroll
-            for (int i = 0; i < 64; i++) {
-                const int t = 64 * i + lane;
-                kv[i] = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+            if (lane == 0) atomicAdd(&fcnt[slot], c);
+            if (tid == 0) fcnt[slot ^ 1] = 0;                        // the other slot is free: ready for the next call
+            __syncthreads();
+            const int tot = fcnt[slot];
+            return tot;
+        };
+        uint32_t lo_b = 1u, hi_b = 0x10000u;
+        int slot = 0;
+        for (int it = 0; it < 17; it++) {
+            const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+            const int c = count_ge(mid, slot);
+            slot ^= 1;
+            if (c >= k) lo_b = mid; else hi_b = mid - 1u;
+        }
+        const uint32_t vstar = lo_b;
+        const int need = k - count_ge(vstar + 1u, slot);             // how many of the ties at the threshold value are taken
+        slot ^= 1;
+        // ordered pass: thread tid owns tokens [tid * per, (tid + 1) * per)
+        int n_gt = 0, n_eq = 0;
+        for (int i = 0; i < per; i++) {
+            const uint32_t kk = fkeys[tid * per + i];
+            n_gt += (kk > vstar) ? 1 : 0;
+            n_eq += (kk == vstar) ? 1 : 0;
+        }
+        // block exclusive scan of (n_gt, n_eq) packed 16 + 16 bits (each total <= T <= 16384)
+        const uint32_t mine = (uint32_t)n_gt | ((uint32_t)n_eq << 16);
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (lane == 63) fscan[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int q = 0; q < wave; q++) base += fscan[q];
+        const uint32_t excl = base + incl - mine;
+        const int gt_before = (int)(excl & 0xFFFFu), eq_before = (int)(excl >> 16);
+        int take_eq = need - eq_before;                               // ties this thread still takes (its first ones)
+        take_eq = take_eq < 0 ? 0 : (take_eq > n_eq ? n_eq : take_eq);
+        int pos = gt_before + (eq_before < need ? eq_before : need);
+        uint32_t bits = 0u;
+        for (int i = 0; i < per; i++) {
+            const int t = tid * per + i;
+            const uint32_t kk = fkeys[t];
+            bool sel = kk > vstar;
+            if (kk == vstar && take_eq > 0) { sel = true; take_eq--; }
+            if (sel) {
+                a.oidx[lbase + pos] = (uint16_t)(t + a.tok_base);
+                a.oval[lbase + pos] = xc[(int64_t)t * KD];
+                pos++;
+                bits |= 1u << (t & 31);
             }
-            uint32_t lo_b = 1u, hi_b = 0x10000u;
-            for (int it = 0; it < 17; it++) {
-                const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
-                int c = 0;
-#pragma unroll
-                for (int i = 0; i < 64; i++) c += (kv[i] >= mid) ? 1 : 0;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-                if (c >= k) lo_b = mid; else hi_b = mid - 1u;
-            }
-            const uint32_t vstar = lo_b;
-            int above = 0;
-#pragma unroll
-            for (int i = 0; i < 64; i++) above += (kv[i] > vstar) ? 1 : 0;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) above += __shfl_xor(above, d, 64);
-            const int need = k - above;
-            int taken = 0, pos = 0;
-#pragma unroll
-            for (int i = 0; i < 64; i++) {
-                if (64 * i < T) {
-                    const bool eq = kv[i] == vstar;
-                    const unsigned long long be = __ballot(eq);
-                    const bool sl_ = kv[i] > vstar || (eq && taken + __popcll(be & lt) < need);
-                    const unsigned long long bs = __ballot(sl_);
-                    if (sl_) {
-                        const int t = 64 * i + lane, r = pos + __popcll(bs & lt);
-                        a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
-                        a.oval[lbase + r] = xc[(int64_t)t * KD];
-                    }
-                    if (bs && lane < 2) atomicOr(&ob[i * (KD * 2) + lane], lane ? (uint32_t)(bs >> 32) : (uint32_t)bs);
-                    taken += __popcll(be);
-                    pos += __popcll(bs);
-                }
-            }
-        } else {
-            uint32_t lo_b = 1u, hi_b = 0x10000u;
-            for (int it = 0; it < 17; it++) {
-                const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
-                int c = 0;
-                for (int tb = 0; tb < T; tb += 64) {
-                    const int t = tb + lane;
-                    const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
-                    c += __popcll(__ballot(kk >= mid));
-                }
-                if (c >= k) lo_b = mid; else hi_b = mid - 1u;
-            }
-            const uint32_t vstar = lo_b;
-            int above = 0;
-            for (int tb = 0; tb < T; tb += 64) {
-                const int t = tb + lane;
-                const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
-                above += __popcll(__ballot(kk > vstar));
-            }
-            const int need = k - above;
-            int taken = 0, pos = 0;
-            for (int tb = 0; tb < T; tb += 64) {
-                const int t = tb + lane;
-                const uint32_t kk = (t < T) ? order_key(xc[(int64_t)t * KD], side) + 1u : 0u;
-                const bool eq = kk == vstar;
-                const unsigned long long be = __ballot(eq);
-                const bool sl_ = kk > vstar || (eq && taken + __popcll(be & lt) < need);
-                const unsigned long long bs = __ballot(sl_);
-                if (sl_) {
-                    const int r = pos + __popcll(bs & lt);
-                    a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
-                    a.oval[lbase + r] = xc[(int64_t)t * KD];
-                }
-                if (bs && lane < 2) atomicOr(&ob[(tb >> 6) * (KD * 2) + lane], lane ? (uint32_t)(bs >> 32) : (uint32_t)bs);
-                taken += __popcll(be);
-                pos += __popcll(bs);
+            if (((t & 31) == 31 || i == per - 1) && bits) {           // the 32-token word ends here (or the thread's run does)
+                atomicOr(&ob[(t >> 6) * (KD * 2) + ((t >> 5) & 1)], bits);
+                bits = 0u;
             }
         }
     }
@@ -1224,8 +1211,8 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         const size_t shmem = ((size_t)64 * KS_STRIDE + 128 + scr_words) * 4;
         hipLaunchKernelGGL(k_select_kernel, dim3((unsigned)(4 * BH)), dim3(256), shmem, st, sa);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(select)");
-        const unsigned fix_grid = (unsigned)(BH * 64 < 1024 ? BH * 64 : 1024);   // waves loop over the to-do list
-        hipLaunchKernelGGL(k_select_fix_kernel, dim3(fix_grid), dim3(256), 0, st, sa);
+        const unsigned fix_grid = (unsigned)(BH * 256 < 2048 ? BH * 256 : 2048);   // workgroups loop over the to-do list
+        hipLaunchKernelGGL(k_select_fix_kernel, dim3(fix_grid), dim3(256), (size_t)((T + 255) / 256 * 256) * 4, st, sa);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(select fix)");
         if (variant & 32) return 0;
     }
