@@ -325,9 +325,10 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     __syncthreads();
     // ---------------------------------------------------------------- phase C.2: outputs, one wave per channel
     const int nwords = (T + 31) >> 5;
-    uint32_t* bmA = scr + wave * 3 * nwords;       // side 0 (large) bitmap of the current channel
+    uint32_t* bmA = scr + wave * 4 * nwords;       // side 0 (large) bitmap of the current channel
     uint32_t* bmB = bmA + nwords;                  // side 1 (small)
-    uint32_t* pfx = bmB + nwords;                  // exclusive prefix popcount per word (one side at a time)
+    uint32_t* pfxA = bmB + nwords;                 // exclusive prefix popcount per word, side 0
+    uint32_t* pfxB = pfxA + nwords;                //                                     side 1
     const int wpl = (nwords + 63) >> 6;            // bitmap words per lane
     for (int lch = wave; lch < 32; lch += 4) {
         const int ch = 32 * q + lch;
@@ -337,58 +338,68 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        // both sides of the channel move through the stages together (mark -> prefix -> emit): three LDS round trips per channel
+        // instead of six, the two sides' loads and atomics in flight at the same time
+        uint32_t cv[2][3];                                            // candidate (bits << 16 | t)
+        bool sel[2][3], fast[2];
+#pragma unroll
         for (int side = 0; side < 2; side++) {
             uint32_t* bm = side == 0 ? bmA : bmB;
             const int list = lch * 2 + side;
             const int n = __builtin_amdgcn_readfirstlane((int)cnt[list]);
             const uint32_t kt = (uint32_t)__builtin_amdgcn_readfirstlane((int)kthr[list]);
-            const bool fast = kt != 0u;
-            uint32_t cv[3] = {0u, 0u, 0u};                           // candidate (bits << 16 | t)
-            bool sel[3] = {false, false, false};
-            if (fast) {
+            fast[side] = kt != 0u;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int g = lane + 64 * i;
-                    if (g < n) {
-                        cv[i] = cand[list * KS_STRIDE + g];
-                        const uint32_t kx = ((order_key(cv[i] >> 16, side) << 14) | (0x3FFFu - (cv[i] & 0x3FFFu))) + 1u;
-                        sel[i] = kx >= kt;
-                        if (sel[i]) atomicOr(&bm[(cv[i] & 0xFFFFu) >> 5], 1u << (cv[i] & 31u));
-                    }
+            for (int i = 0; i < 3; i++) {
+                cv[side][i] = 0u;
+                sel[side][i] = false;
+                const int g = lane + 64 * i;
+                if (fast[side] && g < n) {
+                    cv[side][i] = cand[list * KS_STRIDE + g];
+                    const uint32_t kx = ((order_key(cv[side][i] >> 16, side) << 14) | (0x3FFFu - (cv[side][i] & 0x3FFFu))) + 1u;
+                    sel[side][i] = kx >= kt;
+                    if (sel[side][i]) atomicOr(&bm[(cv[side][i] & 0xFFFFu) >> 5], 1u << (cv[side][i] & 31u));
                 }
-            } else {
-                // threshold guess missed, list overflow or k beyond what the lists hold: this (channel, side) goes to the exact
-                // slow selection of k_select_fix_kernel (which also ORs its bits into the channel's bitmap)
-                if (lane == 0) a.todo[atomicAdd(a.todo_cnt, 1u)] = (uint32_t)((bh * KD + ch) * 2 + side);
-                continue;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // exclusive prefix popcount per bitmap word -> rank of a selected token = its position in the sorted list
-            uint32_t c = 0u;
+            // threshold guess missed, list overflow or k beyond what the lists hold: this (channel, side) goes to the exact
+            // slow selection of k_select_fix_kernel (which also ORs its bits into the channel's bitmap)
+            if (!fast[side] && lane == 0) a.todo[atomicAdd(a.todo_cnt, 1u)] = (uint32_t)((bh * KD + ch) * 2 + side);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // exclusive prefix popcount per bitmap word -> rank of a selected token = its position in the sorted list
+        {
+            uint32_t c = 0u;                                          // side 0 in the low half, side 1 in the high half
             for (int i = 0; i < wpl; i++) {
                 const int w = lane * wpl + i;
-                if (w < nwords) c += (uint32_t)__popc(bm[w]);
+                if (w < nwords) c += (uint32_t)__popc(bmA[w]) | ((uint32_t)__popc(bmB[w]) << 16);
             }
             uint32_t base = wave_incl_scan_u32(c) - c;
             for (int i = 0; i < wpl; i++) {
                 const int w = lane * wpl + i;
-                if (w < nwords) { pfx[w] = base; base += (uint32_t)__popc(bm[w]); }
+                if (w < nwords) {
+                    pfxA[w] = base & 0xFFFFu;
+                    pfxB[w] = base >> 16;
+                    base += (uint32_t)__popc(bmA[w]) | ((uint32_t)__popc(bmB[w]) << 16);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int64_t lbase = ((bh * KD + ch) * 2 + (side == 0 ? 1 : 0)) * (int64_t)a.kcap + a.o_off;
-            {
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    if (sel[i]) {
-                        const uint32_t t = cv[i] & 0xFFFFu;
-                        const uint32_t r = pfx[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
-                        a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
-                        a.oval[lbase + r] = (uint16_t)(cv[i] >> 16);
-                    }
+        for (int side = 0; side < 2; side++) {
+            const uint32_t* bm = side == 0 ? bmA : bmB;
+            const uint32_t* pfx = side == 0 ? pfxA : pfxB;
+            const int64_t lbase = ((bh * KD + ch) * 2 + (side == 0 ? 1 : 0)) * (int64_t)a.kcap + a.o_off;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                if (sel[side][i]) {
+                    const uint32_t t = cv[side][i] & 0xFFFFu;
+                    const uint32_t r = pfx[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
+                    a.oidx[lbase + r] = (uint16_t)(t + a.tok_base);
+                    a.oval[lbase + r] = (uint16_t)(cv[side][i] >> 16);
                 }
             }
         }
@@ -1207,7 +1218,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         sa.todo = sa.todo_cnt + 64;
         if (hipMemsetAsync(sa.todo_cnt, 0, 4, st) != hipSuccess) { gear_set_error("gear_compress_key_fused: memset failed"); return -2; }
         const int nwords = (T + 31) / 32;
-        const size_t scr_words = (size_t)max(max(16 * 16 * 4, 256 * KS_B), 4 * 3 * nwords);
+        const size_t scr_words = (size_t)max(max(16 * 16 * 4, 256 * KS_B), 4 * 4 * nwords);
         const size_t shmem = ((size_t)64 * KS_STRIDE + 128 + scr_words) * 4;
         hipLaunchKernelGGL(k_select_kernel, dim3((unsigned)(4 * BH)), dim3(256), shmem, st, sa);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(select)");
