@@ -86,10 +86,15 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         pf_r[q] = (g.k > 0 && e < fill_n) ? e / per_row_t : -1;
         pf_c[q] = (g.k > 0 && e < fill_n) ? e - pf_r[q] * per_row_t : 0;
     }
+    // Blocks walk their 16 rows in a rotated order (a multiple of the table period, by block index) so that blocks running in
+    // near lockstep do not all write at the same offset of their 128 KB regions (HBM channel camping, tools/ubench/
+    // store_pattern.hip; worth 2 % here)
+    const int rot = (g.rpb == 16 && row0 + 16 <= g.n_rows) ? 4 * (int)((blockIdx.x ^ (blockIdx.x >> 2)) & 3) : 0;
+    auto phys = [&](int ri) { return rot ? ((ri + rot) & 15) : ri; };
     auto prefetch_entries = [&](int rbase) {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            const int64_t row = row0 + rbase + pf_r[q];
+            const int64_t row = row0 + phys(rbase) + pf_r[q];
             pf_idx[q] = 0; pf_val[q] = 0;
             if (pf_r[q] >= 0 && row < g.n_rows && rbase < g.rpb) {
                 pf_idx[q] = oidx[row * per_row_t + pf_c[q]];
@@ -104,12 +109,12 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
         if (pf_ok) {
 #pragma unroll
             for (int q = 0; q < PF; q++)
-                if (pf_r[q] >= 0 && row0 + rbase + pf_r[q] < g.n_rows) lval[(size_t)pf_r[q] * g.len + pf_idx[q]] = pf_val[q];
+                if (pf_r[q] >= 0 && row0 + phys(rbase) + pf_r[q] < g.n_rows) lval[(size_t)pf_r[q] * g.len + pf_idx[q]] = pf_val[q];
             prefetch_entries(rbase + g.trows);
         } else {
             for (int e = tid; e < fill_n; e += blockDim.x) {
                 const int ri = e / per_row_t;
-                const int64_t row = row0 + rbase + ri;
+                const int64_t row = row0 + phys(rbase) + ri;
                 if (row < g.n_rows) lval[(size_t)ri * g.len + oidx[row * per_row_t + e % per_row_t]] = oval[row * per_row_t + e % per_row_t];
             }
         }
@@ -157,7 +162,8 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const uint16_t* fv0p = nullptr;
     if (RV > 0 && r > 0)
         fv0p = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin0) * r : P + ((int64_t)ro * g.D + rin0) * r;
-    auto fetch = [&](int ri, RowIn& in) {
+    auto fetch = [&](int li, RowIn& in) {
+        const int ri = phys(li);
         in.off = off0 + (int64_t)ri * g.inner_stride;
         const int64_t gi = gi0 + (int64_t)ri * gstep;
         in.s = ld_st<ST>(scale + gi);
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                     f[j] = acc;
                 }
             } else {
-                const int rin = rin0 + ri;
+                const int rin = rin0 + phys(ri);
                 const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r
                                                   : P + ((int64_t)ro * g.D + rin) * r;
                 float fv[16];
