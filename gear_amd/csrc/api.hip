@@ -29,6 +29,7 @@ GearOptions& gear_options() {
         v.lowrank_generic = flag("GEAR_LOWRANK_GENERIC");
         v.rows_hist_only = flag("GEAR_ROWS_HIST_ONLY");
         v.rows_v1 = flag("GEAR_ROWS_V1");
+        v.rows_wg_only = flag("GEAR_ROWS_WG_ONLY");
         v.kfused_generic = flag("GEAR_KFUSED_GENERIC");
         v.kselect_slow = flag("GEAR_KSELECT_SLOW");
         v.kfused_no_tr = flag("GEAR_KFUSED_NO_TR");
@@ -41,7 +42,7 @@ extern "C" int gear_set_option(const char* name, int value) {
     GearOptions& o = gear_options();
     const struct { const char* n; int* p; } tab[] = {
         {"attn_generic", &o.attn_generic},     {"lowrank_generic", &o.lowrank_generic}, {"rows_hist_only", &o.rows_hist_only},
-        {"rows_v1", &o.rows_v1},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
+        {"rows_v1", &o.rows_v1}, {"rows_wg_only", &o.rows_wg_only},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
         {"kfused_no_tr", &o.kfused_no_tr},
     };
     for (const auto& t : tab)

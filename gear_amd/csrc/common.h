@@ -35,6 +35,7 @@ struct GearOptions {
     int attn_generic;      // decode attention: the generic variable-chunk kernel instead of the 128-token-chunk one
     int lowrank_generic;   // power iteration: the generic multi-pass kernels instead of the Gram formulation
     int rows_hist_only;    // row compressor: always the radix-select (exact fallback) selection
+    int rows_wg_only;      // row compressor: never the wave-per-row kernel (the workgroup kernel for every row)
     int rows_v1;           // row compressor: first-generation kernel also for fp32 arithmetic (cross-check)
     int kfused_generic;    // fused K path: the element-by-element tile body instead of the packed one
     int kselect_slow;      // fused K path: always the exact slow selection (no candidate lists)

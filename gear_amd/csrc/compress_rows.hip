@@ -989,6 +989,421 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One lane's 16 consecutive elements of a row, after the selection: group min / max (with the mean fill), quantize, pack,
+// error -- the dense half of compress_rows_fp32_kernel as a function (same instructions, same bits), used by the
+// wave-per-row kernel below once per 1024-element chunk of the row.
+template <int BITS>
+__device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t (&m)[8], uint32_t outl, float mean, int group,
+                                        int group_shift, int lane, uint32_t* __restrict__ code_row, float* __restrict__ scale_row,
+                                        float* __restrict__ mn_row, uint32_t ooff, uint16_t* __restrict__ err_row, uint32_t loff) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int WPL = BITS / 2;
+    constexpr int CPW = 32 / BITS;
+    constexpr int HC = 16 / BITS;
+    // ---------------- group min / max over the elements that are not outliers (packed fp16 min/max are exact), plus the
+    // fill value (the fp32 row mean, compress_function.py:279-283 / :315-319) when the lane holds an outlier
+    uint32_t lo2, hi2;
+    {
+        const uint32_t PINF = 0x7C007C00u, NINF = 0xFC00FC00u;
+        lo2 = vbfi(m[0], PINF, rw[0]);
+        hi2 = vbfi(m[0], NINF, rw[0]);
+#pragma unroll
+        for (int w = 1; w < 8; w++) {
+            lo2 = pkmin16(lo2, vbfi(m[w], PINF, rw[w]));
+            hi2 = pkmax16(hi2, vbfi(m[w], NINF, rw[w]));
+        }
+    }
+    float lo = fmin_raw(h2f_bits((uint16_t)(lo2 & 0xFFFFu)), h2f_bits((uint16_t)(lo2 >> 16)));
+    float hi = fmax_raw(h2f_bits((uint16_t)(hi2 & 0xFFFFu)), h2f_bits((uint16_t)(hi2 >> 16)));
+    lo = fmin_raw(lo, outl ? mean : INFINITY);
+    hi = fmax_raw(hi, outl ? mean : -INFINITY);
+    const int lanes_per_group = group / 16;
+    if (lanes_per_group == 4) {   // the usual group of 64: the four lanes of a DPP quad
+        lo = fmin_raw(lo, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lo), 0xB1, 0xF, 0xF, true)));
+        hi = fmax_raw(hi, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hi), 0xB1, 0xF, 0xF, true)));
+        lo = fmin_raw(lo, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lo), 0x4E, 0xF, 0xF, true)));
+        hi = fmax_raw(hi, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hi), 0x4E, 0xF, 0xF, true)));
+    } else {
+        for (int mm = 1; mm < lanes_per_group; mm <<= 1) {
+            lo = fminf(lo, __shfl_xor(lo, mm, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, mm, 64));
+        }
+    }
+    const float qscale = div_rn(hi - lo, (float)LEVELS), qmn = lo;        // make_qparams<1>
+    // (v_rcp_f32 is within 1 ulp: far inside the 1e-5 tie guard below.)  Zero-range group: every code 0 (defect B6)
+    const float inv = (qscale != 0.0f) ? __builtin_amdgcn_rcpf(qscale) : 0.0f;
+    // ---------------- quantize: reciprocal multiply; a lane that sees a quotient within 1e-5 of a rounding tie (the only
+    // place where t * (1/s) and t / s can round differently; 1e-3 for 8-bit codes) redoes its elements by division
+    constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
+    float rq[16];
+    bool tie = false;
+    const float one = 1.0f, negmn = -qmn;
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float dmax = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        float2v t = {sub_mix<0>(rw[w], one, negmn), sub_mix<1>(rw[w], one, negmn)};
+        const float2v c = t * inv;                       // v_pk_mul_f32
+        float2v rr = {rintf(c.x), rintf(c.y)};
+        const float2v d = c - rr;                        // v_pk_add_f32
+        rq[2 * w] = rr.x;
+        rq[2 * w + 1] = rr.y;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
+    }
+    tie = dmax > TIE;
+    if (tie) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float xv = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+            rq[j] = (qscale != 0.0f) ? rintf(div_rn(xv - qmn, qscale)) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) rq[j] = __builtin_amdgcn_fmed3f(rq[j], 0.0f, (float)LEVELS);
+    // ---------------- pack: Horner chains in fp32 over the HC codes of each 16-bit half (exact: < 2^16)
+    // (even, odd) element pairs ride one v_pk_fma_f32: A = sum 4^BITS^i code[2i], B = the same over the odd elements,
+    // half word = A + 2^BITS B
+    uint32_t words[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; w++) {
+        uint32_t hw[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int e0 = w * CPW + hf * HC;
+            float2v ab = {rq[e0 + HC - 2], rq[e0 + HC - 1]};
+            const float2v base2 = {(float)(1 << (2 * BITS)), (float)(1 << (2 * BITS))};
+#pragma unroll
+            for (int i = HC / 2 - 2; i >= 0; i--) {
+                const float2v dg = {rq[e0 + 2 * i], rq[e0 + 2 * i + 1]};
+                ab = __builtin_elementwise_fma(ab, base2, dg);
+            }
+            hw[hf] = (uint32_t)fmaf(ab.y, (float)(1 << BITS), ab.x);
+        }
+        words[w] = hw[0] | (hw[1] << 16);
+    }
+    if (outl) {   // filled positions: every outlier of the group carries quant(mean)
+        const float cq = (mean - qmn) * inv;
+        float cm = rintf(cq);
+        if (fabsf(cq - cm) > TIE) cm = (qscale != 0.0f) ? rintf(div_rn(mean - qmn, qscale)) : 0.0f;
+        cm = __builtin_amdgcn_fmed3f(cm, 0.0f, (float)LEVELS);
+        const uint32_t qrep = (uint32_t)cm * (0xFFFFFFFFu / (uint32_t)LEVELS);
+#pragma unroll
+        for (int w = 0; w < WPL; w++) words[w] = bfi32(spread_flags<BITS>(outl >> (w * CPW)), qrep, words[w]);
+    }
+    uint32_t* cp = code_row + ooff / CPW;
+#pragma unroll
+    for (int w = 0; w < WPL; w++) cp[w] = words[w];
+    if ((lane & (lanes_per_group - 1)) == 0) {
+        scale_row[ooff >> group_shift] = qscale;
+        mn_row[ooff >> group_shift] = qmn;
+    }
+    if (err_row) {
+        // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
+        uint32_t ew[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const float d0 = __fadd_rn(__fmul_rn(rq[2 * w], qscale), qmn), d1 = __fadd_rn(__fmul_rn(rq[2 * w + 1], qscale), qmn);
+            const uint32_t dw = (uint32_t)f2h_bits(d0) | ((uint32_t)f2h_bits(d1) << 16);
+            uint32_t e2;   // x - d in packed fp16 (the optimiser otherwise negates d in fp32 first), outlier halves cleared
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rw[w]), "v"(dw));
+            ew[w] = vbfi(m[w], 0u, e2);
+        }
+        uint4* ep = (uint4*)(err_row + loff);
+        ep[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]);
+        ep[1] = make_uint4(ew[4], ew[5], ew[6], ew[7]);
+    }
+}
+
+// Wave-per-row variant for rows of exactly 1024 C elements (C = 1..4 chunks of 16 elements per lane): the same algorithm as
+// compress_rows_fp32_kernel's fast path -- Gaussian-guess thresholds validated by the survivor counts, candidates compacted
+// in index order, 17-round key bisection, dense part -- with ONE wave per row, so that the per-row machinery (row statistics,
+// prefix scans, the bisection and its outputs) runs once per row instead of once per 1024 elements and on all four waves of a
+// workgroup instead of two, and no workgroup barrier or cross-wave LDS traffic is left (four independent rows per workgroup).
+// A row whose guess fails (counts outside [k, 128] on a side) is marked by the impossible index 0xFFFF in its first list slot and
+// left to the SLOW instantiation of this kernel (exact in-wave selection over all of the row's elements), which is launched
+// behind the fast one over all rows and returns at once for every row that is not marked -- a separate instantiation, so that
+// the rare path's registers do not count against the common one.
+template <int BITS, int C, bool SLOW>
+__global__ __launch_bounds__(256, 4) void compress_rows_wave_kernel(const uint16_t* __restrict__ x, RowGeom gm, int64_t n_rows, int group,
+                                                                    int k, float zthr, float rlen, uint32_t* __restrict__ code,
+                                                                    float* __restrict__ scale, float* __restrict__ mn,
+                                                                    uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
+                                                                    uint16_t* __restrict__ oval, float* __restrict__ omean) {
+    constexpr int LEN = 1024 * C;
+    constexpr int CPW = 32 / BITS;
+    constexpr int WW = LEN / 2 + 256 + 2 * (LEN / 32);     // words of LDS per wave: row image | candidates [2][128] | outlier bits [2][LEN/32]
+    extern __shared__ __attribute__((aligned(16))) uint32_t wdyn[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;
+    if (SLOW && oidx[lrow_of(gm, r) * (int64_t)(2 * k)] != (uint16_t)0xFFFFu) return;      // (launched only with k > 0)
+    uint32_t* rowimg = wdyn + wave * WW;      // the raw row while candidates are emitted, then half-word outlier marks
+    uint32_t* cand = rowimg + LEN / 2;
+    uint32_t* omask = cand + 256;
+    uint32_t loff[C], ooff[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        int seg = 0, pos = 0;
+        seg_pos(gm, c * 1024 + lane * 16, seg, pos);
+        loff[c] = (uint32_t)seg * (uint32_t)gm.seg_stride + (uint32_t)pos;
+        ooff[c] = (uint32_t)seg * (uint32_t)gm.o_seg_stride + (uint32_t)pos;
+    }
+    const int64_t row_base = row_base_of(gm, r);
+    const uint16_t* xrow = x + row_base;
+    const int64_t orow_base = row_base_out(gm, r);
+    uint32_t* code_row = code + orow_base / CPW;
+    float* scale_row = scale + (orow_base >> gm.group_shift);
+    float* mn_row = mn + (orow_base >> gm.group_shift);
+    uint16_t* err_row = err ? err + row_base : nullptr;
+
+    uint4 ra[C], rb[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint4* p = (const uint4*)(xrow + loff[c]);
+        ra[c] = p[0];
+        rb[c] = p[1];
+    }
+    uint32_t flag[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) flag[c] = 0u;
+    float mean = 0.0f;
+    if (k > 0) {
+        const int64_t lrow = lrow_of(gm, r);
+        // ---------------- row sum / sum of squares (exact products, fp32 accumulate), one DPP reduction each
+        const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+        // (the workgroup kernel reduces each wave's 1024 elements first and adds the four wave sums as (w0 + w1) + (w2 + w3);
+        // chunk c here holds what wave c holds there, so the chunks are reduced one by one and added in the same order: the
+        // mean is the fill value and must come out with the same bits)
+        float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t rw[8] = {ra[c].x, ra[c].y, ra[c].z, ra[c].w, rb[c].x, rb[c].y, rb[c].z, rb[c].w};
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const half2v xv = __builtin_bit_cast(half2v, rw[w]);
+                s = __builtin_amdgcn_fdot2(xv, ones, s, false);
+                s2 = __builtin_amdgcn_fdot2(xv, xv, s2, false);
+            }
+            wsum[c] = wave_sum_dpp(s);
+        }
+        const float tot1 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), tot2 = wave_sum_dpp(s2);
+        mean = ((LEN & (LEN - 1)) == 0) ? tot1 * rlen : tot1 / (float)LEN;
+        bool ok = !SLOW && zthr > 0.0f;
+        uint32_t mh[C], ml[C], excl[C];
+        uint32_t nh = 0u, nl = 0u, bh[C], bl[C];
+        if (!SLOW && ok) {
+            const float sd = __builtin_amdgcn_sqrtf(fmaxf(tot2 * rlen - mean * mean, 0.0f));
+            const float thi = mean + zthr * sd, tlo = mean - zthr * sd;
+            const uint32_t th = f2h_bits(thi), tl = f2h_bits(tlo);
+            const half2v thi2 = __builtin_bit_cast(half2v, th | (th << 16)), tlo2 = __builtin_bit_cast(half2v, tl | (tl << 16));
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint32_t rw[8] = {ra[c].x, ra[c].y, ra[c].z, ra[c].w, rb[c].x, rb[c].y, rb[c].z, rb[c].w};
+                uint32_t sg_hi = 0u, sg_lo = 0u;
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    const half2v xv = __builtin_bit_cast(half2v, rw[w]);
+                    const uint32_t dh = __builtin_bit_cast(uint32_t, (half2v)(xv - thi2));
+                    const uint32_t dl = __builtin_bit_cast(uint32_t, (half2v)(tlo2 - xv));
+                    sg_hi |= (dh >> (15 - 2 * w)) & (0x00010001u << (2 * w));
+                    sg_lo |= (dl >> (15 - 2 * w)) & (0x00010001u << (2 * w));
+                }
+                *(uint4*)&rowimg[c * 512 + lane * 8] = ra[c];
+                *(uint4*)&rowimg[c * 512 + lane * 8 + 4] = rb[c];
+                mh[c] = ~(sg_hi | (sg_hi >> 15)) & 0xFFFFu;
+                ml[c] = ~(sg_lo | (sg_lo >> 15)) & 0xFFFFu;
+                const uint32_t cntp = (uint32_t)__popc(mh[c]) | ((uint32_t)__popc(ml[c]) << 16);
+                const uint32_t incl = wave_incl_scan_u32(cntp);
+                excl[c] = incl - cntp;
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                bh[c] = nh; bl[c] = nl;
+                nh += tot & 0xFFFFu;
+                nl += tot >> 16;
+            }
+            ok = nh >= (uint32_t)k && nl >= (uint32_t)k && nh <= 128u && nl <= 128u;
+        }
+        if (!SLOW && !ok) {
+            if (lane == 0) oidx[lrow * (int64_t)(2 * k)] = (uint16_t)0xFFFFu;      // left to the SLOW instantiation
+            return;
+        }
+        if constexpr (SLOW) {
+            // ---------------- the guess failed (heavy tails, few distinct values, constant rows ...): exact selection on the whole
+            // row inside the wave.  Per side: 17-round bisection on the order key over all 16 C elements of every lane, then, in
+            // index order (chunk, lane, element): everything above the threshold value plus the first `need` ties.  Lane-local
+            // except for the counts (DPP sums / prefix scans); rare, so it is written for size, not speed.
+            uint32_t selm[2][C];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                *(uint4*)&rowimg[c * 512 + lane * 8] = ra[c];
+                *(uint4*)&rowimg[c * 512 + lane * 8 + 4] = rb[c];
+            }
+            const uint16_t* rawrow = (const uint16_t*)rowimg;
+            for (int side = 0; side < 2; side++) {
+                auto key_of = [&](int c, int j) {
+                    const uint32_t ky = sort_key(rawrow[c * 1024 + lane * 16 + j]);
+                    return (side == 0 ? ky : 0xFFFFu - ky) + 1u;
+                };
+                auto count = [&](uint32_t thr, bool strict) {     // wave-wide #{key >= thr} or #{key > thr}
+                    int cnt = 0;
+                    for (int c = 0; c < C; c++)
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t ky = key_of(c, j);
+                            cnt += (strict ? ky > thr : ky >= thr) ? 1 : 0;
+                        }
+                    return (int)wave_sum_dpp((float)cnt);         // (<= 4096: exact in fp32)
+                };
+                uint32_t lo_b = 1u, hi_b = 0x10000u;
+                for (int it = 0; it < 17; it++) {
+                    const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                    if (count(mid, false) >= k) lo_b = mid; else hi_b = mid - 1u;
+                }
+                const uint32_t vstar = lo_b;
+                int need = k - count(vstar, true);                // ties still to take, in index order
+                for (int c = 0; c < C; c++) {
+                    uint32_t gt = 0u, eq = 0u;
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t ky = key_of(c, j);
+                        gt |= (ky > vstar ? 1u : 0u) << j;
+                        eq |= (ky == vstar ? 1u : 0u) << j;
+                    }
+                    const uint32_t ne = (uint32_t)__popc(eq);
+                    const uint32_t incl = wave_incl_scan_u32(ne);
+                    const int before = (int)(incl - ne);
+                    int take = need - before;
+                    take = take < 0 ? 0 : (take > (int)ne ? (int)ne : take);
+                    uint32_t sel = gt, rem = eq;
+                    for (int t = 0; t < take; t++) { sel |= rem & (0u - rem); rem &= rem - 1u; }
+                    selm[side][c] = sel;
+                    need -= __builtin_amdgcn_readlane((int)incl, 63);     // (may go negative: no more ties taken)
+                }
+            }
+            // outputs in index order + marks
+            uint32_t pos_h = 0u, pos_l = 0u;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint32_t cntp = (uint32_t)__popc(selm[0][c]) | ((uint32_t)__popc(selm[1][c]) << 16);
+                const uint32_t incl = wave_incl_scan_u32(cntp);
+                const uint32_t ex = incl - cntp;
+                uint32_t ph = pos_h + (ex & 0xFFFFu), pl = pos_l + (ex >> 16);
+                uint16_t* oi = oidx + lrow * (int64_t)(2 * k);
+                uint16_t* ov = oval + lrow * (int64_t)(2 * k);
+                for (uint32_t mm = selm[0][c]; mm; mm &= mm - 1u) {
+                    const int j = __builtin_ctz(mm), idx = c * 1024 + lane * 16 + j;
+                    oi[k + ph] = (uint16_t)idx;
+                    ov[k + ph] = rawrow[idx];
+                    ph++;
+                }
+                for (uint32_t mm = selm[1][c]; mm; mm &= mm - 1u) {
+                    const int j = __builtin_ctz(mm), idx = c * 1024 + lane * 16 + j;
+                    oi[pl] = (uint16_t)idx;
+                    ov[pl] = rawrow[idx];
+                    pl++;
+                }
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                pos_h += tot & 0xFFFFu;
+                pos_l += tot >> 16;
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                *(uint4*)&rowimg[c * 512 + lane * 8] = make_uint4(0, 0, 0, 0);
+                *(uint4*)&rowimg[c * 512 + lane * 8 + 4] = make_uint4(0, 0, 0, 0);
+                flag[c] = selm[0][c] | selm[1][c];
+                for (uint32_t mm = flag[c]; mm; mm &= mm - 1u)
+                    ((uint16_t*)rowimg)[c * 1024 + lane * 16 + __builtin_ctz(mm)] = (uint16_t)0xFFFFu;
+            }
+        } else {
+        // ---------------- candidates in index order: chunk after chunk, lane after lane, element after element
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            uint32_t cm = mh[c] | (ml[c] << 16);
+            uint32_t slot_h = bh[c] + (excl[c] & 0xFFFFu), slot_l = bl[c] + (excl[c] >> 16);
+            const uint16_t* rawh = (const uint16_t*)rowimg + c * 1024 + lane * 16;
+            while (cm) {
+                const uint32_t b = (uint32_t)__builtin_ctz(cm);
+                cm &= cm - 1u;
+                const uint32_t side = b >> 4, j = b & 15u;
+                const uint32_t bits = rawh[j];
+                const uint32_t slot = side ? slot_l : slot_h;
+                cand[side * 128u + slot] = (bits << 16) | (uint32_t)(c * 1024 + lane * 16 + (int)j);
+                slot_l += side;
+                slot_h += 1u - side;
+            }
+            // the raw copy of this lane's elements is dead: the slot becomes its half-word outlier marks
+            *(uint4*)&rowimg[c * 512 + lane * 8] = make_uint4(0, 0, 0, 0);
+            *(uint4*)&rowimg[c * 512 + lane * 8 + 4] = make_uint4(0, 0, 0, 0);
+        }
+        for (int i = lane; i < 2 * (LEN / 32); i += 64) omask[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // ---------------- per side: the k-th largest order key by bisection, ties "lower index first" by position
+        for (int side = 0; side < 2; side++) {
+            const uint32_t n = side == 0 ? nh : nl;
+            const bool v0 = (uint32_t)lane < n, v1 = (uint32_t)(lane + 64) < n;
+            const uint32_t c0 = v0 ? cand[side * 128 + lane] : 0u, c1 = v1 ? cand[side * 128 + lane + 64] : 0u;
+            const uint32_t ka = sort_key(c0 >> 16), kb = sort_key(c1 >> 16);
+            const uint32_t x0 = v0 ? (side == 0 ? ka : 0xFFFFu - ka) + 1u : 0u;
+            const uint32_t x1 = v1 ? (side == 0 ? kb : 0xFFFFu - kb) + 1u : 0u;
+            uint32_t lo_b = 1u, hi_b = 0x10000u;
+            for (int it = 0; it < 17; it++) {
+                const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                const int cnt = __popcll(__ballot(x0 >= mid)) + __popcll(__ballot(x1 >= mid));
+                if (cnt >= k) lo_b = mid; else hi_b = mid - 1u;
+            }
+            const int above = __popcll(__ballot(x0 > lo_b)) + __popcll(__ballot(x1 > lo_b));
+            const int need = k - above;
+            const bool t0 = x0 == lo_b, t1 = x1 == lo_b;
+            const unsigned long long bt0 = __ballot(t0), bt1 = __ballot(t1);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int r0 = __popcll(bt0 & lt), r1 = __popcll(bt0) + __popcll(bt1 & lt);
+            const bool s0 = x0 > lo_b || (t0 && r0 < need), s1 = x1 > lo_b || (t1 && r1 < need);
+            const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+            const int p0 = __popcll(b0 & lt), p1 = __popcll(b0) + __popcll(b1 & lt);
+            uint16_t* oi = oidx + lrow * (int64_t)(2 * k) + (side == 0 ? k : 0);
+            uint16_t* ov = oval + lrow * (int64_t)(2 * k) + (side == 0 ? k : 0);
+            if (s0) {
+                const uint32_t idx = c0 & 0xFFFFu;
+                oi[p0] = (uint16_t)idx;
+                ov[p0] = (uint16_t)(c0 >> 16);
+                atomicOr(&omask[side * (LEN / 32) + (idx >> 5)], 1u << (idx & 31));
+                ((uint16_t*)rowimg)[idx] = (uint16_t)0xFFFFu;
+            }
+            if (s1) {
+                const uint32_t idx = c1 & 0xFFFFu;
+                oi[p1] = (uint16_t)idx;
+                ov[p1] = (uint16_t)(c1 >> 16);
+                atomicOr(&omask[side * (LEN / 32) + (idx >> 5)], 1u << (idx & 31));
+                ((uint16_t*)rowimg)[idx] = (uint16_t)0xFFFFu;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int j0 = c * 1024 + lane * 16;
+            flag[c] = ((omask[j0 >> 5] | omask[LEN / 32 + (j0 >> 5)]) >> (j0 & 31)) & 0xFFFFu;
+        }
+        }
+        if (lane == 0 && omean) omean[r] = mean;
+    }
+    // ---------------- dense part, chunk by chunk
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint32_t rw[8] = {ra[c].x, ra[c].y, ra[c].z, ra[c].w, rb[c].x, rb[c].y, rb[c].z, rb[c].w};
+        uint32_t m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if (k > 0) {
+            const uint4 ma = *(const uint4*)&rowimg[c * 512 + lane * 8], mb = *(const uint4*)&rowimg[c * 512 + lane * 8 + 4];
+            m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w;
+            m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
+        }
+        dense16<BITS>(rw, m, flag[c], mean, group, gm.group_shift, lane, code_row, scale_row, mn_row, ooff[c], err_row, loff[c]);
+    }
+}
+
 }  // namespace
 
 static double inv_norm_cdf(double p) {
@@ -1063,9 +1478,31 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
         else if (bits == 4) GO(4, 1, float);
         else GO(8, 1, float);
     } else {
-        if (bits == 2) GO2(2);
-        else if (bits == 4) GO2(4);
-        else GO2(8);
+        // rows of 1024 / 2048 / 3072 / 4096 elements: one wave per row (compress_rows_wave_kernel)
+        const bool wave_rows = !gear_options().rows_wg_only && len % 1024 == 0 && len <= 4096 && (k == 0 || zthr > 0.0f);
+        if (wave_rows) {
+            const int Cc = (int)(len / 1024);
+            const size_t wlds = (size_t)4 * (len / 2 + 256 + 2 * (len / 32)) * 4;
+            const dim3 wgrid((unsigned)((n_rows + 3) / 4));
+#define GOW(B, CC, SL)                                                                                                  \
+    hipLaunchKernelGGL((compress_rows_wave_kernel<B, CC, SL>), wgrid, dim3(256), wlds, st, (const uint16_t*)x, gm, n_rows, group, k, zthr,   \
+                       1.0f / (float)len, (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx,  \
+                       (uint16_t*)oval, (float*)omean)
+#define GOWC(B)                                                                                                         \
+    do {                                                                                                                \
+        if (Cc == 1) { GOW(B, 1, false); if (k > 0) GOW(B, 1, true); }                                                  \
+        else if (Cc == 2) { GOW(B, 2, false); if (k > 0) GOW(B, 2, true); }                                             \
+        else if (Cc == 3) { GOW(B, 3, false); if (k > 0) GOW(B, 3, true); }                                             \
+        else { GOW(B, 4, false); if (k > 0) GOW(B, 4, true); }                                                          \
+    } while (0)
+            if (bits == 2) GOWC(2); else if (bits == 4) GOWC(4); else GOWC(8);
+#undef GOWC
+#undef GOW
+        } else {
+            if (bits == 2) GO2(2);
+            else if (bits == 4) GO2(4);
+            else GO2(8);
+        }
     }
 #undef GO2
 #undef GO
