@@ -410,7 +410,10 @@ def main():
     rows_out = C._alloc_rows(tuple(V.shape), layers * T, group, bits, 1, k_val, dev)
     ms_rows = timed(lambda: C._compress_rows(V, geom_v, group, bits, 1, k_val, rows_out, errb))
     b_rows = 2 * n + n * bits / 8 + 8 * n / group + layers * T * 2 * k_val * 4
-    kernels.append({"kernel": f"compress_rows_fp32_kernel<{bits}, float> (V rows: select + fill + quantize + pack + error)",
+    rows_len = Hl * D
+    rows_name = (f"compress_rows_wave_kernel<{bits}, {rows_len // 1024}, fast + fallback pass>" if rows_len % 1024 == 0 and rows_len <= 4096 and k_val <= 58
+                 else f"compress_rows_fp32_kernel<{bits}, float>")
+    kernels.append({"kernel": rows_name + " (V rows: select + fill + quantize + pack + error)",
                     "ms": ms_rows, "alg_bytes": b_rows, "not_counted": "the fp16 error it also writes (2n bytes): an intermediate"})
     del errb, rows_out
     # (2) the fused K path, kernel by kernel (variant hooks of gear_compress_key_fused)
@@ -436,9 +439,10 @@ def main():
     if os.path.exists(tp) and world == 1 and not args.layers and not args.emulate_world:
         prof = json.load(open(tp))
         if prof.get("lib_sha256") == lib_sha256() and prof.get("config") == args.config:
-            base = dom["kernel"].split(" ")[0].split("<")[0]       # compress_rows_fp32_kernel / k_select_kernel / k_main_kernel
+            base = dom["kernel"].split(" ")[0].split("<")[0]       # compress_rows_wave_kernel / compress_rows_fp32_kernel / k_select_kernel / k_main_kernel
             hit = [tb for kname, tb in prof.get("kernels", {}).items()
                    if kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")]
+            # (both instantiations of the wave-per-row kernel -- fast and fallback pass -- share the base name and are added up)
             if hit:
                 traffic, tnote = float(sum(hit)), f"profiles/r2_traffic.json ({prof.get('how', '')})"
         else:
