@@ -411,7 +411,7 @@ def main():
     ms_rows = timed(lambda: C._compress_rows(V, geom_v, group, bits, 1, k_val, rows_out, errb))
     b_rows = 2 * n + n * bits / 8 + 8 * n / group + layers * T * 2 * k_val * 4
     rows_len = Hl * D
-    rows_name = (f"compress_rows_wave_kernel<{bits}, {rows_len // 1024}, fast + fallback pass>" if rows_len % 1024 == 0 and rows_len <= 4096 and k_val <= 58
+    rows_name = (f"compress_rows_wave_kernel<{bits}, {rows_len // 1024}, fast + fallback pass>" if rows_len % 1024 == 0 and (rows_len <= 5120 or rows_len == 8192) and k_val <= 58
                  else f"compress_rows_fp32_kernel<{bits}, float>")
     kernels.append({"kernel": rows_name + " (V rows: select + fill + quantize + pack + error)",
                     "ms": ms_rows, "alg_bytes": b_rows, "not_counted": "the fp16 error it also writes (2n bytes): an intermediate"})

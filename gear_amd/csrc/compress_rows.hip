@@ -1115,7 +1115,7 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
     }
 }
 
-// Wave-per-row variant for rows of exactly 1024 C elements (C = 1..4 chunks of 16 elements per lane): the same algorithm as
+// Wave-per-row variant for rows of exactly 1024 C elements (C = 1..5 or 8 chunks of 16 elements per lane): the same algorithm as
 // compress_rows_fp32_kernel's fast path -- Gaussian-guess thresholds validated by the survivor counts, candidates compacted
 // in index order, 17-round key bisection, dense part -- with ONE wave per row, so that the per-row machinery (row statistics,
 // prefix scans, the bisection and its outputs) runs once per row instead of once per 1024 elements and on all four waves of a
@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
 // behind the fast one over all rows and returns at once for every row that is not marked -- a separate instantiation, so that
 // the rare path's registers do not count against the common one.
 template <int BITS, int C, bool SLOW>
-__global__ __launch_bounds__(256, 4) void compress_rows_wave_kernel(const uint16_t* __restrict__ x, RowGeom gm, int64_t n_rows, int group,
+__global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress_rows_wave_kernel(const uint16_t* __restrict__ x, RowGeom gm, int64_t n_rows, int group,
                                                                     int k, float zthr, float rlen, uint32_t* __restrict__ code,
                                                                     float* __restrict__ scale, float* __restrict__ mn,
                                                                     uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
@@ -1173,10 +1173,10 @@ __global__ __launch_bounds__(256, 4) void compress_rows_wave_kernel(const uint16
         const int64_t lrow = lrow_of(gm, r);
         // ---------------- row sum / sum of squares (exact products, fp32 accumulate), one DPP reduction each
         const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
-        // (the workgroup kernel reduces each wave's 1024 elements first and adds the four wave sums as (w0 + w1) + (w2 + w3);
+        // (the workgroup kernel reduces each wave's 1024 elements first and adds the wave sums as a DPP tree, ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
         // chunk c here holds what wave c holds there, so the chunks are reduced one by one and added in the same order: the
         // mean is the fill value and must come out with the same bits)
-        float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2 = 0.0f;
+        float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, s2 = 0.0f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const uint32_t rw[8] = {ra[c].x, ra[c].y, ra[c].z, ra[c].w, rb[c].x, rb[c].y, rb[c].z, rb[c].w};
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256, 4) void compress_rows_wave_kernel(const uint16
             }
             wsum[c] = wave_sum_dpp(s);
         }
-        const float tot1 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), tot2 = wave_sum_dpp(s2);
+        const float tot1 = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7])), tot2 = wave_sum_dpp(s2);
         mean = ((LEN & (LEN - 1)) == 0) ? tot1 * rlen : tot1 / (float)LEN;
         bool ok = !SLOW && zthr > 0.0f;
         uint32_t mh[C], ml[C], excl[C];
@@ -1478,22 +1478,28 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
         else if (bits == 4) GO(4, 1, float);
         else GO(8, 1, float);
     } else {
-        // rows of 1024 / 2048 / 3072 / 4096 elements: one wave per row (compress_rows_wave_kernel)
-        const bool wave_rows = !gear_options().rows_wg_only && len % 1024 == 0 && len <= 4096 && (k == 0 || zthr > 0.0f);
+        // rows of 1024 .. 5120 or 8192 elements: one wave per row (compress_rows_wave_kernel)
+        const bool wave_rows = !gear_options().rows_wg_only && len % 1024 == 0 && (len <= 5120 || len == 8192) && (k == 0 || zthr > 0.0f);
         if (wave_rows) {
             const int Cc = (int)(len / 1024);
             const size_t wlds = (size_t)4 * (len / 2 + 256 + 2 * (len / 32)) * 4;
             const dim3 wgrid((unsigned)((n_rows + 3) / 4));
 #define GOW(B, CC, SL)                                                                                                  \
-    hipLaunchKernelGGL((compress_rows_wave_kernel<B, CC, SL>), wgrid, dim3(256), wlds, st, (const uint16_t*)x, gm, n_rows, group, k, zthr,   \
-                       1.0f / (float)len, (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx,  \
-                       (uint16_t*)oval, (float*)omean)
+    do {                                                                                                                \
+        auto kfn = compress_rows_wave_kernel<B, CC, SL>;                                                                \
+        if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
+        hipLaunchKernelGGL(kfn, wgrid, dim3(256), wlds, st, (const uint16_t*)x, gm, n_rows, group, k, zthr,             \
+                           1.0f / (float)len, (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, \
+                           (uint16_t*)oval, (float*)omean);                                                             \
+    } while (0)
 #define GOWC(B)                                                                                                         \
     do {                                                                                                                \
         if (Cc == 1) { GOW(B, 1, false); if (k > 0) GOW(B, 1, true); }                                                  \
         else if (Cc == 2) { GOW(B, 2, false); if (k > 0) GOW(B, 2, true); }                                             \
         else if (Cc == 3) { GOW(B, 3, false); if (k > 0) GOW(B, 3, true); }                                             \
-        else { GOW(B, 4, false); if (k > 0) GOW(B, 4, true); }                                                          \
+        else if (Cc == 4) { GOW(B, 4, false); if (k > 0) GOW(B, 4, true); }                                             \
+        else if (Cc == 5) { GOW(B, 5, false); if (k > 0) GOW(B, 5, true); }                                             \
+        else { GOW(B, 8, false); if (k > 0) GOW(B, 8, true); }                                                          \
     } while (0)
             if (bits == 2) GOWC(2); else if (bits == 4) GOWC(4); else GOWC(8);
 #undef GOWC
