@@ -1136,9 +1136,7 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
     extern __shared__ __attribute__((aligned(16))) uint32_t wdyn[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-    if (r >= n_rows) return;
-    if (SLOW && oidx[lrow_of(gm, r) * (int64_t)(2 * k)] != (uint16_t)0xFFFFu) return;      // (launched only with k > 0)
+    auto process_row = [&](const int64_t r) {
     uint32_t* rowimg = wdyn + wave * WW;      // the raw row while candidates are emitted, then half-word outlier marks
     uint32_t* cand = rowimg + LEN / 2;
     uint32_t* omask = cand + 256;
@@ -1402,6 +1400,16 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
         }
         dense16<BITS>(rw, m, flag[c], mean, group, gm.group_shift, lane, code_row, scale_row, mn_row, ooff[c], err_row, loff[c]);
     }
+    };
+    if (!SLOW) {
+        const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+        if (r < n_rows) process_row(r);
+    } else {
+        // fallback pass (launched only with k > 0): a wave looks at the marks of 8 rows and takes the marked ones
+        const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 8;
+        const bool marked = lane < 8 && r0 + lane < n_rows && oidx[lrow_of(gm, r0 + lane) * (int64_t)(2 * k)] == (uint16_t)0xFFFFu;
+        for (unsigned long long todo = __ballot(marked); todo; todo &= todo - 1ull) process_row(r0 + __builtin_ctzll(todo));
+    }
 }
 
 }  // namespace
@@ -1487,8 +1495,9 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
 #define GOW(B, CC, SL)                                                                                                  \
     do {                                                                                                                \
         auto kfn = compress_rows_wave_kernel<B, CC, SL>;                                                                \
+        const dim3 wg = SL ? dim3((unsigned)((n_rows + 31) / 32)) : wgrid;                                              \
         if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
-        hipLaunchKernelGGL(kfn, wgrid, dim3(256), wlds, st, (const uint16_t*)x, gm, n_rows, group, k, zthr,             \
+        hipLaunchKernelGGL(kfn, wg, dim3(256), wlds, st, (const uint16_t*)x, gm, n_rows, group, k, zthr,                \
                            1.0f / (float)len, (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, \
                            (uint16_t*)oval, (float*)omean);                                                             \
     } while (0)
