@@ -61,30 +61,44 @@ SIGNATURES = {
     "gear_silu_mul": (_i, [_vp, _i64, _i, _vp, _vp]),
     "gear_transpose_f16": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "gear_gemv_outer": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "gear_compress_block_workspace": (_sz, [_i64, _i]),
+    "gear_compress_block": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "gear_compress_block_status_ptr": (_vp, [_vp]),
 }
+
+ABI_VERSION = 3      # what this table was written against (gear_abi_version() of the library must match)
 
 
 def _source_hash() -> str:
     """sha256 over the kernel sources (names + contents): what the built library is checked against."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".h")) or name == "Makefile":
-            h.update(name.encode())
-            with open(os.path.join(CSRC, name), "rb") as f:
-                h.update(f.read())
+    files = [os.path.join(CSRC, n) for n in sorted(os.listdir(CSRC)) if n.endswith((".hip", ".h")) or n == "Makefile"]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "gear_hip.h"))     # the ABI header is a dependency of every object
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile gear_amd/csrc/*.hip for gfx950 into gear_amd/libgear_hip.so (hipcc cross-compiles without a GPU) and record
     the hash of the sources it was built from next to it."""
+    import fcntl
     cmd = ["make", "-C", CSRC, "-j8"]
-    if force:
-        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
-    with open(LIB_PATH + ".src", "w") as f:
-        f.write(_source_hash())
+    # ranks started together (bench.py under torch.distributed.run, the spawned workers of the tests) must not run make in the
+    # same directory at once: the first takes the lock and builds, the others find the library up to date
+    with open(LIB_PATH + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force:
+                subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+            subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+            with open(LIB_PATH + ".src", "w") as f:
+                f.write(_source_hash())
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -113,6 +127,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI and the library disagree
         fn.restype = res
         fn.argtypes = args
+    got = lib.gear_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, gear_amd/_lib.py was written against {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

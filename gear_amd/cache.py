@@ -121,6 +121,29 @@ def _view(bufs, d, NB, H, D, kk0, seg0, kwin=True):
     return v
 
 
+USE_BLOCK_KERNEL = True      # tests switch it off to compare the single-launch block compressor with the chain
+_BLOCK_WS = {}
+
+
+def _block_sync_ws(lib, NB, H, dev):
+    """Hand-off buffer of gear_compress_block (row flags, masks, means): zeroed once, then owned by the kernel."""
+    key = (str(dev), NB, H)
+    ws = _BLOCK_WS.get(key)
+    if ws is None:
+        ws = _BLOCK_WS[key] = torch.zeros((lib.gear_compress_block_workspace(NB, H),), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def block_kernel_status(dev="cuda") -> int:
+    """OR of the status words of every block-compress hand-off buffer on `dev` (non-zero: a V tile gave up waiting)."""
+    st = 0
+    for (d, _, _), ws in _BLOCK_WS.items():
+        if d == str(torch.device(dev)) or torch.device(d) == ws.device:
+            off = (-ws.data_ptr()) % 256
+            st |= int(ws[off:off + 4].view(torch.int32).item())
+    return st
+
+
 def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_off, loop, gen, kk0=0, seg0=0):
     """Compress K / V [lead*B, H, T, 128] (lead = layers riding in the batch dimension of pooled storage) and write the
     payload behind token t_off of the cache tensors in `bufs` (same leading dimension), factors into segment `seg`, K outlier
@@ -134,6 +157,22 @@ def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_of
     if d["lowrank"]:
         P0k = torch.rand((NB, H, D, d["rk"]), device=dev, generator=gen)
         P0v = torch.rand((NB, H, D, d["rv"]), device=dev, generator=gen)
+    if (USE_BLOCK_KERNEL and T == d["R"] == 64 and k_src is bufs.get("kwin") and v_src is bufs.get("vwin") and H <= 64
+            and kk <= 16 and (d["kv"] <= 255 or "vochunk" not in bufs)):
+        # the decode-time block boundary: ONE launch over all (layer, head, K | V) tiles (csrc/block_fused.hip) instead of the
+        # chain below (select, fused quantize + Gram, solve, Q pass; row compressor, Gram + solve, Q pass; chunk index; 2 tile
+        # builders).  Same payload bits; the factors come from the token-side iteration (same subspace).
+        view = _view(bufs, d, NB, H, D, kk0, seg0, kwin=True)
+        if not kk:
+            view.koidx = view.koval = None
+        seg_k, seg_v = B * H * D * d["rk"], B * H * D * d["rv"]
+        kP = bufs["kPseg"].view(-1)[seg * seg_k:] if d["lowrank"] else None
+        vP = bufs["vPseg"].view(-1)[seg * seg_v:] if d["lowrank"] else None
+        ws = _block_sync_ws(lib, NB, H, dev)
+        rc = lib.gear_compress_block(C_.byref(view), t_off, o_off, loop, p(P0k), p(P0v), p(kP), p(vP), B * H, d["nseg"] * seg_k,
+                                     d["nseg"] * seg_v, p(ws), ws.numel(), L.stream_ptr(k_src))
+        L.check(rc, "gear_compress_block")
+        return
     # per-segment channel factors [lead, nseg, B, H, D, r]: head (l, b, h) of segment seg
     def pseg(name, r):
         if not d["lowrank"]:

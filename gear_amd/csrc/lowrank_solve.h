@@ -18,6 +18,61 @@ __host__ __device__ constexpr size_t gram_solve_lds_bytes(int RP) {
     return (size_t)GS_GD * GS_GP * 4 + 2 * (size_t)GS_GD * RP * 4 + 3 * (size_t)RP * RP * 8 + 16;
 }
 
+// Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0.  One wave: lane m owns column m of R and of R^-1; the
+// pivots' reciprocal square roots come from v_rsq_f64 + Newton.  Md fp64 [RP][RP], Rinv fp64 [2][RP][RP] (the second half stages
+// R for the back substitution), both in LDS.  The caller orders the LDS accesses around the call (barrier or wave fence).
+template <int RP>
+__device__ __forceinline__ void chol_inverse_wave(const double* __restrict__ Md, double* __restrict__ Rinv, int lane) {
+    double* Rl = Rinv + RP * RP;   // R staged for the back substitution
+    const int m = lane;
+    double col[RP], rin[RP], rinvd[RP];
+    bool dead[RP];
+#pragma unroll
+    for (int j = 0; j < RP; j++) {
+        double sacc = (m < RP) ? Md[j * RP + m] : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < RP; kk++) {
+            if (kk < j) {
+                const double rkj = __shfl(col[kk], j, 64);    // R[kk][j]
+                sacc -= rkj * col[kk];
+            }
+        }
+        const double dj = __shfl(sacc, j, 64), dg = Md[j * RP + j];
+        dead[j] = !(dj > 1e-12 * dg) || !(dg > 0.0);
+        double rs = 1.0;
+        if (!dead[j]) {
+            rs = __builtin_amdgcn_rsq(dj);
+            rs = rs * (1.5 - 0.5 * dj * rs * rs);
+            rs = rs * (1.5 - 0.5 * dj * rs * rs);
+        }
+        rinvd[j] = dead[j] ? 0.0 : rs;
+        col[j] = (m == j) ? (dead[j] ? 1.0 : dj * rs) : ((m > j && !dead[j]) ? sacc * rs : 0.0);
+    }
+    if (m < RP) {
+#pragma unroll
+        for (int kk = 0; kk < RP; kk++) Rl[kk * RP + m] = col[kk];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bool deadm = false;
+#pragma unroll
+    for (int j = 0; j < RP; j++) deadm = (m == j) ? dead[j] : deadm;
+    // column m of R^-1 by back substitution
+#pragma unroll
+    for (int i = RP - 1; i >= 0; i--) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < RP; kk++)
+            if (kk > i) sacc += Rl[i * RP + kk] * ((kk <= m) ? rin[kk] : 0.0);
+        rin[i] = (i == m) ? rinvd[i] : ((i < m && !deadm) ? -sacc * rinvd[i] : 0.0);
+    }
+    if (m < RP) {
+#pragma unroll
+        for (int i = 0; i < RP; i++) Rinv[i * RP + m] = rin[i];
+    }
+}
+
 // Wout: fp32 [128][RP] of this head.  P_out: this head's [128][r] block (fp16 or fp32).
 // GREG: the thread's 64 values of G (row d = tid / 2, columns e(i) = (i & 31) + 64 (i >> 5) + 32 (tid & 1), i = 0..63, i.e. two
 // runs of 32 consecutive columns) are passed in registers and G in LDS is not used: 10 KB of LDS per workgroup instead of 76,
@@ -76,56 +131,7 @@ __device__ __forceinline__ void gram_solve_phase2(float* __restrict__ G, float* 
     // Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0.  Lane m of wave 0 owns column m of R and of
     // R^-1; the pivots' reciprocal square roots come from v_rsq_f64 + Newton.
     auto chol_inverse = [&]() {
-        double* Rl = Rinv + RP * RP;   // R staged for the back substitution
-        if (tid < 64) {
-            const int m = lane;
-            double col[RP], rin[RP], rinvd[RP];
-            bool dead[RP];
-#pragma unroll
-            for (int j = 0; j < RP; j++) {
-                double sacc = (m < RP) ? Md[j * RP + m] : 0.0;
-#pragma unroll
-                for (int kk = 0; kk < RP; kk++) {
-                    if (kk < j) {
-                        const double rkj = __shfl(col[kk], j, 64);    // R[kk][j]
-                        sacc -= rkj * col[kk];
-                    }
-                }
-                const double dj = __shfl(sacc, j, 64), dg = Md[j * RP + j];
-                dead[j] = !(dj > 1e-12 * dg) || !(dg > 0.0);
-                double rs = 1.0;
-                if (!dead[j]) {
-                    rs = __builtin_amdgcn_rsq(dj);
-                    rs = rs * (1.5 - 0.5 * dj * rs * rs);
-                    rs = rs * (1.5 - 0.5 * dj * rs * rs);
-                }
-                rinvd[j] = dead[j] ? 0.0 : rs;
-                col[j] = (m == j) ? (dead[j] ? 1.0 : dj * rs) : ((m > j && !dead[j]) ? sacc * rs : 0.0);
-            }
-            if (m < RP) {
-#pragma unroll
-                for (int kk = 0; kk < RP; kk++) Rl[kk * RP + m] = col[kk];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            bool deadm = false;
-#pragma unroll
-            for (int j = 0; j < RP; j++) deadm = (m == j) ? dead[j] : deadm;
-            // column m of R^-1 by back substitution
-#pragma unroll
-            for (int i = RP - 1; i >= 0; i--) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < RP; kk++)
-                    if (kk > i) sacc += Rl[i * RP + kk] * ((kk <= m) ? rin[kk] : 0.0);
-                rin[i] = (i == m) ? rinvd[i] : ((i < m && !deadm) ? -sacc * rinvd[i] : 0.0);
-            }
-            if (m < RP) {
-#pragma unroll
-                for (int i = 0; i < RP; i++) Rinv[i * RP + m] = rin[i];
-            }
-        }
+        if (tid < 64) chol_inverse_wave<RP>(Md, Rinv, lane);
         __syncthreads();
     };
     auto gram_small = [&](const float* A, const float* B) {  // Md = A^T B  (fp64 accumulate), 4 lanes per output

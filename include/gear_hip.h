@@ -305,6 +305,31 @@ int gear_attn_decode_cache(const gear_cache_view* c, const void* q, int Hq, int 
 /* (Re)build the sparse tiles of K chunks [k_chunk0, k_chunk1) (128 tokens each) and V blocks [v_blk0, v_blk1) (64 tokens each) of a
  * cache that holds T compressed tokens: called after the prompt and after every appended block (the chunk the block lies in). */
 int gear_cache_tiles_build(const gear_cache_view* c, int T, int k_chunk0, int k_chunk1, int v_blk0, int v_blk1, void* stream);
+/* ---- the decode-time block boundary in ONE launch -------------------------------------------------------------------------
+ * Replaces, for the 64-token block the attention hook compresses whenever its fp16 window is full
+ * (cuda_supported_gear/modeling_llamagear.py:265-286 key_compression of the block, :335-378 value_compression; with a sparsity
+ * in the config also gears_channelQ / gears_tokenQ of GenerationBench/.../Simulated/compress_function.py:261-333 on the block),
+ * the sequence gear_compress_key_fused + gear_compress_value_fused + gear_outlier_chunk_index_ex + gear_cache_tiles_build (~10
+ * launches): one wave per (layer*batch, head, K | V) tile of 64 x 128 fp16 reads the window (c->kwin / c->vwin, row pitch wcap),
+ * selects the outliers (K: kkb per side and channel over the 64 tokens; V: kv per side and token row ACROSS the heads, found by
+ * "row duty" waves of the same launch and handed to the V tiles through sync_ws), quantizes (fp16-stepwise arithmetic, mode 0),
+ * packs, keeps the error tile in LDS and runs the rank-r power iteration on it (token side: G' = E E^T is 64 x 64), then writes
+ * codes / scale / mn / lists / chunk-index bytes / sparse tiles / factors at token offset t_off of the view's tensors in place.
+ *   c       the cache view with B = layers * batch; mode must be 0, D 128, Hkv <= 64, kkb <= 16; the tensors behind the const
+ *           pointers are WRITTEN (token rows t_off .. t_off + 63, K list positions o_off .. o_off + kkb - 1, tile of the chunk /
+ *           block the tokens lie in)
+ *   P0k / P0v float [B*Hkv, 128, rk | rv] initial bases; kP_out / vP_out fp16, head bh at element offset
+ *           (bh / p_inner) * outer_stride + (bh % p_inner) * 128 * r (the per-segment factor tensors of the cache)
+ *   sync_ws gear_compress_block_workspace(B, Hkv) bytes of device memory, ZEROED ONCE by the caller and then left alone (row
+ *           flags carry a per-call tag); the word at gear_compress_block_status_ptr(sync_ws) becomes non-zero if a V tile ever
+ *           gave up waiting for its rows (never on a healthy device; the call then does not hang, its V outliers are wrong).
+ * Payload (codes, scale, mn, outlier sets and values, chunk index, tile contents) is bit-identical to the chain's; the factors
+ * span the same subspaces (Q P^T within fp16 rounding of the chain's). */
+size_t gear_compress_block_workspace(int64_t B, int Hkv);
+int gear_compress_block(const gear_cache_view* c, int t_off, int o_off, int loop, const void* P0k, const void* P0v, void* kP_out,
+                        void* vP_out, int64_t p_inner, int64_t kp_outer_stride, int64_t vp_outer_stride, void* sync_ws,
+                        size_t sync_ws_bytes, void* stream);
+const void* gear_compress_block_status_ptr(const void* sync_ws);
 /* Chunk index over lists that live inside larger tensors (the streaming cache keeps its tables up to date block by block):
  * lists (o, i), o < n_outer, i < inner, list id = o * outer_pitch + first + i; list `id` is oidx + id * list_stride with k valid
  * entries; out[id * out_pitch + b] = first position whose index is >= b * step, b < n_bounds.
