@@ -122,6 +122,9 @@ def _view(bufs, d, NB, H, D, kk0, seg0, kwin=True):
 
 
 USE_BLOCK_KERNEL = True      # tests switch it off to compare the single-launch block compressor with the chain
+# With V outliers every K tile's wave first selects 64 / H token rows (one after the other): at 1 - 3 KV heads per rank (70B head
+# shards) that serial part outweighs the saved launches (measured, 80 layers x 1 head: 367 us against the chain's 222).
+BLOCK_KERNEL_MIN_HEADS = 4
 _BLOCK_WS = {}
 
 
@@ -158,7 +161,7 @@ def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_of
         P0k = torch.rand((NB, H, D, d["rk"]), device=dev, generator=gen)
         P0v = torch.rand((NB, H, D, d["rv"]), device=dev, generator=gen)
     if (USE_BLOCK_KERNEL and T == d["R"] == 64 and k_src is bufs.get("kwin") and v_src is bufs.get("vwin") and H <= 64
-            and kk <= 16 and (d["kv"] <= 255 or "vochunk" not in bufs)):
+            and kk <= 16 and (d["kv"] <= 255 or "vochunk" not in bufs) and (H >= BLOCK_KERNEL_MIN_HEADS or not d["kv"])):
         # the decode-time block boundary: ONE launch over all (layer, head, K | V) tiles (csrc/block_fused.hip) instead of the
         # chain below (select, fused quantize + Gram, solve, Q pass; row compressor, Gram + solve, Q pass; chunk index; 2 tile
         # builders).  Same payload bits; the factors come from the token-side iteration (same subspace).
@@ -223,6 +226,9 @@ class GearKVCachePool:
     def __init__(self, n_layers: int, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device,
                  head_dim: int = 128, seed: int = 0, heads_total: int = None):
         shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim, heads_total)
+        if batch * n_kv_heads > 65535:
+            raise L.GearError(f"GearKVCachePool: batch * kv heads = {batch * n_kv_heads} exceeds 65535 (one layer's heads ride on a "
+                              "grid dimension of the prefill kernels)")
         self.L, self.B, self.H, self.D = n_layers, batch, n_kv_heads, head_dim
         self.loop = int(compress_config.get("loop", 3))
         self.buf = {}
@@ -244,8 +250,14 @@ class GearKVCachePool:
         t0, seg = c0.n_comp, c0._segment_of(c0.n_comp)
         assert t0 + R <= d["Tmax"], "cache capacity exceeded"
         o_off = c0.kk0 + ((t0 - c0.seg0) // R) * d["kk_blk"]
-        _compress_into(b, d, self.L, self.B, self.H, self.D, b["kwin"], b["vwin"], R, t0, seg, d["kk_blk"], o_off, self.loop,
-                       self.gen, c0.kk0, c0.seg0)
+        # the chain's kernels put (layer, batch, head) on grid.y (<= 65535): when the single-launch block kernel does not apply
+        # (see _compress_into) and the pool is larger than that, the layers go in groups
+        per = max(1, 65535 // (self.B * self.H))
+        groups = [(0, self.L)] if self.L <= per else [(l0, min(self.L, l0 + per)) for l0 in range(0, self.L, per)]
+        for l0, l1 in groups:
+            sub = b if (l0, l1) == (0, self.L) else {n: t[l0:l1] for n, t in b.items()}
+            _compress_into(sub, d, l1 - l0, self.B, self.H, self.D, sub["kwin"], sub["vwin"], R, t0, seg, d["kk_blk"], o_off,
+                           self.loop, self.gen, c0.kk0, c0.seg0)
         for c in self.caches:
             c.n_comp += R
             c.n_win = 0

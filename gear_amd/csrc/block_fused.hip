@@ -96,18 +96,20 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
     const float mean = (float)(s / (double)(H * KD));
     const int row = nb * 64 + t;
     // ---- thresholds: large side = the largest K with #{key >= K} >= kv; small side = the smallest K with #{key <= K} >= kv
+    // Wave-wide counts through the scalar unit: one compare per key (the high halves as 32-bit compares against the threshold
+    // shifted up, the low halves as 16-bit compares), ballot -> s_bcnt1 -> scalar add.  (The first version counted per lane with
+    // packed min / max / xor and reduced across the wave every round: twice the vector instructions plus a DPP scan per round.)
     auto counts = [&](uint32_t midL, uint32_t midS) -> uint32_t {   // (#{key >= midL}) | (#{key <= midS}) << 16 over the row
-        const uint32_t mL = midL | (midL << 16), mS = midS | (midS << 16);
-        uint32_t accL = 0u, accS = 0u;
+        const uint32_t upL = midL << 16, upS = (midS << 16) | 0xFFFFu;
+        const uint16_t loLv = (uint16_t)midL, loSv = (uint16_t)midS;
+        uint32_t nL = 0u, nS = 0u;
 #pragma unroll 8
         for (int h = 0; h < H; h++) {
             const uint32_t k2 = kw[h * 64 + lane];
-            accL += pkminu16(pkmaxu16(k2, mL) ^ k2, 0x00010001u);    // 1 per half with key < midL
-            accS += pkminu16(pkminu16(k2, mS) ^ k2, 0x00010001u);    // 1 per half with key > midS
+            nL += (uint32_t)__popcll(__ballot(k2 >= upL)) + (uint32_t)__popcll(__ballot((uint16_t)k2 >= loLv));
+            nS += (uint32_t)__popcll(__ballot(k2 <= upS)) + (uint32_t)__popcll(__ballot((uint16_t)k2 <= loSv));
         }
-        const uint32_t ge = (uint32_t)(2 * H) - ((accL & 0xFFFFu) + (accL >> 16));
-        const uint32_t le = (uint32_t)(2 * H) - ((accS & 0xFFFFu) + (accS >> 16));
-        return wave_total_u32(ge | (le << 16));
+        return nL | (nS << 16);
     };
     uint32_t loL = 1u, hiL = 0xFFFFu, loS = 0u, hiS = 0xFFFFu;
 #pragma unroll 1
@@ -191,7 +193,7 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
 
 // ================================================================================================ low-rank step on the LDS tile
 __host__ __device__ constexpr size_t blk_lr_lds_bytes(int RP) {      // behind the error tile
-    return (size_t)2 * 16 * RP * 8 * 2 + (size_t)2 * 64 * RP * 4 + (size_t)3 * RP * RP * 8;
+    return (size_t)2 * 64 * RP * 4 + (size_t)3 * RP * RP * 8;
 }
 
 // etile: fp16 [64 tokens][ET_PITCH] in LDS (complete, visible).  P0h: float [128][r] of this head (global).  Writes P_out fp16
@@ -199,10 +201,12 @@ __host__ __device__ constexpr size_t blk_lr_lds_bytes(int RP) {      // behind t
 template <int RP>
 __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned char* sm, const float* __restrict__ P0h, int r, int loop,
                                              uint16_t* __restrict__ P_out, uint16_t* __restrict__ Q_out, int lane) {
-    uint16_t* Ah = (uint16_t*)sm;                       // [16][RP][8]: P0 as fp16, [k / 8][m][k % 8]   (later Q': [8][RP][8])
-    uint16_t* Al = Ah + 16 * RP * 8;                    // remainder p - fp16(p)
-    float* Ya = (float*)(Al + 16 * RP * 8);             // [64][RP]
+    // [64][RP] floats twice (Ya, Yb); the same bytes first hold P0 and at the end Q' as matrix-core operands (fp16 head in the
+    // first half, remainder in the second), [k / 8][m][k % 8]: P0 needs 16 x RP x 8 halves = exactly one Y buffer
+    float* Ya = (float*)sm;
     float* Yb = Ya + 64 * RP;
+    uint16_t* Ah = (uint16_t*)Ya;
+    uint16_t* Al = (uint16_t*)Yb;
     double* Md = (double*)(Yb + 64 * RP);               // [RP][RP]
     double* Rinv = Md + RP * RP;                        // [2][RP][RP]
     const int n = lane & 31, kg = lane >> 5;
@@ -217,12 +221,12 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
         Al[pos] = f2h_bits(w - h2f_bits(hi));
     }
     __syncthreads();
-    // ---- Y0 = E P0: C[m = rank column][n = token]
+    // ---- Y0 = E P0: C[m = rank column][n = token]; both halves stay in registers until the operand bytes are dead
+    float16_t y0acc[2];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        float16_t acc;
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+        for (int q = 0; q < 16; q++) y0acc[half][q] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             U ah, al, b;
@@ -232,13 +236,8 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
                 al.u = *(const uint4*)&Al[((2 * ks + kg) * RP + n) * 8];
             }
             b.u = *(const uint4*)(etile + (32 * half + n) * ET_PITCH + 16 * ks + 8 * kg);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int qb = 0; qb < (RP + 7) / 8; qb++) {
-            const int c0 = 8 * qb + 4 * kg;
-            if (c0 < RP) *(float4*)&Ya[(32 * half + n) * RP + c0] = make_float4(acc[4 * qb], acc[4 * qb + 1], acc[4 * qb + 2], acc[4 * qb + 3]);
+            y0acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, y0acc[half], 0, 0, 0);
+            y0acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, y0acc[half], 0, 0, 0);
         }
     }
     // ---- G' = E E^T: g[I][J][q] = G'[32 I + (q & 3) + 8 (q >> 2) + 4 kg][32 J + n]
@@ -255,6 +254,16 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
             g01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, f1.h, g01, 0, 0, 0);
             g10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, f0.h, g10, 0, 0, 0);
             g11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, f1.h, g11, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int qb = 0; qb < (RP + 7) / 8; qb++) {
+            const int c0 = 8 * qb + 4 * kg;
+            if (c0 < RP)
+                *(float4*)&Ya[(32 * half + n) * RP + c0] = make_float4(y0acc[half][4 * qb], y0acc[half][4 * qb + 1], y0acc[half][4 * qb + 2], y0acc[half][4 * qb + 3]);
         }
     }
     __syncthreads();

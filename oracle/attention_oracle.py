@@ -2,10 +2,12 @@
 
 Follows cuda_supported_gear/modeling_llamagear.py:177-484 (LlamaAttention_GEAR.forward) from the point where
 q / k / v (post-RoPE, fp16) are known up to the tensor handed to o_proj, with the build's documented stances on
-reference defects B1 (all code columns packed) and B2 (K factors approximate the true error).  The reference's own
-forward cannot be imported under the installed transformers, so this restatement is pinned
-only through its building blocks (oracle.py functions, each checked against golden vectors) -- "parity unpinned"
-at the level of the whole state machine.
+reference defects B1 (all code columns packed) and B2 (K factors approximate the true error).  The reference's module
+cannot be imported whole under the installed transformers; the pin is tests/golden/f8_ref_*.npz:
+traces made by executing the reference's OWN forward / key_compression / value_compression / matmul_withlrap source
+(extracted with ast by tests/golden/make_f8_ref.py, model plumbing stubbed), which tests/test_oracle_golden.py holds
+this restatement to -- the KIVI-method cases with nothing of the reference replaced, the low-rank cases with the two
+defective glue functions replaced by their documented stance.
 """
 import math
 
@@ -25,6 +27,31 @@ def add16(a, b):
 
 def rep(t, n):
     return t if n == 1 else np.repeat(t, n, axis=-3)
+
+
+def matmul_withlrap(group_size, a, code, scale, mn, bits, pbase, qbase, type="key", n_rep=1):
+    """modeling_llamagear.py:54-111: dequant GEMV + low-rank correction, fp16 matmuls.  pbase / qbase in the reference's
+    format: [None] | [prefill] | [prefill, stacked [nbuf, B, H, ., r]].  a [B,Hq,1,K]."""
+    r1 = orc.gemv_outer(np.ascontiguousarray(a), code, scale, mn, group_size, bits)
+    if pbase[0] is None:
+        return r1
+    if type == "key":          # r1[.., :Tp] += (a Q0) P0^T ; r1[.., Tp + 64 i ..] += (a Q1[i]) P1[i]^T   (:64-85)
+        parts = [mm16(mm16(a, rep(qbase[0], n_rep)), rep(pbase[0], n_rep).transpose(0, 1, 3, 2))]
+        if len(pbase) > 1:
+            for P, Qf in zip(pbase[1], qbase[1]):
+                parts.append(mm16(mm16(a, rep(Qf, n_rep)), rep(P, n_rep).transpose(0, 1, 3, 2)))
+        return add16(r1, np.concatenate(parts, axis=-1))
+    # value: out += (a[:, :Tp] Q0) P0^T + sum_i (a_blk_i Q1[i]) P1[i]^T   (:87-108)
+    tp = qbase[0].shape[-2]
+    out = add16(r1, mm16(mm16(a[..., :tp], rep(qbase[0], n_rep)), rep(pbase[0], n_rep).transpose(0, 1, 3, 2)))
+    if len(pbase) > 1:
+        bl = qbase[1].shape[-2]
+        acc = None
+        for i, (P, Qf) in enumerate(zip(pbase[1], qbase[1])):
+            t = mm16(mm16(a[..., tp + i * bl:tp + (i + 1) * bl], rep(Qf, n_rep)), rep(P, n_rep).transpose(0, 1, 3, 2))
+            acc = t if acc is None else add16(acc, t)       # torch: result4.sum(dim=0) of fp16 terms
+        out = add16(out, acc)
+    return out
 
 
 class GearAttentionOracle:

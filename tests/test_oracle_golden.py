@@ -234,3 +234,121 @@ def test_f7_gemv(golden, name, b):
     # reference recipe rounds the dequantized weight to fp16 (gemv.py:70-74); the kernel does not
     assert rel_fro(out32, ref) < 2e-3
     assert rel_fro(out.astype(np.float32), ref) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# F8-ref: the state machines against traces made by EXECUTING the reference's own forward / compression glue /
+# matmul_withlrap source (tests/golden/make_f8_ref.py).  Tolerances: the reference-side GEMV of the fixture rounds the
+# dequantized weight to fp16 before the product (its own check of the kernel, quant/gemv.py:70-74) where the kernel -- and
+# orc.gemv_outer -- keep fp32 (2e-3, as fixture F7); low-rank factors agree up to the basis of the subspace (products only).
+F8_REF_GEAR = ["gear_kivi_b2", "gear_kivi_b4_t64", "gear_stance_gearl_b2", "gear_stance_gearl_b4_t30"]
+F8_REF_KIVI = ["kivi_b2", "kivi_b4_t64"]
+
+
+def _f8_ref_inputs(f, case):
+    qkv = f[case + "_qkv"]                       # [3, 1, H, T, D] post-RoPE q, k, v
+    out = f[case + "_out"]                       # [1, 1 + steps, H*D]
+    H, T, D = qkv.shape[2], qkv.shape[3], qkv.shape[4]
+    steps = out.shape[1] - 1
+    return qkv[0], qkv[1], qkv[2], out.reshape(1, steps + 1, H, D).transpose(0, 2, 1, 3), H, D, T - steps, steps
+
+
+def _run_trace(o, q, k, v, TP, steps):
+    mask = np.triu(np.full((TP, TP), np.finfo(np.float16).min, np.float16), 1)[None, None]
+    outs = [o.prefill(q[:, :, :TP], k[:, :, :TP], v[:, :, :TP], mask)[:, :, -1:]]
+    for i in range(steps):
+        t = TP + i
+        outs.append(o.decode(q[:, :, t:t + 1], k[:, :, t:t + 1], v[:, :, t:t + 1]))
+    return np.concatenate(outs, 2)
+
+
+@pytest.mark.parametrize("case", F8_REF_GEAR)
+def test_f8_ref_gear_state_machine_vs_reference_forward(golden, case):
+    """oracle/attention_oracle.py against LlamaAttention_GEAR.forward of the reference (cuda_supported_gear/modeling_llamagear.py:
+    177-484) run step by step: attention output of every step, slot 8, the packed cache bit for bit, the factor products."""
+    from oracle.attention_oracle import GearAttentionOracle
+    f = golden(f"f8_ref_{case}.npz")
+    q, k, v, ref, H, D, TP, steps = _f8_ref_inputs(f, case)
+    bits = 4 if "_b4" in case else 2
+    method = "gearlKIVI" if "gearl" in case else "KIVI"
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
+    drawn = []
+
+    def draw(B, Hh, S, Dm, r):
+        p = f[f"{case}_P0_{len(drawn)}"]
+        assert p.shape == (B, Hh, Dm, r)
+        drawn.append(p)
+        return p
+    o = GearAttentionOracle(H, H, D, cc, draw)
+    got = _run_trace(o, q, k, v, TP, steps)
+    assert got.shape == ref.shape
+    assert rel_fro(got, ref) < 2e-3, rel_fro(got, ref)
+    worst = max(rel_fro(got[:, :, i], ref[:, :, i]) for i in range(steps + 1))
+    assert worst < 4e-3, worst
+    c = o.c
+    assert c["n"] == int(f[case + "_seq"][0]) == TP + steps
+    # (a prompt of exactly `residual` tokens strands V in fp16 for good -- modeling_llamagear.py:416 / :335 -- in both)
+    for name, key in (("kcode", "kc"), ("vcode", "vc"), ("kscale", "ks"), ("kmn", "km"), ("vscale", "vs"), ("vmn", "vm"),
+                      ("kfull", "kfull"), ("vfull", "vfull")):
+        if c[key] is None:
+            assert f"{case}_{name}" not in f.files, name
+        elif c[key].dtype == np.float16:
+            assert np.array_equal(c[key].view(np.uint16), f[f"{case}_{name}"].view(np.uint16)), name
+        else:
+            assert np.array_equal(c[key], f[f"{case}_{name}"]), name
+    if method == "gearlKIVI":
+        assert len(drawn) == len([n for n in f.files if n.startswith(case + "_P0_")])
+        # factors: reference format [prefill, stacked blocks]; the oracle keeps one entry per segment
+        for pn, qn, op, oq in (("kp", "kq", "kp", "kq"), ("vp", "vq", "vp", "vq")):
+            refs = [(f[f"{case}_{pn}0"], f[f"{case}_{qn}0"])] if f"{case}_{pn}0" in f.files else []
+            if f"{case}_{pn}1" in f.files:
+                refs += list(zip(f[f"{case}_{pn}1"], f[f"{case}_{qn}1"]))
+            assert len(refs) == len(c[op])
+            for (P, Qf), Po, Qo in zip(refs, c[op], c[oq]):
+                a = Qf.astype(np.float64) @ P.astype(np.float64).transpose(0, 1, 3, 2)
+                b = Qo.astype(np.float64) @ Po.astype(np.float64).transpose(0, 1, 3, 2)
+                assert rel_fro(b, a) < 3e-3, (pn, rel_fro(b, a))
+
+
+@pytest.mark.parametrize("case", F8_REF_KIVI)
+def test_f8_ref_kivi_state_machine_vs_reference_forward(golden, case):
+    """oracle/kivi_oracle.py against LlamaAttention_KIVI.forward of the reference (modeling_llama_kivi.py:81-289), incl. the
+    per-token V quantization past the sliding window (:200-213)."""
+    from oracle.kivi_oracle import KiviAttentionOracle
+    f = golden(f"f8_ref_{case}.npz")
+    q, k, v, ref, H, D, TP, steps = _f8_ref_inputs(f, case)
+    bits = 4 if "_b4" in case else 2
+    o = KiviAttentionOracle(H, H, D, 64, bits, 64)
+    got = _run_trace(o, q, k, v, TP, steps)
+    assert rel_fro(got, ref) < 2e-3, rel_fro(got, ref)
+    assert max(rel_fro(got[:, :, i], ref[:, :, i]) for i in range(steps + 1)) < 4e-3
+    c = o.c
+    assert c["n"] == int(f[case + "_seq"][0])
+    assert np.array_equal(c["kc"], f[case + "_kcode"]) and np.array_equal(c["vc"], f[case + "_vcode"])
+    for name, key in (("kscale", "ks"), ("kmn", "km"), ("vscale", "vs"), ("vmn", "vm"), ("vfull", "vfull")):
+        assert np.array_equal(c[key].view(np.uint16), f[f"{case}_{name}"].view(np.uint16)), name
+    assert c["vfull"].shape[2] == 64                  # the sliding fp16 window
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_f8_ref_matmul_withlrap(golden, bits):
+    """oracle matmul_withlrap against the reference's (modeling_llamagear.py:54-111): no factors, prefill factors, prefill +
+    stacked block factors, key and value side."""
+    from oracle.attention_oracle import matmul_withlrap
+    f = golden("f8_ref_matmul.npz")
+    g = lambda n: f[f"mm_b{bits}_{n}"]
+    fpi, Tp = 32 // bits, 128
+    cases = {
+        "key_none": (g("q"), g("kc"), g("ks"), g("km"), [None], [None], "key"),
+        "key_prefill": (g("q"), np.ascontiguousarray(g("kc")[..., :Tp // fpi]), np.ascontiguousarray(g("ks")[..., :Tp // 64]),
+                        np.ascontiguousarray(g("km")[..., :Tp // 64]), [g("kp0")], [g("kq0")], "key"),
+        "key_stacked": (g("q"), g("kc"), g("ks"), g("km"), [g("kp0"), g("kp1")], [g("kq0"), g("kq1")], "key"),
+        "value_none": (g("a"), g("vc"), g("vs"), g("vm"), [None], [None], "value"),
+        "value_prefill": (g("a_prefill"), np.ascontiguousarray(g("vc")[:, :, :Tp]), np.ascontiguousarray(g("vs")[:, :, :Tp]),
+                          np.ascontiguousarray(g("vm")[:, :, :Tp]), [g("vp0")], [g("vq0")], "value"),
+        "value_stacked": (g("a"), g("vc"), g("vs"), g("vm"), [g("vp0"), g("vp1")], [g("vq0"), g("vq1")], "value"),
+    }
+    for name, (a, code, scale, mn, pb, qb, typ) in cases.items():
+        got = matmul_withlrap(64, a, code, scale, mn, bits, pb, qb, type=typ)
+        ref = g(name).reshape(got.shape)
+        assert rel_fro(got, ref) < 2e-3, (name, rel_fro(got, ref))
