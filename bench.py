@@ -105,6 +105,68 @@ def cpu_baseline(cfg):
     }
 
 
+def block_boundary_cost(cfg, dev, Hl=None):
+    """The decode-time block boundary (every 64 tokens the fp16 window of every layer is compressed in place behind the cache:
+    cuda_supported_gear/modeling_llamagear.py:265-286, :335-378) at the configuration's shapes: the single-launch block compressor
+    (csrc/block_fused.hip) against the kernel chain it replaced, HIP events around back-to-back boundaries on the launch stream.
+    Algorithmic bytes per boundary (SURVEY 8d on n = layers x heads x 64 x 128 elements per tensor kind): read 2n, write codes +
+    scale / mn (fp16) + factors + outlier lists."""
+    from gear_amd import cache as gc
+    H, T, bits, group, rnk, loop, s = (Hl or cfg["kv_heads"]), cfg["T"], cfg["bits"], cfg["group"], cfg["rank"], cfg["loop"], cfg["s"]
+    layers = cfg["layers"]
+    cc = dict(compress_method="gearslKIVI" if s > 0 else "gearlKIVI", group_size=group, residual=64, quantize_bit=bits, rank=rnk,
+              rankv=rnk, loop=loop, left=s)
+    out = {}
+    tcap = min(T + 256, 16384)
+    t_at = (min(T, tcap - 128) // 64) * 64 - 64
+    for use_block in (True, False):
+        gc.USE_BLOCK_KERNEL = use_block
+        try:
+            pool = gc.GearKVCachePool(layers, 1, H, tcap, cc, dev, seed=1, heads_total=cfg["kv_heads"])
+            caches = [gc.GearKVCache(1, H, tcap, cc, dev, pool=pool, layer=l, heads_total=cfg["kv_heads"]) for l in range(layers)]
+            torch.manual_seed(0)
+            pool.buf["kwin"].copy_(torch.randn(pool.buf["kwin"].shape, device=dev, dtype=torch.float16))
+            pool.buf["vwin"].copy_(torch.randn(pool.buf["vwin"].shape, device=dev, dtype=torch.float16))
+            kk0 = min(pool.dims["kk0_max"], t_at // 2) if pool.dims["kk_blk"] else 0
+            for c in caches:
+                c.seg0, c.kk0 = t_at, kk0
+
+            def once():
+                for c in caches:
+                    c.n_comp, c.n_win = t_at, 64
+                pool.compress_all()
+            for _ in range(3):
+                once()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                once()
+            e1.record()
+            torch.cuda.synchronize()
+            out["block_kernel_us" if use_block else "chain_us"] = e0.elapsed_time(e1) / reps * 1e3
+            if use_block:
+                d = pool.dims
+                n = layers * H * 64 * D
+                alg = 2 * (2 * n) + 2 * (n * bits / 8 + 4 * n / group) + 2 * 2 * rnk * (64 + D) * layers * H \
+                    + layers * H * D * 2 * d["kk_blk"] * 4 + layers * 64 * 2 * d["kv"] * 4
+                out["one_launch"] = bool(H >= gc.BLOCK_KERNEL_MIN_HEADS or not d["kv"])
+                out["alg_bytes"] = alg
+                out["outliers_per_side"] = {"k_block_row": d["kk_blk"], "v_row": d["kv"]}
+            del pool, caches
+        finally:
+            gc.USE_BLOCK_KERNEL = True
+        torch.cuda.empty_cache()
+    out["achieved_GBps"] = out["alg_bytes"] / (out["block_kernel_us"] * 1e-6) / 1e9
+    out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
+    out["shape"] = f"{layers} layers x {H} KV heads x 64 tokens x {D}, K and V, at context {t_at}"
+    out["kernel"] = "block_compress_kernel (one launch: V row selection + K / V tiles + low-rank step)" if out["one_launch"] else \
+        "kernel chain (fewer than 4 KV heads per rank: the row duties would serialize)"
+    out["amortized_us_per_token"] = out["block_kernel_us"] / 64
+    return out
+
+
 def attn_decode_by_batch(cfg, dev):
     """One layer's decode attention over the streaming cache (GearKVCache: 2-bit codes + per-block factors + outlier tiles + fp16
     window) at batch 1, 4, 16: time per call and compressed bytes per second.  The decode leg runs batch 1; this shows how far
@@ -433,9 +495,9 @@ def main():
         kx["achieved"] = kx["alg_bytes"] / (kx["ms"] * 1e-3) / 1e9 if kx["ms"] else None
         kx["frac"] = kx["achieved"] / HBM_PEAK_GBS if kx["ms"] else None
     dom = max(kernels[:3], key=lambda kx: kx["ms"])
-    # HBM bytes from PMC counters: only from a profile taken on exactly this library (profiles/r2_traffic.json)
+    # HBM bytes from PMC counters: only from a profile taken on exactly this library (profiles/r3_traffic.json)
     traffic, tnote = None, "no profile for this library build"
-    tp = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r3_traffic.json")
     if os.path.exists(tp) and world == 1 and not args.layers and not args.emulate_world:
         prof = json.load(open(tp))
         if prof.get("lib_sha256") == lib_sha256() and prof.get("config") == args.config:
@@ -444,13 +506,25 @@ def main():
                    if kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")]
             # (both instantiations of the wave-per-row kernel -- fast and fallback pass -- share the base name and are added up)
             if hit:
-                traffic, tnote = float(sum(hit)), f"profiles/r2_traffic.json ({prof.get('how', '')})"
+                traffic, tnote = float(sum(hit)), f"profiles/r3_traffic.json ({prof.get('how', '')})"
         else:
-            tnote = "profiles/r2_traffic.json was measured on a different library build / config"
-    roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            tnote = "profiles/r3_traffic.json was measured on a different library build / config"
+    dominant = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac"], "traffic": traffic, "traffic_source": tnote, "alg_bytes_per_launch": dom["alg_bytes"],
                 "ms_per_launch": dom["ms"],
-                "bytes_definition": "SURVEY.md 8(d): read 2n + codes n*b/8 + scale/mn 8n/g + outliers; no error term",
+                "note": "timed alone, back to back on one stream; inside the bench step the K and V chains share the chip on two "
+                        "streams and the same kernel takes longer (profiles/r3_kernel_stats_bench.md vs r3_kernel_stats_isolated.md)"}
+    # the headline roofline object is what north_star names -- the fused K / V quant + low-rank + outlier COMPRESS, i.e. the chain
+    # of launches per tensor kind -- not its fastest member: the chain with the lower fraction
+    cname = min(("k_compress", "v_compress"), key=lambda c: chain[c]["frac"])
+    launches = {"k_compress": "k_select_kernel + k_select_fix_kernel + k_main_kernel + k_solve_kernel + k_qpass_kernel",
+                "v_compress": "compress_rows_wave_kernel (fast + fallback pass) + lr_gram_solve_kernel + lr_qpass_tm_mfma_kernel"}
+    roofline = {"bound": "hbm", "kernel": f"{cname} chain: {launches[cname]}", "achieved": chain[cname]["achieved"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chain[cname]["frac"], "traffic": None,
+                "traffic_source": "per kernel under `kernels` / profiles/r3_pmc_traffic.md", "alg_bytes_per_launch": chain[cname]["alg_bytes"],
+                "ms_per_launch": chain[cname]["ms"], "launch": "one chain = one call of gear_compress_%s_fused over all layers" % ("key" if cname == "k_compress" else "value"),
+                "bytes_definition": "SURVEY.md 8(d): read 2n + codes n*b/8 + scale/mn 8n/g + factors + outliers; no error term",
+                "dominant_kernel": dominant,
                 "spread": "the same binary measures within +-4 % from box to box (round-1 observation, DESIGN.md section 6)"}
 
     # ---- decompress-into-attention: one decode token's attention over the compressed cache of ALL layers
@@ -511,6 +585,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg)
     del K, V, kr, vr, pk, pv, out, qv
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.layers:
+        res["block_boundary"] = block_boundary_cost(cfg, dev, Hl)
     if rank == 0 and world == 1 and not args.layers and not args.emulate_world:
         res["attn_decode"]["one_layer_streaming_cache_by_batch"] = attn_decode_by_batch(cfg, dev)
     if not args.no_decode and not args.layers and not args.emulate_world:
@@ -521,6 +597,8 @@ def main():
             dec["tokens_per_s"] = 1.0 / float(t.item())
             dec["ms_per_token"] = 1e3 * float(t.item())
         if rank == 0:
+            if "block_boundary" in res:
+                dec["block_compress_ms"] = res["block_boundary"]["block_kernel_us"] * 1e-3
             res["decode"] = dec
     if rank == 0:
         print(json.dumps(res))

@@ -21,11 +21,11 @@
 //   on that span only.  (The chain iterates on the 128 x 128 matrix E^T E, which is the cheaper side only for T > 128.)
 //
 //   V outliers are selected per TOKEN ROW ACROSS THE HEADS (gears_tokenQ, compress_function.py:297-333), i.e. across tiles.
-//   The first NB*H workgroups (the K tiles) each do `rows_per_blk` "row duties" before their tile: one wave reads one token
+//   Every workgroup does `rows_per_blk` "row duties" before its tile: one wave reads one token
 //   row of all H heads, finds the exact top / bottom-kv sets (16-round bisection on the 16-bit order key, both sides at once;
 //   ties by index), writes the sorted lists, the chunk index bytes and -- write-through -- a 128-bit outlier mask per (row,
-//   head) and the row mean, then raises the row's flag.  The V tiles (the LAST NB*H workgroups, so their producers have lower
-//   block ids) poll the 64 flags of their rows -- lane = token = row -- and read mask and mean with agent-scope loads.  A poll
+//   head) and the row mean, then raises the row's flag.  The V tiles (the LAST NB*H workgroups) poll the 64 flags of their
+//   rows -- lane = token = row -- and read mask and mean with agent-scope loads.  A poll
 //   that outlasts its bound sets the status word instead of hanging the GPU.
 #include "common.h"
 #include "lowrank_solve.h"
@@ -86,30 +86,47 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
     const uint32_t* xrow = (const uint32_t*)(a.vwin + ((int64_t)nb * H * a.wcap + t) * KD) + lane;      // + h * wcap * 64 words
     const int64_t hstride = (int64_t)a.wcap * (KD / 2);
     double s = 0.0;
-#pragma unroll 4
-    for (int h = 0; h < H; h++) {
-        const uint32_t w = xrow[h * hstride];
-        s += (double)h2f_bits((uint16_t)(w & 0xFFFFu)) + (double)h2f_bits((uint16_t)(w >> 16));
-        kw[h * 64 + lane] = sort_key16(w & 0xFFFFu) | (sort_key16(w >> 16) << 16);
+#pragma unroll 1
+    for (int h0 = 0; h0 < H; h0 += 8) {              // eight heads' loads in flight at a time
+        uint32_t w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w8[j] = (h0 + j < H) ? xrow[(h0 + j) * hstride] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (h0 + j < H) {
+                s += (double)h2f_bits((uint16_t)(w8[j] & 0xFFFFu)) + (double)h2f_bits((uint16_t)(w8[j] >> 16));
+                kw[(h0 + j) * 64 + lane] = sort_key16(w8[j] & 0xFFFFu) | (sort_key16(w8[j] >> 16) << 16);
+            }
+        }
     }
+    const int H8 = (H + 7) & ~7;
+    for (int h = H; h < H8; h++) kw[h * 64 + lane] = 0u;        // padding words: key 0 (below every finite value's key)
     s = wave_sum_f64(s);
     const float mean = (float)(s / (double)(H * KD));
     const int row = nb * 64 + t;
     // ---- thresholds: large side = the largest K with #{key >= K} >= kv; small side = the smallest K with #{key <= K} >= kv
     // Wave-wide counts through the scalar unit: one compare per key (the high halves as 32-bit compares against the threshold
-    // shifted up, the low halves as 16-bit compares), ballot -> s_bcnt1 -> scalar add.  (The first version counted per lane with
-    // packed min / max / xor and reduced across the wave every round: twice the vector instructions plus a DPP scan per round.)
+    // shifted up, the low halves as 16-bit compares), ballot -> s_bcnt1 -> scalar add, eight words per trip with their LDS reads
+    // issued together (the ballots are convergent operations: the compiler does not unroll a loop around them by itself, and one
+    // word per trip -- read, wait, four compares, four scalar counts -- made this function 60 us of a 200 us kernel).  The padding
+    // keys are never >= a threshold (thresholds start at 1) and always <= one: their count is taken off the small side.
+    const uint32_t padle = (uint32_t)(2 * (H8 - H) * 64);
     auto counts = [&](uint32_t midL, uint32_t midS) -> uint32_t {   // (#{key >= midL}) | (#{key <= midS}) << 16 over the row
         const uint32_t upL = midL << 16, upS = (midS << 16) | 0xFFFFu;
         const uint16_t loLv = (uint16_t)midL, loSv = (uint16_t)midS;
         uint32_t nL = 0u, nS = 0u;
-#pragma unroll 8
-        for (int h = 0; h < H; h++) {
-            const uint32_t k2 = kw[h * 64 + lane];
-            nL += (uint32_t)__popcll(__ballot(k2 >= upL)) + (uint32_t)__popcll(__ballot((uint16_t)k2 >= loLv));
-            nS += (uint32_t)__popcll(__ballot(k2 <= upS)) + (uint32_t)__popcll(__ballot((uint16_t)k2 <= loSv));
+#pragma unroll 1
+        for (int h0 = 0; h0 < H8; h0 += 8) {
+            uint32_t k8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) k8[j] = kw[(h0 + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                nL += (uint32_t)__popcll(__ballot(k8[j] >= upL)) + (uint32_t)__popcll(__ballot((uint16_t)k8[j] >= loLv));
+                nS += (uint32_t)__popcll(__ballot(k8[j] <= upS)) + (uint32_t)__popcll(__ballot((uint16_t)k8[j] <= loSv));
+            }
         }
-        return nL | (nS << 16);
+        return nL | ((nS - padle) << 16);
     };
     uint32_t loL = 1u, hiL = 0xFFFFu, loS = 0u, hiS = 0xFFFFu;
 #pragma unroll 1
@@ -135,44 +152,53 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
     uint32_t mk0 = 0u, mk1 = 0u, mk2 = 0u, mk3 = 0u;             // lane h keeps head h's mask
     uint32_t chS = 0u, chL = 0u;                                  // lane h keeps the list positions at the start of head h
 #pragma unroll 1
-    for (int h = 0; h < H; h++) {
-        const uint32_t k2 = kw[h * 64 + lane];
-        const uint32_t xw = xrow[h * hstride];
-        const uint32_t kA = k2 & 0xFFFFu, kB = k2 >> 16;
-        bool sLA = kA > vL, sLB = kB > vL, sSA = kA < vS, sSB = kB < vS;
-        const bool eLA = kA == vL, eLB = kB == vL, eSA = kA == vS, eSB = kB == vS;
-        if (part) {
-            const uint32_t c = (uint32_t)((eLA ? 1 : 0) + (eLB ? 1 : 0)) | ((uint32_t)((eSA ? 1 : 0) + (eSB ? 1 : 0)) << 16);
-            const uint32_t inc = wave_incl_scan_u32(c);
-            const uint32_t exc = inc - c;
-            const int rL = tieL + (int)(exc & 0xFFFFu), rS = tieS + (int)(exc >> 16);
-            sLA |= eLA && rL < needL;
-            sLB |= eLB && (rL + (eLA ? 1 : 0)) < needL;
-            sSA |= eSA && rS < needS;
-            sSB |= eSB && (rS + (eSA ? 1 : 0)) < needS;
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            tieL += (int)(tot & 0xFFFFu);
-            tieS += (int)(tot >> 16);
-        } else {
-            sLA |= eLA; sLB |= eLB; sSA |= eSA; sSB |= eSB;
+    for (int h0 = 0; h0 < H; h0 += 8) {              // the values of eight heads are loaded together (an L2 round trip per head
+        uint32_t xw8[8];                              // in a dependent loop was most of this function's time)
+#pragma unroll
+        for (int j = 0; j < 8; j++) xw8[j] = (h0 + j < H) ? xrow[(h0 + j) * hstride] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int h = h0 + j;
+            if (h < H) {
+                const uint32_t k2 = kw[h * 64 + lane];
+                const uint32_t xw = xw8[j];
+                const uint32_t kA = k2 & 0xFFFFu, kB = k2 >> 16;
+                bool sLA = kA > vL, sLB = kB > vL, sSA = kA < vS, sSB = kB < vS;
+                const bool eLA = kA == vL, eLB = kB == vL, eSA = kA == vS, eSB = kB == vS;
+                if (part) {
+                    const uint32_t c = (uint32_t)((eLA ? 1 : 0) + (eLB ? 1 : 0)) | ((uint32_t)((eSA ? 1 : 0) + (eSB ? 1 : 0)) << 16);
+                    const uint32_t inc = wave_incl_scan_u32(c);
+                    const uint32_t exc = inc - c;
+                    const int rL = tieL + (int)(exc & 0xFFFFu), rS = tieS + (int)(exc >> 16);
+                    sLA |= eLA && rL < needL;
+                    sLB |= eLB && (rL + (eLA ? 1 : 0)) < needL;
+                    sSA |= eSA && rS < needS;
+                    sSB |= eSB && (rS + (eSA ? 1 : 0)) < needS;
+                    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    tieL += (int)(tot & 0xFFFFu);
+                    tieS += (int)(tot >> 16);
+                } else {
+                    sLA |= eLA; sLB |= eLB; sSA |= eSA; sSB |= eSB;
+                }
+                const uint32_t c = (uint32_t)((sLA ? 1 : 0) + (sLB ? 1 : 0)) | ((uint32_t)((sSA ? 1 : 0) + (sSB ? 1 : 0)) << 16);
+                const uint32_t inc = wave_incl_scan_u32(c);
+                const uint32_t exc = inc - c;
+                int pL = baseL + (int)(exc & 0xFFFFu), pS = baseS + (int)(exc >> 16);
+                const uint16_t col = (uint16_t)(h * KD + 2 * lane);
+                if (sSA) { oi[pS] = col; ov[pS] = (uint16_t)(xw & 0xFFFFu); pS++; }
+                if (sSB) { oi[pS] = (uint16_t)(col + 1); ov[pS] = (uint16_t)(xw >> 16); }
+                if (sLA) { oi[kv + pL] = col; ov[kv + pL] = (uint16_t)(xw & 0xFFFFu); pL++; }
+                if (sLB) { oi[kv + pL] = (uint16_t)(col + 1); ov[kv + pL] = (uint16_t)(xw >> 16); }
+                const uint64_t bA = __ballot(sLA || sSA), bB = __ballot(sLB || sSB);
+                if (lane == h) {
+                    mk0 = (uint32_t)bA; mk1 = (uint32_t)(bA >> 32); mk2 = (uint32_t)bB; mk3 = (uint32_t)(bB >> 32);
+                    chS = (uint32_t)baseS; chL = (uint32_t)baseL;
+                }
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                baseL += (int)(tot & 0xFFFFu);
+                baseS += (int)(tot >> 16);
+            }
         }
-        const uint32_t c = (uint32_t)((sLA ? 1 : 0) + (sLB ? 1 : 0)) | ((uint32_t)((sSA ? 1 : 0) + (sSB ? 1 : 0)) << 16);
-        const uint32_t inc = wave_incl_scan_u32(c);
-        const uint32_t exc = inc - c;
-        int pL = baseL + (int)(exc & 0xFFFFu), pS = baseS + (int)(exc >> 16);
-        const uint16_t col = (uint16_t)(h * KD + 2 * lane);
-        if (sSA) { oi[pS] = col; ov[pS] = (uint16_t)(xw & 0xFFFFu); pS++; }
-        if (sSB) { oi[pS] = (uint16_t)(col + 1); ov[pS] = (uint16_t)(xw >> 16); }
-        if (sLA) { oi[kv + pL] = col; ov[kv + pL] = (uint16_t)(xw & 0xFFFFu); pL++; }
-        if (sLB) { oi[kv + pL] = (uint16_t)(col + 1); ov[kv + pL] = (uint16_t)(xw >> 16); }
-        const uint64_t bA = __ballot(sLA || sSA), bB = __ballot(sLB || sSB);
-        if (lane == h) {
-            mk0 = (uint32_t)bA; mk1 = (uint32_t)(bA >> 32); mk2 = (uint32_t)bB; mk3 = (uint32_t)(bB >> 32);
-            chS = (uint32_t)baseS; chL = (uint32_t)baseL;
-        }
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        baseL += (int)(tot & 0xFFFFu);
-        baseS += (int)(tot >> 16);
     }
     if (lane == H) { chS = (uint32_t)kv; chL = (uint32_t)kv; }
     if (a.vochunk && lane <= H) {
@@ -212,13 +238,21 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
     const int n = lane & 31, kg = lane >> 5;
     union U { uint4 u; half8_t h; };
     // ---- P0 -> LDS as matrix-core operand (head + remainder)
-    for (int idx = lane; idx < KD * RP; idx += 64) {
-        const int k = idx / RP, m = idx % RP;
-        const float w = (m < r) ? P0h[k * r + m] : 0.0f;
-        const uint16_t hi = f2h_bits(w);
-        const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
-        Ah[pos] = hi;
-        Al[pos] = f2h_bits(w - h2f_bits(hi));
+    {
+        float pw[2 * RP];                       // 128 * RP / 64 values per lane, their loads in flight together
+#pragma unroll
+        for (int i = 0; i < 2 * RP; i++) {
+            const int idx = lane + 64 * i, k = idx / RP, m = idx % RP;
+            pw[i] = (m < r) ? P0h[k * r + m] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * RP; i++) {
+            const int idx = lane + 64 * i, k = idx / RP, m = idx % RP;
+            const uint16_t hi = f2h_bits(pw[i]);
+            const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
+            Ah[pos] = hi;
+            Al[pos] = f2h_bits(pw[i] - h2f_bits(hi));
+        }
     }
     __syncthreads();
     // ---- Y0 = E P0: C[m = rank column][n = token]; both halves stay in registers until the operand bytes are dead
@@ -427,15 +461,18 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
     uint16_t* P_out = nullptr;
     uint16_t* Q_out = nullptr;
 
-    if (isK) {
-        // ---------------------------------------------------------------- V row duties of this workgroup
-        if (a.kv > 0) {
-            for (int j = 0; j < a.rows_per_blk; j++) {
-                const int64_t row = bh * a.rows_per_blk + j;
-                if (row >= (int64_t)a.NB * 64) break;
-                vrow_select(a, tw, (int)(row >> 6), (int)(row & 63), lane);
-            }
+    // ---------------------------------------------------------------- V row duties: every workgroup, before its tile
+    // (a row duty never waits, so the V tiles -- which then wait for their 64 rows -- cannot starve a producer: the rows of
+    // group nb belong to workgroups around 64 nb / rows_per_blk, all of which start, do their rows first and are dispatched
+    // before or at most 63 workgroups after the waiting tile)
+    if (a.kv > 0) {
+        for (int j = 0; j < a.rows_per_blk; j++) {
+            const int64_t row = (int64_t)blockIdx.x * a.rows_per_blk + j;
+            if (row >= (int64_t)a.NB * 64) break;
+            vrow_select(a, tw, (int)(row >> 6), (int)(row & 63), lane);
         }
+    }
+    if (isK) {
         // ---------------------------------------------------------------- K tile: lane = channel pair
         constexpr int NG = 64 / G;
         const uint16_t* xb = a.kwin + bh * (int64_t)a.wcap * KD;
@@ -482,10 +519,12 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
         }
         const uint64_t oA = cLA | cSA, oB = cLB | cSB;
         float dqA[NG], dqB[NG];                   // what the attention reconstructs at a filled position of group gi
+        QuantParams<0> qAs[NG], qBs[NG];
         uint32_t* codeA = a.kcode + (bh * KD + 2 * lane) * a.ldk + tok0 / CPW;
         uint32_t* codeB = codeA + a.ldk;
         uint16_t* sclA = a.kscale + (bh * KD + 2 * lane) * a.lsk + tok0 / G;
         uint16_t* mnlA = a.kmn + (bh * KD + 2 * lane) * a.lsk + tok0 / G;
+        // ---- pass 1: the groups' parameters
 #pragma unroll
         for (int gi = 0; gi < NG; gi++) {
             float loA = INFINITY, hiA = -INFINITY, loB = INFINITY, hiB = -INFINITY;
@@ -498,32 +537,15 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
                 loA = fminf(loA, va); hiA = fmaxf(hiA, va);
                 loB = fminf(loB, vb); hiB = fmaxf(hiB, vb);
             }
-            const QuantParams<0> qA = make_qparams<0>(loA, hiA, LEVELS), qB = make_qparams<0>(loB, hiB, LEVELS);
-            sclA[gi] = f2h_bits(qA.scale); mnlA[gi] = f2h_bits(qA.mn);
-            sclA[a.lsk + gi] = f2h_bits(qB.scale); mnlA[a.lsk + gi] = f2h_bits(qB.mn);
-            dqA[gi] = fmaf(qA.scale, (float)quant_one<0>(fillA, qA), qA.mn);
-            dqB[gi] = fmaf(qB.scale, (float)quant_one<0>(fillB, qB), qB.mn);
-#pragma unroll 1
-            for (int wd = 0; wd < G / CPW; wd++) {
-                uint32_t cwA = 0u, cwB = 0u;
-#pragma unroll 4
-                for (int jj = 0; jj < CPW; jj++) {
-                    const int tk = gi * G + wd * CPW + jj;
-                    const uint32_t w = tw[tk * WP + lane];
-                    const bool isoA = ((oA >> tk) & 1ull) != 0ull, isoB = ((oB >> tk) & 1ull) != 0ull;
-                    const float va = isoA ? fillA : h2f_bits((uint16_t)(w & 0xFFFFu)), vb = isoB ? fillB : h2f_bits((uint16_t)(w >> 16));
-                    const int qa = quant_one<0>(va, qA), qb = quant_one<0>(vb, qB);
-                    cwA |= (uint32_t)qa << (BITS * jj);
-                    cwB |= (uint32_t)qb << (BITS * jj);
-                    const float ea = isoA ? 0.0f : (va - dequant_one<0>(qa, qA.scale, qA.mn));
-                    const float eb = isoB ? 0.0f : (vb - dequant_one<0>(qb, qB.scale, qB.mn));
-                    tw[tk * WP + lane] = (uint32_t)f2h_bits(ea) | ((uint32_t)f2h_bits(eb) << 16);      // the error, in place
-                }
-                codeA[gi * (G / CPW) + wd] = cwA;
-                codeB[gi * (G / CPW) + wd] = cwB;
-            }
+            qAs[gi] = make_qparams<0>(loA, hiA, LEVELS);
+            qBs[gi] = make_qparams<0>(loB, hiB, LEVELS);
+            sclA[gi] = f2h_bits(qAs[gi].scale); mnlA[gi] = f2h_bits(qAs[gi].mn);
+            sclA[a.lsk + gi] = f2h_bits(qBs[gi].scale); mnlA[a.lsk + gi] = f2h_bits(qBs[gi].mn);
+            dqA[gi] = fmaf(qAs[gi].scale, (float)quant_one<0>(fillA, qAs[gi]), qAs[gi].mn);
+            dqB[gi] = fmaf(qBs[gi].scale, (float)quant_one<0>(fillB, qBs[gi]), qBs[gi].mn);
         }
-        // ---- sparse part: sorted lists (slot 0 = smallest, slot 1 = largest) + this block's entries of the 128-token tile
+        // ---- sparse part (x is still in the LDS tile): sorted lists (slot 0 = smallest, slot 1 = largest) + this block's entries
+        // of the 128-token tile
         if (kk > 0) {
             const int chunk = tok0 >> 7, tin = tok0 & 127;
             int tbase = -1;                       // first tile entry of this block (-1: the tile is not maintained / overflowed)
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
                     while (m) {
                         const int tk = __builtin_ctzll(m);
                         m &= m - 1ull;
-                        const uint16_t vb = xb[tk * KD + ch];
+                        const uint16_t vb = (uint16_t)(tw[tk * WP + lane] >> (16 * h));
                         a.koidx[lbase + pos] = (uint16_t)(tok0 + tk);
                         a.koval[lbase + pos] = vb;
                         if (tbase >= 0) {
@@ -559,6 +581,30 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
                         pos++;
                     }
                 }
+            }
+        }
+        // ---- pass 2: codes, packed along T, and the error in place of x
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) {
+            const QuantParams<0> qA = qAs[gi], qB = qBs[gi];
+#pragma unroll 1
+            for (int wd = 0; wd < G / CPW; wd++) {
+                uint32_t cwA = 0u, cwB = 0u;
+#pragma unroll 4
+                for (int jj = 0; jj < CPW; jj++) {
+                    const int tk = gi * G + wd * CPW + jj;
+                    const uint32_t w = tw[tk * WP + lane];
+                    const bool isoA = ((oA >> tk) & 1ull) != 0ull, isoB = ((oB >> tk) & 1ull) != 0ull;
+                    const float va = isoA ? fillA : h2f_bits((uint16_t)(w & 0xFFFFu)), vb = isoB ? fillB : h2f_bits((uint16_t)(w >> 16));
+                    const int qa = quant_one<0>(va, qA), qb = quant_one<0>(vb, qB);
+                    cwA |= (uint32_t)qa << (BITS * jj);
+                    cwB |= (uint32_t)qb << (BITS * jj);
+                    const float ea = isoA ? 0.0f : (va - dequant_one<0>(qa, qA.scale, qA.mn));
+                    const float eb = isoB ? 0.0f : (vb - dequant_one<0>(qb, qB.scale, qB.mn));
+                    tw[tk * WP + lane] = (uint32_t)f2h_bits(ea) | ((uint32_t)f2h_bits(eb) << 16);      // the error, in place
+                }
+                codeA[gi * (G / CPW) + wd] = cwA;
+                codeB[gi * (G / CPW) + wd] = cwB;
             }
         }
         r = a.rk;
@@ -632,6 +678,20 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
             const QuantParams<0> qp = make_qparams<0>(lo, hi, LEVELS);
             a.vscale[prow * NGV + gi] = f2h_bits(qp.scale);
             a.vmn[prow * NGV + gi] = f2h_bits(qp.mn);
+            if (tiles && tile_ok) {                  // (before pass 2 replaces x by the error)
+                const float dqv = fmaf(qp.scale, (float)quant_one<0>(fill, qp), qp.mn);
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    uint32_t m = par ? gO : gE;
+                    while (m) {
+                        const int w = __builtin_ctz(m);
+                        m &= m - 1u;
+                        const int d = gi * G + 2 * w + par;
+                        vt[pos++] = (uint32_t)lane | ((uint32_t)d << 6) |
+                                    ((uint32_t)f2h_bits(h2f_bits(tile[lane * ET_PITCH + d]) - dqv) << 16);
+                    }
+                }
+            }
             uint32_t cw = 0u;
 #pragma unroll 2
             for (int jj = 0; jj < G / 8; jj++) {
@@ -652,19 +712,6 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
                 else {
                     cw |= bits << (16 * (jj & 1));
                     if (jj & 1) { cp[(gi * (G / 8) + jj) >> 1] = cw; cw = 0u; }
-                }
-            }
-            if (tiles && tile_ok) {
-                const float dqv = fmaf(qp.scale, (float)quant_one<0>(fill, qp), qp.mn);
-#pragma unroll
-                for (int par = 0; par < 2; par++) {
-                    uint32_t m = par ? gO : gE;
-                    while (m) {
-                        const int w = __builtin_ctz(m);
-                        m &= m - 1u;
-                        const int d = gi * G + 2 * w + par;
-                        vt[pos++] = (uint32_t)lane | ((uint32_t)d << 6) | ((uint32_t)f2h_bits(h2f_bits(xrow[d]) - dqv) << 16);
-                    }
                 }
             }
         }
@@ -739,7 +786,7 @@ extern "C" int gear_compress_block(const gear_cache_view* c, int t_off, int o_of
     uint32_t ep = __atomic_add_fetch(&g_block_epoch, 1u, __ATOMIC_RELAXED);
     if (ep == 0u) ep = __atomic_add_fetch(&g_block_epoch, 1u, __ATOMIC_RELAXED);
     a.epoch = ep;
-    a.rows_per_blk = (int)((NB * 64 + NB * H - 1) / (NB * H));
+    a.rows_per_blk = (int)((NB * 64 + 2 * NB * H - 1) / (2 * NB * H));     // every workgroup (K and V tiles) takes its share
     const int rmax = a.rk > a.rv ? a.rk : a.rv;
     const int RP = rmax <= 4 ? 4 : (rmax <= 8 ? 8 : 16);
     const size_t shmem = (size_t)64 * ET_PITCH * 2 + (rmax > 0 ? blk_lr_lds_bytes(RP) : 0);

@@ -32,6 +32,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib as L
 from .quant.matmul import cuda_bmm_fA_qB_outer
 from .quant.new_pack import (headwise_lrap, triton_quantize_and_pack_along_last_dim,
                              triton_quantize_and_pack_along_last_dim_witherror)
@@ -104,38 +105,43 @@ def _rep(t: torch.Tensor, n_rep: int) -> torch.Tensor:
 
 
 def matmul_withlrap(group_size, a, b, scale, mn, bits, pbase: list, qbase: list, type="key"):
-    """modeling_llamagear.py:54-111: fused dequant GEMV + low-rank correction.
+    """modeling_llamagear.py:54-111: dequant GEMV + low-rank correction -- here ONE call into the HIP library
+    (gear_gemv_outer_lrap: the GEMV kernel writes fp32 partial sums, its split-K epilogue adds the factor terms and rounds once)
+    where the reference adds the correction with ~8 eager matmul / permute / slice-assign launches.
 
-    a [B,Hq,1,K] fp16; b packed [B,Hkv,K,N/fpi]; type "key": K = head_dim, N = compressed tokens;
-    type "value": K = compressed tokens, N = head_dim.  pbase / qbase: [None] | [prefill] | [prefill, stacked]."""
-    result1 = cuda_bmm_fA_qB_outer(group_size, a, b, scale, mn, bits)
+    a [B,Hq,1,K] fp16; b packed [B,Hkv,K,N/fpi]; type "key": K = head_dim, N = compressed tokens; type "value": K = compressed
+    tokens, N = head_dim.  pbase / qbase: [None] | [prefill] | [prefill, stacked [nbuf,B,Hkv,.,r]] (:71-85 / :87-108):
+    key P [B,Hkv,T,r] (token side), Q [B,Hkv,D,r]; value P [B,Hkv,D,r], Q [B,Hkv,T,r]."""
     if pbase[0] is None:
-        return result1
-    n_rep = a.shape[1] // b.shape[1]
-    if type == "key":
-        # scores += (a Q0) P0^T over the prefill tokens, (a Q1[i]) P1[i]^T over each decode block (:71-85)
-        result3 = (a @ _rep(qbase[0], n_rep)) @ _rep(pbase[0], n_rep).transpose(2, 3)
-        prefill_length = pbase[0].shape[-2]
-        if len(pbase) == 1:
-            return result1 + result3
-        result1[:, :, :, :prefill_length] = result1[:, :, :, :prefill_length] + result3
-        result4 = a.unsqueeze(0) @ _rep(qbase[1], n_rep) @ _rep(pbase[1], n_rep).transpose(3, 4)
-        buffer_num, bsz, num_head, q_len, seq_len_buffer = result4.shape
-        result4 = result4.permute(1, 2, 3, 0, 4).reshape(bsz, num_head, q_len, buffer_num * seq_len_buffer)
-        result1[:, :, :, prefill_length:] = result1[:, :, :, prefill_length:] + result4
-        return result1
-    # value: out += (a[:, :Tp] Q0) P0^T + sum_blocks (a_blk Q1[i]) P1[i]^T (:87-108)
-    prefill_length = qbase[0].shape[-2]
-    result3 = (a[:, :, :, :prefill_length] @ _rep(qbase[0], n_rep)) @ _rep(pbase[0], n_rep).transpose(2, 3)
-    result1 = result1 + result3
-    if len(pbase) == 1:
-        return result1
-    buffer_length = qbase[1].shape[-2]
-    generated_a = a[:, :, :, prefill_length:]
-    bsz, num_head, q_len, _ = generated_a.shape
-    generated_a = generated_a.reshape(bsz, num_head, q_len, -1, buffer_length).permute(3, 0, 1, 2, 4)
-    result4 = generated_a @ _rep(qbase[1], n_rep) @ _rep(pbase[1], n_rep).transpose(3, 4)
-    return result1 + result4.sum(dim=0)
+        return cuda_bmm_fA_qB_outer(group_size, a, b, scale, mn, bits)
+    assert type in ("key", "value") and bits in (2, 4) and a.dim() == 4 and b.dim() == 4
+    B, Hq, M, K = a.shape
+    if M != 1:
+        raise L.GearError("matmul_withlrap supports q_len == 1 only (decode GEMV)")
+    Hkv = b.shape[1]
+    N = b.shape[-1] * (32 // bits)
+    p0, q0 = pbase[0].contiguous(), qbase[0].contiguous()
+    r = p0.shape[-1]
+    tp = (p0 if type == "key" else q0).shape[-2]
+    p1 = q1 = None
+    nbuf, blk = 0, 64
+    if len(pbase) > 1:
+        p1, q1 = pbase[1].contiguous(), qbase[1].contiguous()
+        nbuf, blk = p1.shape[0], (p1 if type == "key" else q1).shape[-2]
+    a, b, scale, mn = a.contiguous(), b.contiguous(), scale.contiguous(), mn.contiguous()
+    L.require_gpu(a, b, scale, mn, p0, q0, p1, q1)
+    if any(t is not None and t.dtype != torch.float16 for t in (a, p0, q0, p1, q1)):
+        raise L.GearError("matmul_withlrap: activations and factors must be float16")
+    lib = L.load()
+    BA = B * Hq
+    wsb = lib.gear_gemv_outer_lrap_workspace(BA, K, N, bits)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=a.device)
+    out = torch.empty((B, Hq, 1, N), dtype=torch.float16, device=a.device)
+    rc = lib.gear_gemv_outer_lrap(L.ptr(a), L.ptr(b), L.ptr(scale), L.ptr(mn), BA, Hq // Hkv, K, N, group_size, bits,
+                                  0 if scale.dtype == torch.float16 else 1, 0 if type == "key" else 1, L.ptr(p0), L.ptr(q0), tp,
+                                  L.ptr(p1), L.ptr(q1), nbuf, blk, r, L.ptr(out), L.ptr(ws), wsb, L.stream_ptr(a))
+    L.check(rc, "gear_gemv_outer_lrap")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------- RoPE (Llama)

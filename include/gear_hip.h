@@ -95,6 +95,20 @@ int gear_gemv_outer(const void* a, const void* qB, const void* scale, const void
                     int N, int group, int bits, int mode, int64_t ldq, int64_t lds, void* out, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ---- a7: dequant GEMV + low-rank correction in two launches -------------------------------------------------------------
+ * Replaces matmul_withlrap (cuda_supported_gear/modeling_llamagear.py:54-111): cuda_bmm_fA_qB_outer followed by ~8 eager matmul /
+ * permute / slice-assign launches for the prefill factors (pbase[0], qbase[0]) and the per-block factors stacked on a leading
+ * dim (pbase[1], qbase[1], :71-85 / :87-108).  The GEMV kernel of gear_gemv_outer writes fp32 partial sums; ONE epilogue kernel
+ * reduces them, adds the low-rank terms in fp32 and rounds to fp16 once.
+ *   kind 0 "key":   K = head_dim, N = Tp + nbuf * blk tokens;  P0 [BW, Tp, r], Q0 [BW, K, r];  P1 [nbuf, BW, blk, r], Q1 [nbuf, BW, K, r]
+ *   kind 1 "value": K = Tp + nbuf * blk tokens, N = head_dim;  P0 [BW, N, r], Q0 [BW, Tp, r];  P1 [nbuf, BW, N, r], Q1 [nbuf, BW, blk, r]
+ *   (BW = BA / n_rep KV heads; all factors fp16; nbuf == 0: prefill factors only; dense row pitches.) */
+size_t gear_gemv_outer_lrap_workspace(int64_t BA, int K, int N, int bits);
+int gear_gemv_outer_lrap(const void* a, const void* qB, const void* scale, const void* zero, int64_t BA, int n_rep, int K, int N,
+                         int group, int bits, int mode, int kind, const void* P0, const void* Q0, int Tp, const void* P1,
+                         const void* Q1, int nbuf, int blk, int r, void* out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* ---- a11 (+ a9): one pass per row -- outlier top-k select, mean fill, group quantize, pack, error -------------
  * Replaces gears_channelQ / gears_tokenQ (GenerationBench/.../Simulated/compress_function.py:261-333) and, with
  * k == 0, the fake_groupwise_*_asymmetric_quantization functions (:7-67, :100-160), producing a REAL payload.
