@@ -36,6 +36,8 @@ namespace {
 typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
+constexpr int BT_PITCH = 136;        // halfs per tile row: 272 bytes = 17 x 16 (aligned 16-byte operand reads), 68 words
+
 struct BlkArgs {
     const uint16_t* kwin;    // [NB*H][wcap][128] fp16 window of every (layer*batch, head): the block's K
     const uint16_t* vwin;
@@ -85,21 +87,26 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
     const int H = a.H, kv = a.kv;
     const uint32_t* xrow = (const uint32_t*)(a.vwin + ((int64_t)nb * H * a.wcap + t) * KD) + lane;      // + h * wcap * 64 words
     const int64_t hstride = (int64_t)a.wcap * (KD / 2);
+    const int H8 = (H + 7) & ~7;
+    // the row's words stay in LDS behind the keys when both fit (up to 34 heads): the emission loop then needs no second trip to
+    // global memory (its eight-loads-at-a-time round trips were a third of this function)
+    const bool x_in_lds = 2 * H8 * 64 * 4 <= 64 * BT_PITCH * 2;
+    uint32_t* xs = kw + H8 * 64;
     double s = 0.0;
 #pragma unroll 1
-    for (int h0 = 0; h0 < H; h0 += 8) {              // eight heads' loads in flight at a time
-        uint32_t w8[8];
+    for (int h0 = 0; h0 < H; h0 += 16) {             // sixteen heads' loads in flight at a time
+        uint32_t w16[16];
 #pragma unroll
-        for (int j = 0; j < 8; j++) w8[j] = (h0 + j < H) ? xrow[(h0 + j) * hstride] : 0u;
+        for (int j = 0; j < 16; j++) w16[j] = (h0 + j < H) ? xrow[(h0 + j) * hstride] : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < 16; j++) {
             if (h0 + j < H) {
-                s += (double)h2f_bits((uint16_t)(w8[j] & 0xFFFFu)) + (double)h2f_bits((uint16_t)(w8[j] >> 16));
-                kw[(h0 + j) * 64 + lane] = sort_key16(w8[j] & 0xFFFFu) | (sort_key16(w8[j] >> 16) << 16);
+                s += (double)h2f_bits((uint16_t)(w16[j] & 0xFFFFu)) + (double)h2f_bits((uint16_t)(w16[j] >> 16));
+                kw[(h0 + j) * 64 + lane] = sort_key16(w16[j] & 0xFFFFu) | (sort_key16(w16[j] >> 16) << 16);
+                if (x_in_lds) xs[(h0 + j) * 64 + lane] = w16[j];
             }
         }
     }
-    const int H8 = (H + 7) & ~7;
     for (int h = H; h < H8; h++) kw[h * 64 + lane] = 0u;        // padding words: key 0 (below every finite value's key)
     s = wave_sum_f64(s);
     const float mean = (float)(s / (double)(H * KD));
@@ -155,7 +162,7 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
     for (int h0 = 0; h0 < H; h0 += 8) {              // the values of eight heads are loaded together (an L2 round trip per head
         uint32_t xw8[8];                              // in a dependent loop was most of this function's time)
 #pragma unroll
-        for (int j = 0; j < 8; j++) xw8[j] = (h0 + j < H) ? xrow[(h0 + j) * hstride] : 0u;
+        for (int j = 0; j < 8; j++) xw8[j] = (h0 + j < H) ? (x_in_lds ? xs[(h0 + j) * 64 + lane] : xrow[(h0 + j) * hstride]) : 0u;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int h = h0 + j;
@@ -218,60 +225,75 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
 }
 
 // ================================================================================================ low-rank step on the LDS tile
-__host__ __device__ constexpr size_t blk_lr_lds_bytes(int RP) {      // behind the error tile
-    return (size_t)2 * 64 * RP * 4 + (size_t)3 * RP * RP * 8;
+// LDS plan (RP = 8: 20 480 bytes per tile with the 136-half row pitch, i.e. eight tiles per CU -- all 2048 tiles of a Llama-2-7B
+// boundary resident at once; the first version's 28 KB gave five per CU and two rounds): the tile, ONE [64][RP] float buffer
+// (Y, rewritten in place behind a barrier; at the end it holds Q' as matrix-core operand), R^-1 and R (fp64), and the small
+// Gram matrix in the 16 padding bytes of the tile's rows (RP * RP <= 64 entries).  P0 goes from global memory straight into
+// the A operand registers.
+__host__ __device__ constexpr size_t blk_lr_lds_bytes(int RP) {      // behind the tile
+    return (size_t)64 * RP * 4 + (size_t)2 * RP * RP * 8 + (RP * RP <= 64 ? 0 : (size_t)RP * RP * 8);
 }
 
-// etile: fp16 [64 tokens][ET_PITCH] in LDS (complete, visible).  P0h: float [128][r] of this head (global).  Writes P_out fp16
+// MFMA B operand of lane (x31, kg): channel 32 I + x31, tokens t0 + 8 kg .. + 7, through the transposing LDS read (ktile.h's
+// load_operand with this kernel's row pitch)
+__device__ __forceinline__ half8_t load_operand_bt(const uint16_t* tile, int t0, int I, int lane) {
+    const int kg = lane >> 5, i = lane & 15, c0 = 32 * I + 16 * ((lane >> 4) & 1);
+    const uint16_t* p = tile + (t0 + 8 * kg + (i >> 2)) * BT_PITCH + c0 + 4 * (i & 3);
+    const uint32_t addr = (uint32_t)(uintptr_t)p;
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    short4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * BT_PITCH * 2) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    union { half8_t h; short4v s[2]; } cv;
+    cv.s[0] = lo;
+    cv.s[1] = hi;
+    return cv.h;
+}
+
+// tile: fp16 error [64 tokens][BT_PITCH] in LDS (complete, visible).  P0h: float [128][r] of this head (global).  Writes P_out fp16
 // [128][r] and Q_out fp16 [64][r] (the block's 64 token rows).  One wave.
 template <int RP>
-__device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned char* sm, const float* __restrict__ P0h, int r, int loop,
+__device__ __forceinline__ void lowrank_tile(uint16_t* tile, unsigned char* sm, const float* __restrict__ P0h, int r, int loop,
                                              uint16_t* __restrict__ P_out, uint16_t* __restrict__ Q_out, int lane) {
-    // [64][RP] floats twice (Ya, Yb); the same bytes first hold P0 and at the end Q' as matrix-core operands (fp16 head in the
-    // first half, remainder in the second), [k / 8][m][k % 8]: P0 needs 16 x RP x 8 halves = exactly one Y buffer
-    float* Ya = (float*)sm;
-    float* Yb = Ya + 64 * RP;
-    uint16_t* Ah = (uint16_t*)Ya;
-    uint16_t* Al = (uint16_t*)Yb;
-    double* Md = (double*)(Yb + 64 * RP);               // [RP][RP]
-    double* Rinv = Md + RP * RP;                        // [2][RP][RP]
+    constexpr bool MD_IN_PAD = RP * RP <= 64;
+    constexpr int MDS = MD_IN_PAD ? BT_PITCH / 4 : 1;   // doubles from one Md entry to the next (row padding: one entry per row)
+    float* Y = (float*)sm;                              // [64][RP]
+    uint16_t* Ah = (uint16_t*)Y;                        // at the end: Q' as operand [8][RP][8] halves, head ...
+    uint16_t* Al = Ah + 64 * RP;                        // ... and remainder
+    double* Rinv = (double*)(Y + 64 * RP);              // [2][RP][RP]
+    double* Md = MD_IN_PAD ? (double*)(tile + KD) : Rinv + 2 * RP * RP;
     const int n = lane & 31, kg = lane >> 5;
     union U { uint4 u; half8_t h; };
-    // ---- P0 -> LDS as matrix-core operand (head + remainder)
-    {
-        float pw[2 * RP];                       // 128 * RP / 64 values per lane, their loads in flight together
+    // ---- A operand of Y0 = E P0 from global: lane (m = n < RP, kg) holds P0[16 ks + 8 kg + j][m], j < 8, as head + remainder
+    float pw[8][8];
 #pragma unroll
-        for (int i = 0; i < 2 * RP; i++) {
-            const int idx = lane + 64 * i, k = idx / RP, m = idx % RP;
-            pw[i] = (m < r) ? P0h[k * r + m] : 0.0f;
-        }
+    for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-        for (int i = 0; i < 2 * RP; i++) {
-            const int idx = lane + 64 * i, k = idx / RP, m = idx % RP;
-            const uint16_t hi = f2h_bits(pw[i]);
-            const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
-            Ah[pos] = hi;
-            Al[pos] = f2h_bits(pw[i] - h2f_bits(hi));
-        }
-    }
-    __syncthreads();
-    // ---- Y0 = E P0: C[m = rank column][n = token]; both halves stay in registers until the operand bytes are dead
-    float16_t y0acc[2];
+        for (int j = 0; j < 8; j++) pw[ks][j] = (n < r) ? P0h[(16 * ks + 8 * kg + j) * r + n] : 0.0f;
+    // ---- Y0 = E P0: C[m = rank column][n = token]
 #pragma unroll
     for (int half = 0; half < 2; half++) {
+        float16_t acc;
 #pragma unroll
-        for (int q = 0; q < 16; q++) y0acc[half][q] = 0.0f;
+        for (int q = 0; q < 16; q++) acc[q] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
-            U ah, al, b;
-            ah.u = al.u = make_uint4(0, 0, 0, 0);
-            if (n < RP) {
-                ah.u = *(const uint4*)&Ah[((2 * ks + kg) * RP + n) * 8];
-                al.u = *(const uint4*)&Al[((2 * ks + kg) * RP + n) * 8];
+            union { half8_t h; uint16_t u[8]; } ah, al;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                ah.u[j] = f2h_bits(pw[ks][j]);
+                al.u[j] = f2h_bits(pw[ks][j] - h2f_bits(ah.u[j]));
             }
-            b.u = *(const uint4*)(etile + (32 * half + n) * ET_PITCH + 16 * ks + 8 * kg);
-            y0acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, y0acc[half], 0, 0, 0);
-            y0acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, y0acc[half], 0, 0, 0);
+            U b;
+            b.u = *(const uint4*)(tile + (32 * half + n) * BT_PITCH + 16 * ks + 8 * kg);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b.h, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b.h, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int qb = 0; qb < (RP + 7) / 8; qb++) {
+            const int c0 = 8 * qb + 4 * kg;
+            if (c0 < RP) *(float4*)&Y[(32 * half + n) * RP + c0] = make_float4(acc[4 * qb], acc[4 * qb + 1], acc[4 * qb + 2], acc[4 * qb + 3]);
         }
     }
     // ---- G' = E E^T: g[I][J][q] = G'[32 I + (q & 3) + 8 (q >> 2) + 4 kg][32 J + n]
@@ -282,8 +304,8 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             U f0, f1;
-            f0.u = *(const uint4*)(etile + n * ET_PITCH + 16 * ks + 8 * kg);
-            f1.u = *(const uint4*)(etile + (32 + n) * ET_PITCH + 16 * ks + 8 * kg);
+            f0.u = *(const uint4*)(tile + n * BT_PITCH + 16 * ks + 8 * kg);
+            f1.u = *(const uint4*)(tile + (32 + n) * BT_PITCH + 16 * ks + 8 * kg);
             g00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, f0.h, g00, 0, 0, 0);
             g01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.h, f1.h, g01, 0, 0, 0);
             g10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.h, f0.h, g10, 0, 0, 0);
@@ -291,19 +313,7 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-#pragma unroll
-        for (int qb = 0; qb < (RP + 7) / 8; qb++) {
-            const int c0 = 8 * qb + 4 * kg;
-            if (c0 < RP)
-                *(float4*)&Ya[(32 * half + n) * RP + c0] = make_float4(y0acc[half][4 * qb], y0acc[half][4 * qb + 1], y0acc[half][4 * qb + 2], y0acc[half][4 * qb + 3]);
-        }
-    }
-    __syncthreads();
-    float* cur = Ya;
-    float* oth = Yb;
-    // ---- Y <- G' Y, loop - 1 times (G' symmetric: column 32 J + n of G' = this lane's accumulators over its 32 rows)
+    // ---- Y <- G' Y, loop - 1 times, in place (G' symmetric: column 32 J + n of G' = this lane's accumulators over its 32 rows)
 #pragma unroll 1
     for (int it = 0; it + 1 < loop; it++) {
         float s0[RP], s1[RP];
@@ -317,7 +327,7 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
                 const float ga = I == 0 ? g00[q] : g10[q], gb = I == 0 ? g01[q] : g11[q];
 #pragma unroll
                 for (int c4 = 0; c4 < RP; c4 += 4) {
-                    const float4 y = *(const float4*)&cur[row * RP + c4];
+                    const float4 y = *(const float4*)&Y[row * RP + c4];
                     s0[c4] = fmaf(ga, y.x, s0[c4]); s0[c4 + 1] = fmaf(ga, y.y, s0[c4 + 1]);
                     s0[c4 + 2] = fmaf(ga, y.z, s0[c4 + 2]); s0[c4 + 3] = fmaf(ga, y.w, s0[c4 + 3]);
                     s1[c4] = fmaf(gb, y.x, s1[c4]); s1[c4 + 1] = fmaf(gb, y.y, s1[c4 + 1]);
@@ -330,19 +340,19 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
             s0[c] += __shfl_xor(s0[c], 32, 64);
             s1[c] += __shfl_xor(s1[c], 32, 64);
         }
+        __syncthreads();                                  // every read of the old Y is done
         const int orow = kg == 0 ? n : 32 + n;
 #pragma unroll
         for (int c4 = 0; c4 < RP; c4 += 4)
-            *(float4*)&oth[orow * RP + c4] = kg == 0 ? make_float4(s0[c4], s0[c4 + 1], s0[c4 + 2], s0[c4 + 3])
-                                                      : make_float4(s1[c4], s1[c4 + 1], s1[c4 + 2], s1[c4 + 3]);
+            *(float4*)&Y[orow * RP + c4] = kg == 0 ? make_float4(s0[c4], s0[c4 + 1], s0[c4 + 2], s0[c4 + 3])
+                                                    : make_float4(s1[c4], s1[c4 + 1], s1[c4 + 2], s1[c4 + 3]);
         __syncthreads();
-        float* tp = cur; cur = oth; oth = tp;
     }
     // ---- Q' = orth(Y): CholeskyQR twice, small Gram in fp64; lane = token row
     float yr[RP];
 #pragma unroll
     for (int c4 = 0; c4 < RP; c4 += 4) {
-        const float4 y = *(const float4*)&cur[lane * RP + c4];
+        const float4 y = *(const float4*)&Y[lane * RP + c4];
         yr[c4] = y.x; yr[c4 + 1] = y.y; yr[c4 + 2] = y.z; yr[c4 + 3] = y.w;
     }
 #pragma unroll 1
@@ -351,11 +361,11 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
             const int ca = o / RP, cb = o % RP;
             double sacc = 0.0;
 #pragma unroll 8
-            for (int i = 0; i < 64; i++) sacc += (double)cur[i * RP + ca] * (double)cur[i * RP + cb];
-            Md[o] = sacc;
+            for (int i = 0; i < 64; i++) sacc += (double)Y[i * RP + ca] * (double)Y[i * RP + cb];
+            Md[o * MDS] = sacc;
         }
         __syncthreads();
-        chol_inverse_wave<RP>(Md, Rinv, lane);
+        chol_inverse_wave<RP, MDS>(Md, Rinv, lane);
         __syncthreads();
         float yn[RP];
 #pragma unroll
@@ -368,12 +378,13 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
         }
 #pragma unroll
         for (int c = 0; c < RP; c++) yr[c] = yn[c];
+        if (rep == 0) {
 #pragma unroll
-        for (int c4 = 0; c4 < RP; c4 += 4) *(float4*)&oth[lane * RP + c4] = make_float4(yr[c4], yr[c4 + 1], yr[c4 + 2], yr[c4 + 3]);
+            for (int c4 = 0; c4 < RP; c4 += 4) *(float4*)&Y[lane * RP + c4] = make_float4(yr[c4], yr[c4 + 1], yr[c4 + 2], yr[c4 + 3]);
+        }
         __syncthreads();
-        float* tp = cur; cur = oth; oth = tp;
     }
-    // ---- Q' out (fp16) and as matrix-core operand [k / 8][m][k % 8], k = token
+    // ---- Q' out (fp16) and, over the dead Y, as matrix-core operand [k / 8][m][k % 8], k = token
     {
         uint16_t qh[RP];
 #pragma unroll
@@ -411,7 +422,7 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
         }
 #pragma unroll
         for (int J = 0; J < 4; J++) {
-            const half8_t b = load_operand<true>(etile, 16 * ks, J, lane);
+            const half8_t b = load_operand_bt(tile, 16 * ks, J, lane);
             pacc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, b, pacc[J], 0, 0, 0);
             pacc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, b, pacc[J], 0, 0, 0);
         }
@@ -439,7 +450,7 @@ __device__ __forceinline__ void lowrank_tile(const uint16_t* etile, unsigned cha
 
 // ================================================================================================ the kernel
 // grid 2 * NB * H workgroups of one wave: [0, NB*H) = K tiles (+ the V row duties), [NB*H, 2 NB*H) = V tiles.
-// The tile [64 tokens][ET_PITCH] lives in LDS from the first load to the last matrix-core read: x first, overwritten in place
+// The tile [64 tokens][BT_PITCH] lives in LDS from the first load to the last matrix-core read: x first, overwritten in place
 // by the error; the loops over tokens / channels stay rolled (a first, register-resident version unrolled everything: 75 000
 // instructions per kernel, 117 spilled registers).
 template <int BITS, int G, int RP>
@@ -447,10 +458,10 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
     constexpr int CPW = 32 / BITS;
     constexpr int LEVELS = (1 << BITS) - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* tile = (uint16_t*)smem;                                    // [64][ET_PITCH]
-    uint32_t* tw = (uint32_t*)smem;                                      // the same as words: row pitch ET_PITCH / 2
-    constexpr int WP = ET_PITCH / 2;
-    unsigned char* lrsm = smem + (size_t)64 * ET_PITCH * 2;
+    uint16_t* tile = (uint16_t*)smem;                                    // [64][BT_PITCH]
+    uint32_t* tw = (uint32_t*)smem;                                      // the same as words: row pitch BT_PITCH / 2
+    constexpr int WP = BT_PITCH / 2;
+    unsigned char* lrsm = smem + (size_t)64 * BT_PITCH * 2;
     const int lane = threadIdx.x;
     const int64_t NBH = (int64_t)a.NB * a.H;
     const bool isK = (int64_t)blockIdx.x < NBH;
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
         const uint16_t* xb = a.kwin + bh * (int64_t)a.wcap * KD;
         {
             const uint32_t* xw = (const uint32_t*)xb + lane;
-#pragma unroll 16
+#pragma unroll 32
             for (int i = 0; i < 64; i++) tw[i * WP + lane] = xw[i * 64];
         }
         const int kk = a.kk;
@@ -618,8 +629,8 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
         constexpr int NGV = KD / G;
         const int nb = (int)(bh / a.H), hh = (int)(bh % a.H);
         const uint16_t* xrow = a.vwin + (bh * a.wcap + lane) * (int64_t)KD;
-        uint4* trow = (uint4*)(tile + lane * ET_PITCH);                  // 16 chunks of 8 channels
-#pragma unroll 8
+        uint4* trow = (uint4*)(tile + lane * BT_PITCH);                  // 16 chunks of 8 channels
+#pragma unroll
         for (int j = 0; j < 16; j++) trow[j] = ((const uint4*)xrow)[j];
         uint64_t mE = 0, mO = 0;                  // outlier bits of the even / odd channels (bit w = channel 2w / 2w + 1)
         float fill = 0.f;
@@ -688,7 +699,7 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
                         m &= m - 1u;
                         const int d = gi * G + 2 * w + par;
                         vt[pos++] = (uint32_t)lane | ((uint32_t)d << 6) |
-                                    ((uint32_t)f2h_bits(h2f_bits(tile[lane * ET_PITCH + d]) - dqv) << 16);
+                                    ((uint32_t)f2h_bits(h2f_bits(tile[lane * BT_PITCH + d]) - dqv) << 16);
                     }
                 }
             }
@@ -789,7 +800,7 @@ extern "C" int gear_compress_block(const gear_cache_view* c, int t_off, int o_of
     a.rows_per_blk = (int)((NB * 64 + 2 * NB * H - 1) / (2 * NB * H));     // every workgroup (K and V tiles) takes its share
     const int rmax = a.rk > a.rv ? a.rk : a.rv;
     const int RP = rmax <= 4 ? 4 : (rmax <= 8 ? 8 : 16);
-    const size_t shmem = (size_t)64 * ET_PITCH * 2 + (rmax > 0 ? blk_lr_lds_bytes(RP) : 0);
+    const size_t shmem = (size_t)64 * BT_PITCH * 2 + (rmax > 0 ? blk_lr_lds_bytes(RP) : 0);
     const dim3 grid((unsigned)(2 * NB * H));
     hipStream_t st = (hipStream_t)stream;
 #define BLK_GO3(B, GG, RR)                                                                                         \

@@ -21,7 +21,8 @@ __host__ __device__ constexpr size_t gram_solve_lds_bytes(int RP) {
 // Md = R^T R  ->  Rinv = R^-1 (upper); dependent / zero columns -> 0.  One wave: lane m owns column m of R and of R^-1; the
 // pivots' reciprocal square roots come from v_rsq_f64 + Newton.  Md fp64 [RP][RP], Rinv fp64 [2][RP][RP] (the second half stages
 // R for the back substitution), both in LDS.  The caller orders the LDS accesses around the call (barrier or wave fence).
-template <int RP>
+// MDS: stride (in doubles) between consecutive entries of Md (1 = dense).
+template <int RP, int MDS = 1>
 __device__ __forceinline__ void chol_inverse_wave(const double* __restrict__ Md, double* __restrict__ Rinv, int lane) {
     double* Rl = Rinv + RP * RP;   // R staged for the back substitution
     const int m = lane;
@@ -29,7 +30,7 @@ __device__ __forceinline__ void chol_inverse_wave(const double* __restrict__ Md,
     bool dead[RP];
 #pragma unroll
     for (int j = 0; j < RP; j++) {
-        double sacc = (m < RP) ? Md[j * RP + m] : 0.0;
+        double sacc = (m < RP) ? Md[(j * RP + m) * MDS] : 0.0;
 #pragma unroll
         for (int kk = 0; kk < RP; kk++) {
             if (kk < j) {
@@ -37,7 +38,7 @@ __device__ __forceinline__ void chol_inverse_wave(const double* __restrict__ Md,
                 sacc -= rkj * col[kk];
             }
         }
-        const double dj = __shfl(sacc, j, 64), dg = Md[j * RP + j];
+        const double dj = __shfl(sacc, j, 64), dg = Md[(j * RP + j) * MDS];
         dead[j] = !(dj > 1e-12 * dg) || !(dg > 0.0);
         double rs = 1.0;
         if (!dead[j]) {

@@ -483,6 +483,41 @@ static int cmp_desc(const void* a, const void* b) {
     return (x->i > y->i) - (x->i < y->i);
 }
 
+/* first k elements of a[0..n) under cmp, unordered (Hoare quickselect, median-of-three pivot): the two full sorts per row this
+ * replaces were most of the selection's time on the CPU-baseline run */
+static void select_k(vi_t* a, int n, int k, int (*cmp)(const void*, const void*)) {
+    int lo = 0, hi = n - 1;
+    if (k <= 0 || k >= n) return;
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        vi_t t;
+        if (cmp(&a[mid], &a[lo]) < 0) { t = a[mid]; a[mid] = a[lo]; a[lo] = t; }
+        if (cmp(&a[hi], &a[lo]) < 0) { t = a[hi]; a[hi] = a[lo]; a[lo] = t; }
+        if (cmp(&a[hi], &a[mid]) < 0) { t = a[hi]; a[hi] = a[mid]; a[mid] = t; }
+        vi_t pv = a[mid];
+        int i = lo, j = hi;
+        while (i <= j) {
+            while (cmp(&a[i], &pv) < 0) i++;
+            while (cmp(&pv, &a[j]) < 0) j--;
+            if (i <= j) { t = a[i]; a[i] = a[j]; a[j] = t; i++; j--; }
+        }
+        /* [lo, j] <= pivot <= [i, hi]; position k - 1 must end up in the left part of the final order */
+        if (k - 1 <= j) hi = j;
+        else if (k - 1 >= i) lo = i;
+        else break;
+    }
+}
+
+static void row_select(const float* xr, int len, int k, vi_t* buf, int32_t* isml, int32_t* ilrg) {
+    for (int j = 0; j < len; j++) { buf[j].v = xr[j]; buf[j].i = j; }
+    select_k(buf, len, k, cmp_asc);
+    qsort(buf, (size_t)k, sizeof(vi_t), cmp_asc);
+    for (int j = 0; j < k; j++) isml[j] = buf[j].i;
+    select_k(buf, len, k, cmp_desc);
+    qsort(buf, (size_t)k, sizeof(vi_t), cmp_desc);
+    for (int j = 0; j < k; j++) ilrg[j] = buf[j].i;
+}
+
 int orc_outlier_select(const float* x, int64_t rows, int len, int k, int32_t* idx_small, int32_t* idx_large,
                        float* mean) {
     if (k < 0 || k > len) return -1;
@@ -496,13 +531,86 @@ int orc_outlier_select(const float* x, int64_t rows, int len, int k, int32_t* id
             for (int j = 0; j < len; j++) s += (double)xr[j];
             if (mean) mean[r] = (float)(s / (double)len);
             if (k == 0) continue;
-            for (int j = 0; j < len; j++) { buf[j].v = xr[j]; buf[j].i = j; }
-            qsort(buf, (size_t)len, sizeof(vi_t), cmp_asc);
-            for (int j = 0; j < k; j++) idx_small[r * k + j] = buf[j].i;
-            qsort(buf, (size_t)len, sizeof(vi_t), cmp_desc);
-            for (int j = 0; j < k; j++) idx_large[r * k + j] = buf[j].i;
+            row_select(xr, len, k, buf, idx_small + r * k, idx_large + r * k);
         }
         free(buf);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a12 (method GEAR), one tensor, no numpy glue
+ * out = fp16( q + lowrank(x - q) ),  q = gears_channelQ(x) (layout 0: rows = the H*D channels over T) or gears_tokenQ(x)
+ * (layout 1: rows = tokens over H*D): GenerationBench/.../Simulated/compress_function.py:204-220 on top of :261-333, the same
+ * operations in the same order as oracle.py's gearslkivi_*Q_new (which spends most of its time in single-threaded numpy casts
+ * and transposes: this form exists for the CPU baseline of bench.py and is checked against it in tests/test_oracle_golden.py).
+ * x fp16 [B,H,T,D]; P0 float [B*H, D, rank] (rank 0: no low-rank part); work: float [2 * B*H*T*D] scratch. */
+int orc_gear_tensor(const h16* x, int64_t B, int H, int T, int D, int layout, int bits, int group, int k, int rank, int loop,
+                    const float* P0, float* work, h16* out) {
+    const int levels = (1 << bits) - 1;
+    const int64_t n = B * H * (int64_t)T * D;
+    float* q32 = work;            /* float(fp16(gears(x))) */
+    float* err = work + n;        /* x - q32, [B,H,T,D] */
+    const int len = layout == 0 ? T : H * D;
+    const int64_t rows = layout == 0 ? B * H * (int64_t)D : B * (int64_t)T;
+    if (group <= 0 || k < 0 || 2 * k > len) return -1;
+    if (layout == 1 && len % group) return -1;
+    const int fixed = (len / group) * group;          /* channel layout: the T mod group tail stays unquantized (:109-122) */
+#pragma omp parallel
+    {
+        vi_t* buf = (vi_t*)malloc(sizeof(vi_t) * (size_t)len);
+        float* row = (float*)malloc(sizeof(float) * (size_t)len * 2);
+        float* deq = row + len;
+        int32_t* isml = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * k + 2));
+        int32_t* ilrg = isml + k + 1;
+        int* qtmp = (int*)malloc(sizeof(int) * (size_t)group);
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < rows; r++) {
+            /* element j of the row lives at base + off(j) */
+            int64_t base, st_in = 1;
+            if (layout == 0) { base = (r / D) * (int64_t)T * D + (r % D); st_in = D; }
+            else { base = (r / T) * (int64_t)H * T * D + (r % T) * (int64_t)D; }
+            double s = 0.0;
+            for (int j = 0; j < len; j++) {
+                const int64_t o = layout == 0 ? base + j * st_in : base + (j / D) * (int64_t)T * D + (j % D);
+                row[j] = h2f(x[o]);
+                s += (double)row[j];
+            }
+            const float mean = (float)(s / (double)len);
+            if (k > 0) {
+                row_select(row, len, k, buf, isml, ilrg);
+                for (int j = 0; j < k; j++) { deq[isml[j]] = 0; }
+            }
+            /* fill, quantize per group, restore */
+            for (int j = 0; j < len; j++) deq[j] = row[j];
+            for (int j = 0; j < k; j++) { deq[isml[j]] = mean; deq[ilrg[j]] = mean; }
+            for (int g0 = 0; g0 < fixed; g0 += group) {
+                float sc, mn;
+                quant_group_fp32(deq + g0, 1, group, levels, qtmp, &sc, &mn, deq + g0, 1);
+            }
+            for (int j = 0; j < k; j++) { deq[isml[j]] = row[isml[j]]; deq[ilrg[j]] = row[ilrg[j]]; }
+            for (int j = 0; j < len; j++) {
+                const int64_t o = layout == 0 ? base + j * st_in : base + (j / D) * (int64_t)T * D + (j % D);
+                const float qv = h2f(f2h(deq[j]));      /* gears_*Q returns fp16 */
+                q32[o] = qv;
+                err[o] = row[j] - qv;
+            }
+        }
+        free(buf); free(row); free(isml); free(qtmp);
+    }
+    if (rank > 0) {
+        const int64_t bh = B * H;
+        float* P = (float*)malloc(sizeof(float) * (size_t)(bh * (int64_t)(D + T) * rank));
+        if (!P) return -2;
+        float* Q = P + bh * (int64_t)D * rank;
+        int rc = orc_lowrank(err, bh, T, D, rank, loop, P0, P, Q);
+        if (rc == 0) rc = orc_lowrank_reconstruct(P, Q, bh, T, D, rank, err);     /* err <- Q P^T */
+        free(P);
+        if (rc) return rc;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) out[i] = f2h(q32[i] + err[i]);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) out[i] = f2h(q32[i]);
     }
     return 0;
 }
