@@ -79,29 +79,40 @@ def lib_sha256():
 
 
 def cpu_baseline(cfg):
-    """The oracle (CPU restatement of the reference's simulated path, validated against the reference in the build
-    container) on a bounded sample of the same workload: 8 layers' K and V at full heads / context."""
+    """The oracle (CPU restatement of the reference's simulated path, validated against the reference in the build container) on
+    a bounded sample of the same workload: method GEAR on up to 8 layers' K and V at full heads / context.  Two forms, both
+    reported: `value` = oracle.gear_tensor, the whole per-tensor round trip inside the C library (OpenMP over rows / heads,
+    bit-identical to the glue form: tests/test_oracle_golden.py); `numpy_glue` = the function-by-function restatement the parity
+    tests use, which spends most of its time in single-threaded numpy casts and transposes."""
     import numpy as np
     from oracle import oracle as orc
     H, T, bits, group, rank, loop, s = cfg["kv_heads"], cfg["T"], cfg["bits"], cfg["group"], cfg["rank"], cfg["loop"], cfg["s"]
-    nl = max(1, min(8, (32 * 4096 * 8) // (H * T)))   # about 10 s on the GPU box's host cores
+    nl = max(1, min(8, (32 * 4096 * 8) // (H * T)))
     rng = np.random.default_rng(0)
     k = rng.standard_normal((nl, H, T, D)).astype(np.float16)
     v = rng.standard_normal((nl, H, T, D)).astype(np.float16)
     P0k = rng.random((nl, H, D, rank), dtype=np.float32)
     P0v = rng.random((nl, H, D, rank), dtype=np.float32)
-    orc.compress_insert_function(k[:1, :1, :256], v[:1, :1, :256], "GEAR", bits, group, rank, rank, loop, s,
-                                 P0k[:1, :1], P0v[:1, :1])  # warm up / load the library
+    orc.gear_tensor(k[:1, :1, :256], "k", bits, group, s, rank, loop, P0k[:1, :1])      # warm up / load the library
     t0 = time.perf_counter()
-    orc.compress_insert_function(k, v, "GEAR", bits, group, rank, rank, loop, s, P0k, P0v)
+    orc.gear_tensor(k, "k", bits, group, s, rank, loop, P0k)
+    orc.gear_tensor(v, "v", bits, group, s, rank, loop, P0v)
     dt = time.perf_counter() - t0
     nbytes = 2 * (k.size + v.size) * 2  # quantize->dequantize round trip: counted like the GPU step
+    t0 = time.perf_counter()
+    orc.compress_insert_function(k[:1], v[:1], "GEAR", bits, group, rank, rank, loop, s, P0k[:1], P0v[:1])
+    dt_glue = time.perf_counter() - t0
     return {
         "value": nbytes / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
-        "sample": f"oracle compress_insert_function(GEAR) on {nl} layers x {H} heads x T={T} (K+V), {dt:.2f} s",
+        "sample": f"oracle.gear_tensor (method GEAR: outliers + quantize + rank-{rank} power iteration, all in C / OpenMP) on "
+                  f"{nl} layers x {H} heads x T={T}, K and V, {dt:.2f} s",
+        "numpy_glue": {"value": nbytes / nl / dt_glue / 1e9, "unit": "GB/s",
+                       "what": f"oracle.compress_insert_function(GEAR) on 1 layer, {dt_glue:.2f} s: the same arithmetic function by "
+                               "function with numpy casts / transposes in between (single-threaded outside the C calls)"},
         # for scale: the reference's own torch CPU path, measured in the BUILD container (it cannot travel), BASELINE.md section 2
         "reference_torch_in_build_container": {"value": 0.15, "unit": "GB/s", "cores": 8,
-                                               "what": "compress_insert_function(GEAR, prefill) 7B one layer T=4096, 8 vCPU Xeon 2.1 GHz"},
+                                               "what": "compress_insert_function(GEAR, prefill) 7B one layer T=4096, 8 vCPU Xeon 2.1 GHz; "
+                                                       "oracle.gear_tensor on the same 8 vCPUs: 0.25 GB/s"},
     }
 
 

@@ -578,7 +578,6 @@ int orc_gear_tensor(const h16* x, int64_t B, int H, int T, int D, int layout, in
             const float mean = (float)(s / (double)len);
             if (k > 0) {
                 row_select(row, len, k, buf, isml, ilrg);
-                for (int j = 0; j < k; j++) { deq[isml[j]] = 0; }
             }
             /* fill, quantize per group, restore */
             for (int j = 0; j < len; j++) deq[j] = row[j];

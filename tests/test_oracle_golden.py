@@ -352,3 +352,21 @@ def test_f8_ref_matmul_withlrap(golden, bits):
         got = matmul_withlrap(64, a, code, scale, mn, bits, pb, qb, type=typ)
         ref = g(name).reshape(got.shape)
         assert rel_fro(got, ref) < 2e-3, (name, rel_fro(got, ref))
+
+
+@pytest.mark.parametrize("B,H,T,bits,g,s,r", [(1, 4, 256, 2, 64, 0.02, 4), (2, 2, 192, 4, 32, 0.05, 8), (1, 3, 200, 2, 64, 0.01, 2),
+                                             (1, 2, 128, 4, 64, 0.0, 4)])
+def test_fused_cpu_gear_path_equals_the_glue_path(B, H, T, bits, g, s, r):
+    """oracle.gear_tensor (bench.py's cpu_baseline: method GEAR on one tensor inside the C library) is bit-identical to the
+    function-by-function restatement that is pinned to the reference's fixtures (compress_insert_function, F6)."""
+    rng = np.random.default_rng(3)
+    k = rng.standard_normal((B, H, T, 128)).astype(np.float16)
+    v = rng.standard_normal((B, H, T, 128)).astype(np.float16)
+    k[:, :, 5::17, 3::29] *= 6
+    v[:, :, 2::9, 1::31] *= 6
+    P0k, P0v = rng.random((B, H, 128, r), dtype=np.float32), rng.random((B, H, 128, r), dtype=np.float32)
+    rk, rv = orc.compress_insert_function(k, v, "GEAR", bits, g, r, r, 3, s, P0k, P0v)
+    gk = orc.gear_tensor(k, "k", bits, g, s, r, 3, P0k)
+    gv = orc.gear_tensor(v, "v", bits, g, s, r, 3, P0v)
+    assert np.array_equal(gk.view(np.uint16), rk.view(np.uint16))
+    assert np.array_equal(gv.view(np.uint16), rv.view(np.uint16))
