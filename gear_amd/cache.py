@@ -48,9 +48,9 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=Non
     lowrank = ("gearl" in m) or ("gearsl" in m)
     rk = int(cc["rank"]) if lowrank else 0
     rv = int(cc["rankv"]) if lowrank else 0
-    if R != 64:
-        raise L.GearError(f"GearKVCache: residual must be 64 (got {R}): the decode attention kernel holds at most 64 window "
-                          "tokens (gear_attn_decode: 0 <= W <= 64)")
+    if R not in (64, 128):
+        raise L.GearError(f"GearKVCache: residual must be 64 or 128 (got {R}): the decode attention kernel holds at most 128 "
+                          "window tokens (gear_attn_decode: 0 <= W <= 128) and blocks are whole 64-token tiles")
     assert R % group == 0 and group in (32, 64) and bits in (2, 4), "GearKVCache: group 32 / 64, 2 or 4 bits"
     fpi = 32 // bits
     Tmax = (max_tokens + R - 1) // R * R

@@ -868,8 +868,8 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
                                                                  const uint16_t* __restrict__ vwin, int W_arg, int wcap,
                                                                  uint16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ float qs[AD];
-    __shared__ float sw[64];
-    __shared__ float coef[64 + 64];  // per split, then per window token
+    __shared__ float sw[128];
+    __shared__ float coef[64 + 128];  // per split, then per window token
     __shared__ float og[4][AD];
     __shared__ float stat[2];
     const int tid = threadIdx.x, d = tid & (AD - 1), grp = tid >> 7;
@@ -880,13 +880,19 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
     if (a.dyn) W = a.dyn[3];
     const int ns = (a.dyn || a.T > 0) ? a.splits : 0;
-    // loads that depend on nothing: q, this thread's 16 channels of window token tid / 8, the split statistics
+    // loads that depend on nothing: q, this thread's 16 channels of window tokens tid / 8 and 64 + tid / 8 (the window holds up
+    // to 128 tokens: the KIVI default residual_length), the split statistics
     const int j = tid >> 3, part = tid & 7;
-    uint4 k0 = {0, 0, 0, 0}, k1 = {0, 0, 0, 0};
+    uint4 k0 = {0, 0, 0, 0}, k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
     if (j < W) {
         const uint4* kr = (const uint4*)(kwin + (bhk * wcap + j) * (int64_t)AD + part * 16);
         k0 = kr[0];
         k1 = kr[1];
+    }
+    if (j + 64 < W) {
+        const uint4* kr = (const uint4*)(kwin + (bhk * wcap + j + 64) * (int64_t)AD + part * 16);
+        k2 = kr[0];
+        k3 = kr[1];
     }
     float mi = -INFINITY, li = 0.0f;
     if (tid < ns) {
@@ -895,8 +901,8 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
     }
     if (tid < AD) qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
     __syncthreads();
-    {   // window scores: 8 threads per token
-        float t[8], acc = 0.0f;
+    {   // window scores: 8 threads per token, two tokens per thread group
+        float t[8], acc = 0.0f, acc2 = 0.0f;
         unpack8(k0, t);
 #pragma unroll
         for (int c = 0; c < 8; c++) acc = fmaf(qs[part * 16 + c], t[c], acc);
@@ -907,18 +913,33 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 1, 64);
         if (j < W && part == 0) sw[j] = acc;
+        if (W > 64) {                                     // (block-uniform)
+            unpack8(k2, t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc2 = fmaf(qs[part * 16 + c], t[c], acc2);
+            unpack8(k3, t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc2 = fmaf(qs[part * 16 + 8 + c], t[c], acc2);
+            acc2 += __shfl_xor(acc2, 4, 64);
+            acc2 += __shfl_xor(acc2, 2, 64);
+            acc2 += __shfl_xor(acc2, 1, 64);
+            if (j + 64 < W && part == 0) sw[j + 64] = acc2;
+        }
     }
     __syncthreads();
-    if (tid < 64) {   // softmax statistics over <= 64 splits and <= 64 window tokens, one lane each
+    if (tid < 64) {   // softmax statistics over <= 64 splits and <= 128 window tokens: one split and two tokens per lane
         const float sj = tid < W ? sw[tid] : -INFINITY;
-        float M = fmaxf(mi, sj);
+        const float sj2 = tid + 64 < W ? sw[tid + 64] : -INFINITY;
+        float M = fmaxf(fmaxf(mi, sj), sj2);
 #pragma unroll
         for (int x = 32; x >= 1; x >>= 1) M = fmaxf(M, __shfl_xor(M, x, 64));
         const float ci = tid < ns ? __expf(mi - M) : 0.0f;
         const float cw = tid < W ? __expf(sj - M) : 0.0f;
+        const float cw2 = tid + 64 < W ? __expf(sj2 - M) : 0.0f;
         coef[tid] = ci;
         coef[64 + tid] = cw;
-        float L = fmaf(ci, li, cw);
+        coef[128 + tid] = cw2;
+        float L = fmaf(ci, li, cw) + cw2;
 #pragma unroll
         for (int x = 32; x >= 1; x >>= 1) L += __shfl_xor(L, x, 64);
         if (tid == 0) { stat[0] = M; stat[1] = L; }
@@ -1041,7 +1062,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     GEAR_CHECK_ARG(bits == 2 || bits == 4, "gear_attn_decode: bits must be 2 or 4 (got %d)", bits);
     GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_attn_decode: bad mode %d", mode);
     GEAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "gear_attn_decode: bad head counts %d / %d", Hq, Hkv);
-    GEAR_CHECK_ARG(T >= 0 && W >= 0 && W <= 64 && T + W > 0, "gear_attn_decode: need 0 <= W <= 64 and T + W > 0");
+    GEAR_CHECK_ARG(T >= 0 && W >= 0 && W <= 128 && T + W > 0, "gear_attn_decode: need 0 <= W <= 128 and T + W > 0");
     GEAR_CHECK_ARG(T <= 64 * TC_MAX, "gear_attn_decode: at most %d compressed tokens", 64 * TC_MAX);
     GEAR_CHECK_ARG((int64_t)B * Hq <= 65535, "gear_attn_decode: too many (batch, head) pairs");
     const int cpw = 32 / bits;

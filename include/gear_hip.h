@@ -222,7 +222,7 @@ int gear_transpose_f16(const void* x, int64_t bh, int R, int C, void* y, void* s
  *     koidx / koval uint16 / fp16 [B*Hkv, 128, 2*kk] (token index, each half ascending) -- factors / outliers may be NULL
  *   V payload (token-major): vcode int32 [B*Hkv, tcap_v, 128/fpi], vscale / vmn [B*Hkv, tcap_v, 128/group], vP fp16
  *     [B*Hkv, 128, rv], vQ fp16 [B*Hkv, tf_v, rv], voidx / voval [B, tcap_v, 2*kv] (column Hkv-head*128 + d)
- *   kwin / vwin fp16 [B*Hkv, W, 128]: the W <= 64 most recent, still uncompressed tokens (NULL when W == 0)
+ *   kwin / vwin fp16 [B*Hkv, W, 128]: the W <= 128 most recent, still uncompressed tokens (NULL when W == 0)
  *   T compressed tokens (multiple of fpi); scores are scaled by qscale (1/sqrt(128)); softmax in fp32.
  *   out fp16 [B, Hq, 128]; lse optional float [B, Hq] (log-sum-exp of the scaled scores).
  */
@@ -311,7 +311,7 @@ typedef struct gear_cache_view {
     int ktile_cap, nck, vtile_cap, nblk;
 } gear_cache_view;
 
-/* Single-token decode attention over a cache view: gear_attn_decode_dyn's arithmetic (segment factors, fp16 window of W <= 64
+/* Single-token decode attention over a cache view: gear_attn_decode_dyn's arithmetic (segment factors, fp16 window of W <= 128
  * tokens with row pitch wcap, optional device-side {pos, slot, T, W}), outliers through the tiles when present (no search, no
  * dependent loads), else through the chunk indices, else by binary search in the lists. */
 int gear_attn_decode_cache(const gear_cache_view* c, const void* q, int Hq, int T, int W, const void* dyn_state, float qscale,

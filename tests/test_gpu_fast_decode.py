@@ -464,3 +464,30 @@ def test_pooled_block_compress_matches_per_layer(left):
         assert float((a.float() - b_.float()).abs().max()) <= 2e-3 * float(b_.float().abs().max())
     else:
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("method,bits,left", [("gearslKIVI", 2, 0.02), ("KIVI", 4, 0.0)])
+def test_cache_with_the_kivi_default_residual_of_128(method, bits, left):
+    """residual_length = 128 (the KIVI default, cuda_supported_gear/modeling_llama_kivi.py): a 128-token fp16 window, blocks of
+    128 tokens compressed in place; attention over compressed + window tokens against the float64 reconstruction."""
+    from gear_amd.cache import GearKVCache
+    torch.manual_seed(74)
+    B, Hq, Hkv, D, T0, steps, R = 1, 4, 2, 128, 300, 280, 128
+    cc = dict(compress_method=method, group_size=64, residual=R, quantize_bit=bits, rank=4, rankv=4, loop=3, left=left)
+    c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
+    c.prefill(torch.randn(B, Hkv, T0, D).half().cuda(), torch.randn(B, Hkv, T0, D).half().cuda())
+    assert c.n_comp == 256 and c.n_win == 44
+    worst, seen_full = 0.0, False
+    for i in range(steps):
+        c.append(torch.randn(B, Hkv, 1, D).half().cuda(), torch.randn(B, Hkv, 1, D).half().cuda())
+        q = torch.randn(B, Hq, 1, D).half().cuda()
+        out = c.attend(q)
+        if i % 17 == 0 or c.n_win in (1, 65, 127, 128):
+            seen_full |= c.n_win == 128
+            K, V = _reconstruct_cache(c)
+            ref = _ref_attn(host(q), K, V, host(c.kwin[:, :, :c.n_win]), host(c.vwin[:, :, :c.n_win]), Hq // Hkv)
+            worst = max(worst, rel_fro(host(out).astype(np.float64), ref))
+        c.maybe_compress()
+        assert c.n_win < 128
+    assert seen_full and worst < 2e-3, worst
+    assert c.n_comp == (T0 + steps) // R * R
