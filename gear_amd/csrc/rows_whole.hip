@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void quant_rows_whole_kernel(const uint16_t* _
     const int64_t base = (r / g.rows_inner) * g.outer_stride + (r % g.rows_inner) * g.inner_stride;
     for (int i = tid; i < (len + 31) / 32; i += 256) obit[i] = 0u;
     __syncthreads();
-    if (k > 0 && tid < 2 * k) {
-        const uint32_t j = oidx[r * (int64_t)(2 * k) + tid];
+    for (int i = tid; i < 2 * k; i += 256) {          // any list length (the reference has no limit on it)
+        const uint32_t j = oidx[r * (int64_t)(2 * k) + i];
         atomicOr(&obit[j >> 5], 1u << (j & 31u));
     }
     __syncthreads();
@@ -97,7 +97,7 @@ extern "C" int gear_quant_rows_whole(const void* x, int64_t n_rows, int rows_inn
     GEAR_CHECK_ARG(n_rows > 0 && n_rows < 0x7FFFFFFFLL && rows_inner > 0 && nseg > 0 && seglen > 0, "gear_quant_rows_whole: empty input");
     const int64_t len = (int64_t)nseg * seglen;
     GEAR_CHECK_ARG(len <= 16384, "gear_quant_rows_whole: row length %lld exceeds 16384", (long long)len);
-    GEAR_CHECK_ARG(k >= 0 && 2 * (int64_t)k <= len && 2 * k <= 256 && (k == 0 || oidx), "gear_quant_rows_whole: bad outlier count %d", k);
+    GEAR_CHECK_ARG(k >= 0 && 2 * (int64_t)k <= len && (k == 0 || oidx), "gear_quant_rows_whole: bad outlier count %d", k);
     WGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)n_rows), block(256);

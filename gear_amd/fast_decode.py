@@ -214,6 +214,10 @@ class FastGearDecoder:
         """One greedy decode token by replaying the captured graph.  token_ids (optional) overrides the token the graph
         produced itself; returns the NEXT token [B,1] (the graph's own argmax).  Block compression (every `residual`
         tokens) runs eagerly between replays."""
+        if self.gather is not None:
+            raise NotImplementedError("step_graph() with tp_world > 1: the per-layer all-gather of the attention output is not "
+                                      "captured (the one-GPU gloo staging path copies through the host; with RCCL the "
+                                      "communicator and its buffers would have to be registered for the graph) -- use step()")
         if token_ids is not None:
             self.tok.copy_(token_ids.view(self.batch, 1))
         if self.graph is None:

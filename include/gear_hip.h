@@ -173,7 +173,7 @@ int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group,
  * fake_groupwise_token_asymmetric_quantization(value, bits, num_head * sep_dim) of the KCVT / GEAR-KCVT / GEARL-KCVT branches
  * (GenerationBench/.../Simulated/compress_function.py:441-452, :496-525, :555-582), optionally around the row's sparse outliers
  * (gears_channelQ / gears_tokenQ with that group size).  Geometry as gear_compress_rows; len = nseg * seglen <= 16384, any
- * length.  oidx: uint16 [n_rows, 2k] as gear_compress_rows writes it (k == 0: none, k <= 128).
+ * length.  oidx: uint16 [n_rows, 2k] as gear_compress_rows writes it (k == 0: none).
  *   y   fp16, same geometry: quantize -> dequantize, outliers keep their original value
  *   err optional fp16 x - y (0 at the outliers)
  */
