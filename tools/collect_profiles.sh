@@ -14,6 +14,17 @@ python tools/kstats.py $(find $OUT/stats -name "*kernel_stats.csv" | head -1) 30
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dec -o st -- python tools/prof_decode.py > $OUT/stats_dec.log 2>&1
 python tools/kstats.py $(find $OUT/stats_dec -name "*kernel_stats.csv" | head -1) 30 > $OUT/kernel_stats_decode.md
 tail -3 $OUT/stats_dec.log >> $OUT/kernel_stats_decode.md
+# the compress kernels ONE AT A TIME on one stream (tools/prof_step.py): the durations the per-kernel roofline fractions stand on
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_iso -o st -- python tools/prof_step.py > $OUT/stats_iso.log 2>&1
+python tools/kstats.py $(find $OUT/stats_iso -name "*kernel_stats.csv" | head -1) 30 > $OUT/kernel_stats_isolated.md
+# the decode-time block boundary: single-launch block compressor vs the chain (tools/prof_block.py)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_blk -o st -- python tools/prof_block.py > $OUT/stats_blk.log 2>&1
+python tools/kstats.py $(find $OUT/stats_blk -name "*kernel_stats.csv" | head -1) 30 > $OUT/kernel_stats_block.md
+for P in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pb_$P -o pmc -- python tools/prof_block.py > $OUT/pb_$P.log 2>&1
+  cp $(find $OUT/pb_$P -name "*counter_collection.csv" | head -1) $OUT/pmc_block_$P.csv
+  rm -rf $OUT/pb_$P
+done
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 P2="SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"
 i=0
@@ -23,6 +34,6 @@ for P in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE"; do
   cp $(find $OUT/p$i -name "*counter_collection.csv" | head -1) $OUT/pmc_p$i.csv
   rm -rf $OUT/p$i
 done
-rm -rf $OUT/stats $OUT/stats_dec
+rm -rf $OUT/stats $OUT/stats_dec $OUT/stats_iso $OUT/stats_blk
 sha256sum gear_amd/libgear_hip.so > $OUT/lib.sha256
 ls -la $OUT

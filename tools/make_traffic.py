@@ -41,4 +41,20 @@ with open(f"{dst}_pmc_traffic.md", "w") as fmd:
               "| kernel | read GB | written GB | total GB |\n|---|---:|---:|---:|\n")
     for n, f, w in rows:
         fmd.write(f"| `{n[:80]}` | {f / 1e9:.3f} | {w / 1e9:.3f} | {(f + w) / 1e9:.3f} |\n")
+# the block boundary (tools/prof_block.py), when collected: same calibration
+import os
+if os.path.exists(f"{src}/pmc_block_FETCH_SIZE.csv"):
+    bf, bw_ = table(f"{src}/pmc_block_FETCH_SIZE.csv"), table(f"{src}/pmc_block_WRITE_SIZE.csv")
+    with open(f"{dst}_pmc_traffic.md", "a") as fmd:
+        fmd.write("\n## The decode-time block boundary (tools/prof_block.py: 32 layers x 32 heads x 64 tokens, K and V = 33.6 MB of fp16 in)\n\n"
+                  "| kernel | read MB | written MB | total MB |\n|---|---:|---:|---:|\n")
+        for n in bf:
+            if not n.startswith(("block_compress", "compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "ktile", "vtile", "outlier_chunk")):
+                continue
+            f = sorted(bf[n]["FETCH_SIZE"])[len(bf[n]["FETCH_SIZE"]) // 2] * kf
+            w = sorted(bw_[n]["WRITE_SIZE"])[len(bw_[n]["WRITE_SIZE"]) // 2] * kw if n in bw_ else 0.0
+            fmd.write(f"| `{n[:80]}` | {f / 1e6:.2f} | {w / 1e6:.2f} | {(f + w) / 1e6:.2f} |\n")
+            if n.startswith("block_compress"):
+                out["kernels"][n[:60]] = f + w
+    json.dump(out, open(f"{dst}_traffic.json", "w"), indent=1)
 print(open(f"{dst}_pmc_traffic.md").read())

@@ -14,7 +14,15 @@ hdr = {"bench": "`rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-b
                 "run also contains the warm-up steps, the per-kernel timing passes and the attention-by-batch calls)",
        "decode": "`rocprofv3 --kernel-trace --stats -- python tools/prof_decode.py` (FastGearDecoder, Llama-2-7B shapes, prompt 4040, "
                  "2 % outliers, 20 + 20 timed eager token steps after the prefill; hipBLASLt kernels = the prefill GEMMs)"}
-for kind in ("bench", "decode"):
+hdr["isolated"] = ("`rocprofv3 --kernel-trace --stats -- python tools/prof_step.py`: the compress kernels of one bench step at config-3 size, "
+                   "ONE AT A TIME on one stream (3 launches each after a 1 GiB copy) -- the durations bench.py's `kernels` fractions stand "
+                   "on; inside the bench step the K and V chains share the chip on two streams and the same kernels take longer")
+hdr["block"] = ("`rocprofv3 --kernel-trace --stats -- python tools/prof_block.py`: the decode-time block boundary at Llama-2-7B shapes "
+                "(32 layers x 32 heads x 64 tokens, K and V, 2 % outliers, rank 8): `block_compress_kernel` (ONE launch per boundary) x 5, "
+                "then the kernel chain it replaced x 5 (one launch of each kernel below per boundary)")
+for kind in ("bench", "decode", "isolated", "block"):
+    if not os.path.exists(os.path.join(src, f"kernel_stats_{kind}.md")):
+        continue
     body = open(os.path.join(src, f"kernel_stats_{kind}.md")).read()
     open(dst + f"_kernel_stats_{kind}.md", "w").write(
         f"# rocprofv3 kernel stats, {tag}, library {sha[:12]}\n\n{hdr[kind]}\n\n{body}")
