@@ -528,11 +528,22 @@ def main():
     # the headline roofline object is what north_star names -- the fused K / V quant + low-rank + outlier COMPRESS, i.e. the chain
     # of launches per tensor kind -- not its fastest member: the chain with the lower fraction
     cname = min(("k_compress", "v_compress"), key=lambda c: chain[c]["frac"])
+    # PMC traffic of the chain = the sum over its launches (same library-tied profile as above)
+    chain_traffic = None
+    members = {"k_compress": ("k_select_kernel", "k_select_fix_kernel", "k_main_kernel", "k_solve_kernel", "k_qpass_kernel"),
+               "v_compress": ("compress_rows_wave_kernel", "compress_rows_fp32_kernel", "lr_gram_solve_kernel<8, true>",
+                              "lr_gram_solve_kernel<4, true>", "lr_gram_solve_kernel<16, true>", "lr_qpass_tm_mfma_kernel")}
+    if traffic is not None:
+        hit = [tb for kname, tb in prof.get("kernels", {}).items()
+               if any(kname == mname or kname.startswith(mname + "<") or kname.startswith(mname) and "<" in mname for mname in members[cname])]
+        if hit:
+            chain_traffic = float(sum(hit))
     launches = {"k_compress": "k_select_kernel + k_select_fix_kernel + k_main_kernel + k_solve_kernel + k_qpass_kernel",
                 "v_compress": "compress_rows_wave_kernel (fast + fallback pass) + lr_gram_solve_kernel + lr_qpass_tm_mfma_kernel"}
     roofline = {"bound": "hbm", "kernel": f"{cname} chain: {launches[cname]}", "achieved": chain[cname]["achieved"],
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chain[cname]["frac"], "traffic": None,
-                "traffic_source": "per kernel under `kernels` / profiles/r3_pmc_traffic.md", "alg_bytes_per_launch": chain[cname]["alg_bytes"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chain[cname]["frac"], "traffic": chain_traffic,
+                "traffic_source": tnote + " (sum over the chain's kernels; per kernel: profiles/r3_pmc_traffic.md)",
+                "alg_bytes_per_launch": chain[cname]["alg_bytes"],
                 "ms_per_launch": chain[cname]["ms"], "launch": "one chain = one call of gear_compress_%s_fused over all layers" % ("key" if cname == "k_compress" else "value"),
                 "bytes_definition": "SURVEY.md 8(d): read 2n + codes n*b/8 + scale/mn 8n/g + factors + outliers; no error term",
                 "dominant_kernel": dominant,
@@ -598,6 +609,10 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.layers:
         res["block_boundary"] = block_boundary_cost(cfg, dev, Hl)
+        res["block_boundary"]["traffic"] = None
+        if traffic is not None and not args.emulate_world:
+            bt = [tb for kname, tb in prof.get("kernels", {}).items() if kname.startswith("block_compress_kernel")]
+            res["block_boundary"]["traffic"] = float(sum(bt)) if bt else None
     if rank == 0 and world == 1 and not args.layers and not args.emulate_world:
         res["attn_decode"]["one_layer_streaming_cache_by_batch"] = attn_decode_by_batch(cfg, dev)
     if not args.no_decode and not args.layers and not args.emulate_world:

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json"])
+@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json", "r3_bench_line.json"])
 def test_committed_bench_line_has_the_contract_fields(line):
     d = json.load(open(os.path.join(ROOT, "profiles", line)))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
@@ -29,6 +29,20 @@ def test_committed_bench_line_has_the_contract_fields(line):
     # value = fp16 KV bytes through compress + decompress per second, whole job
     n = 32 * 32 * 4096 * 128
     assert abs(d["value"] - 2 * (2 * n * 2) / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    if line.startswith("r3"):
+        # round 3: the headline roofline object is the compress CHAIN north_star names (the lower of K / V), with the PMC traffic of
+        # its launches; the dominant single kernel rides along; the decode-time block boundary is measured and reported
+        assert r["kernel"].startswith(("k_compress chain", "v_compress chain")) and "dominant_kernel" in r
+        lo = min(d["roofline_chain"][c]["frac"] for c in ("k_compress", "v_compress"))
+        assert abs(r["frac"] - lo) < 1e-12
+        dk = r["dominant_kernel"]
+        assert abs(dk["frac"] - dk["achieved"] / 8000.0) < 1e-9 and dk["ms_per_launch"] <= r["ms_per_launch"]
+        bb = d["block_boundary"]
+        assert bb["one_launch"] and 0 < bb["block_kernel_us"] < bb["chain_us"]
+        assert abs(bb["frac"] - bb["alg_bytes"] / (bb["block_kernel_us"] * 1e-6) / 1e9 / 8000.0) < 1e-9
+        assert bb["traffic"] is None or bb["traffic"] >= 0.9 * bb["alg_bytes"]
+        assert abs(d["decode"]["block_compress_ms"] - bb["block_kernel_us"] * 1e-3) < 1e-9
+        assert "numpy_glue" in c and c["value"] > c["numpy_glue"]["value"]
     if line.startswith("r2"):
         # round 2: per-kernel and per-chain rooflines on SURVEY 8(d) bytes (no error term), traffic tied to the library build
         assert "no error term" in r["bytes_definition"] and "traffic_source" in r
@@ -43,8 +57,9 @@ def test_committed_bench_line_has_the_contract_fields(line):
         assert d["decode"]["outliers_per_side"]["v_row"] == 40 and "2% outliers" in d["decode"]["method"]
 
 
-def test_traffic_profile_names_the_library_it_was_measured_on():
-    t = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+@pytest.mark.parametrize("name", ["r2_traffic.json", "r3_traffic.json"])
+def test_traffic_profile_names_the_library_it_was_measured_on(name):
+    t = json.load(open(os.path.join(ROOT, "profiles", name)))
     assert len(t["lib_sha256"]) == 64 and t["config"] == "c3" and t["kernels"] and "FETCH_SIZE" in t["how"]
     assert all(v > 0 for v in t["kernels"].values())
 
