@@ -20,7 +20,8 @@ Outlier counts.  V rows (a token across the heads) and the K rows of the prompt 
 (compress_function.py:264-267, :299-303: int(H*D*s/2) per side, capped at half the row).  For the K rows of a 64-token
 decode block that formula asks for more outliers than the row has elements (defect B7: it depends on H*D, not on the
 row length; torch.topk then takes overlapping sets and the block ends up stored losslessly); the cache uses the NOMINAL
-count max(1, round(64*s/2)) per side there.
+count max(1, round(64*s/2)) per side there (`block_outlier_count="reference"` in the config selects the reference's count, capped at
+half the row).
 
 Differences from the hook, on purpose: K and V are compressed in lockstep (the hook compresses V only when T > residual,
 :416, which strands V in fp16 when the prompt is exactly `residual` long), and the block factors start from a
@@ -64,7 +65,13 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=Non
     # spans the heads, so a shard selects k / world inside its own heads: see parallel.py)
     Ht = heads_total or H
     kk0_max = int(int(B * Ht * T * D * s) / B / T / 2) if s > 0 else 0
-    kk_blk = max(1, round(R * s / 2)) if s > 0 else 0                     # nominal count for a 64-token block (B7)
+    # K outliers per side and channel row of a decode block: "nominal" = the sparsity applied to the row's own length; "reference" =
+    # the reference's formula (B7: it depends on H*D, not on the row length), capped at half the row -- what gears_channelQ does to a
+    # 64-token block with the streaming hook's config (compress_function.py:264-267): at s = 0.02 on 7B that stores the block losslessly
+    if cc.get("block_outlier_count", "nominal") == "reference":
+        kk_blk = min(int(int(B * Ht * R * D * s) / B / R / 2), R // 2) if s > 0 else 0
+    else:
+        kk_blk = max(1, round(R * s / 2)) if s > 0 else 0                 # nominal count for a 64-token block (B7)
     kcap = kk0_max + (Tmax // R) * kk_blk
     shapes = dict(kcode=((B, H, D, T // fpi), torch.int32), kscale=((B, H, D, T // group), torch.float16),
                   kmn=((B, H, D, T // group), torch.float16), vcode=((B, H, T, D // fpi), torch.int32),

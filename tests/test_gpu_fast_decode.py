@@ -140,16 +140,20 @@ def _oracle_block(x, layout, k, g, bits):
     return orc.unpack_tensor(q["code"], bits, 1), q["scale"], q["mn"], isml, ilrg, orig
 
 
-@pytest.mark.parametrize("left,bits,Hkv", [(0.0, 2, 2), (0.02, 2, 4), (0.05, 4, 2)])
-def test_cache_contents_match_oracle_block_by_block(left, bits, Hkv):
+@pytest.mark.parametrize("left,bits,Hkv,count", [(0.0, 2, 2, "nominal"), (0.02, 2, 4, "nominal"), (0.05, 4, 2, "nominal"),
+                                                 (0.02, 2, 4, "reference"), (0.05, 4, 2, "reference")])
+def test_cache_contents_match_oracle_block_by_block(left, bits, Hkv, count):
     """After a prefill and 150 appended tokens every block of the cache -- packed codes, scale / zero point, outlier lists
     and values -- is what the ORACLE makes of the fp16 K / V of exactly that block (bit-exact: fp16-stepwise arithmetic):
     a block written from the wrong window slice, at the wrong offset or with the wrong list position fails here."""
     from gear_amd.cache import GearKVCache
     torch.manual_seed(73)
     B, D, T0, steps, g, R = 2, 128, 200, 150, 64, 64
-    cc = dict(compress_method="gearlKIVI", group_size=g, residual=R, quantize_bit=bits, rank=4, rankv=4, loop=3, left=left)
+    cc = dict(compress_method="gearlKIVI", group_size=g, residual=R, quantize_bit=bits, rank=4, rankv=4, loop=3, left=left,
+              block_outlier_count=count)
     c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
+    if count == "reference" and left:      # the reference's formula on a 64-token row: int(H * D * s / 2), at most half the row
+        assert c.kk_blk == min(int(int(B * Hkv * 64 * D * left) / B / 64 / 2), 32) and c.kk_blk > max(1, round(64 * left / 2))
     k_all = torch.randn(B, Hkv, T0 + steps, D).half()
     v_all = torch.randn(B, Hkv, T0 + steps, D).half()
     c.prefill(k_all[:, :, :T0].cuda(), v_all[:, :, :T0].cuda())
