@@ -17,10 +17,19 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.fixture(autouse=True)
+def _block_kernel_for_every_head_count():
+    """The tests cover every head count the kernel accepts (cache.py keeps the chain below 4 KV heads for speed)."""
+    from gear_amd import cache as gc
+    old = (gc.USE_BLOCK_KERNEL, gc.BLOCK_KERNEL_MIN_HEADS)
+    gc.BLOCK_KERNEL_MIN_HEADS = 1
+    yield
+    gc.USE_BLOCK_KERNEL, gc.BLOCK_KERNEL_MIN_HEADS = old
+
+
 def _mk(n_layers, B, H, cc, tmax, use_block, seed=5):
     from gear_amd import cache as gc
     gc.USE_BLOCK_KERNEL = use_block
-    gc.BLOCK_KERNEL_MIN_HEADS = 1          # the tests cover every head count the kernel accepts
     pool = gc.GearKVCachePool(n_layers, B, H, tmax, cc, "cuda", seed=seed)
     caches = [gc.GearKVCache(B, H, tmax, cc, "cuda", pool=pool, layer=l) for l in range(n_layers)]
     return pool, caches
@@ -159,7 +168,6 @@ def test_block_factors_match_reference_iteration(H, bits, group, rank, left):
     from gear_amd import cache as gc
     torch.manual_seed(7)
     B, seed = 1, 11
-    gc.BLOCK_KERNEL_MIN_HEADS = 1
     cc = dict(compress_method="gearslKIVI", group_size=group, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=3, left=left)
     c = gc.GearKVCache(B, H, 64, cc, "cuda", seed=seed)
     k = torch.randn(B, H, 64, 128).half()
