@@ -7,12 +7,12 @@
 // (kfused.hip, compress_rows.hip, lowrank_gram.hip, attention.hip's tile builders) takes ~10 launches for that; the tiles here
 // are 64 x 128 fp16 = 16 KB per (layer, head, K | V), so the whole block fits on chip:
 //
-//   one wave = one tile.  K tile: lane = channel pair, the 64 tokens of a channel live in one lane's registers -> exact row
-//   mean (fp64 accumulation of fp16 values), top / bottom-kk selection by repeated scans (ties: lower token first), fill,
-//   group quantization along T, bit-packing into the channel-major K^T cache rows at the block's token offset, the outlier lists
-//   and the block's entries of the 128-token sparse tile.  V tile: lane = token, its 128 channels in registers -> group
-//   quantization along D, packing, the 64-token sparse tile.  Both leave the fp16 error tile [64 tokens][128 channels] in LDS
-//   and run the SAME low-rank step on it, written on the 64-dimensional token side because a block has only 64 rows:
+//   one wave = one tile, kept in LDS ([64 tokens][136 halves]: x first, overwritten in place by the error).  K tile: lane = channel
+//   pair walking the 64 tokens -> exact row mean (fp64 accumulation of fp16 values), top / bottom-kk selection by repeated scans
+//   (ties: lower token first), fill, group quantization along T, bit-packing into the channel-major K^T cache rows at the block's
+//   token offset, the outlier lists and the block's entries of the 128-token sparse tile.  V tile: lane = token walking its 128
+//   channels -> group quantization along D, packing, the 64-token sparse tile.  Both leave the fp16 error tile in LDS and run the
+//   SAME low-rank step on it, written on the 64-dimensional token side because a block has only 64 rows:
 //       Y0 = E P0 (matrix cores; P0 as fp16 head + remainder) ; G' = E E^T (64 x 64, matrix cores, accumulators stay in
 //       registers) ; Y = G'^(loop-1) Y0 ; Q' = orth(Y) (CholeskyQR2, fp64 small Gram) ; P = E^T Q' (matrix cores, transposing
 //       LDS reads)
@@ -21,12 +21,12 @@
 //   on that span only.  (The chain iterates on the 128 x 128 matrix E^T E, which is the cheaper side only for T > 128.)
 //
 //   V outliers are selected per TOKEN ROW ACROSS THE HEADS (gears_tokenQ, compress_function.py:297-333), i.e. across tiles.
-//   Every workgroup does `rows_per_blk` "row duties" before its tile: one wave reads one token
-//   row of all H heads, finds the exact top / bottom-kv sets (16-round bisection on the 16-bit order key, both sides at once;
+//   Every workgroup does `rows_per_blk` "row duties" before its tile: one wave reads one token row of all H heads, finds the exact top / bottom-kv sets (16-round bisection on the 16-bit order key, both sides at once;
 //   ties by index), writes the sorted lists, the chunk index bytes and -- write-through -- a 128-bit outlier mask per (row,
 //   head) and the row mean, then raises the row's flag.  The V tiles (the LAST NB*H workgroups) poll the 64 flags of their
-//   rows -- lane = token = row -- and read mask and mean with agent-scope loads.  A poll
-//   that outlasts its bound sets the status word instead of hanging the GPU.
+//   rows -- lane = token = row -- and read mask and mean with agent-scope loads.  A poll that outlasts its bound sets the status
+//   word instead of hanging the GPU.  (Row duties never wait; a V tile's rows belong to workgroups dispatched before it or at most
+//   63 after it, so forward progress needs 64 resident workgroups: one XCD holds 256.)
 #include "common.h"
 #include "lowrank_solve.h"
 #include "ktile.h"
