@@ -3,7 +3,9 @@
 Follows cuda_supported_gear/modeling_llama_kivi.py:81-289 from the point where q / k / v (post-RoPE, fp16) are known up to the
 tensor handed to o_proj: K fp16 window quantized as a block of `residual` tokens (:149-162), V sliding window whose oldest token
 is quantized per token once it holds residual + 1 (:200-213), prompt split (:222-248).  Building blocks: oracle.py
-(quant_pack_lastdim / gemv_outer, pinned by the golden fixtures F1 / F7)."""
+(quant_pack_lastdim / gemv_outer, pinned by the golden fixtures F1 / F7).  The state machine as a whole is pinned by
+tests/golden/f8_ref_kivi_*.npz: traces made by executing the reference's own LlamaAttention_KIVI.forward source step by step
+(tests/golden/make_f8_ref.py), which tests/test_oracle_golden.py holds this restatement to."""
 import math
 
 import numpy as np

@@ -1,8 +1,9 @@
 """Fixture F8: a 130-step single-layer decode trace of the attention cache state machine
 (prefill 200 tokens -> crosses two 64-token blocks), produced by oracle/attention_oracle.py -- the restatement of
-cuda_supported_gear/modeling_llamagear.py:177-484 with the documented stances on defects B1 / B2.  The reference's own forward
-cannot be imported under the installed transformers, so this trace is NOT reference output: it pins the ORACLE (a later edit
-of the restatement that changes its behaviour fails tests/test_oracle_golden.py::test_f8_*), nothing more.
+cuda_supported_gear/modeling_llamagear.py:177-484 with the documented stances on defects B1 / B2.  This trace is NOT reference
+output: it is a regression pin of the ORACLE on shapes the reference rejects (GQA) -- a later edit of the restatement that
+changes its behaviour fails tests/test_oracle_golden.py::test_f8_*.  The pin against the reference's own executed forward is
+tests/golden/make_f8_ref.py -> f8_ref_*.npz.
 Inputs (q, k, v per step, the bases P0) are stored, not re-drawn.   python tests/golden/make_f8.py"""
 import os
 import sys
