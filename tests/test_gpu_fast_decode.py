@@ -250,20 +250,22 @@ def test_glue_kernels_match_torch():
     assert float((out.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
-def _tiny(method):
+def _tiny(method, n_kv=2):
     from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
     cfg = LlamaConfigLite(vocab_size=1000, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
-                          num_attention_heads=4, num_key_value_heads=2, k_bits=4, v_bits=4)
+                          num_attention_heads=4, num_key_value_heads=n_kv, k_bits=4, v_bits=4)
     cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=4, rank=4, rankv=4, loop=3)
     torch.manual_seed(0)
     return LlamaForCausalLM_GEARKIVI(cfg, cc).half().cuda().eval()
 
 
-def test_fast_decoder_tracks_the_attention_hook_module():
+@pytest.mark.parametrize("n_kv", [2, 4])
+def test_fast_decoder_tracks_the_attention_hook_module(n_kv):
     """Quantization-only cache (no random bases): the fast path and the reference-shaped module see the same tokens and
-    must produce near-identical logits over a decode run that crosses two block boundaries."""
+    must produce near-identical logits over a decode run that crosses two block boundaries -- with 2 KV heads through the kernel
+    chain, with 4 through the single-launch block compressor (cache.BLOCK_KERNEL_MIN_HEADS)."""
     from gear_amd.fast_decode import FastGearDecoder
-    model = _tiny("KIVI")
+    model = _tiny("KIVI", n_kv)
     ids = torch.randint(0, 1000, (1, 100)).cuda()
     fast = FastGearDecoder(model, 512)
     with torch.no_grad():
