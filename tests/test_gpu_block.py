@@ -234,3 +234,40 @@ def test_block_kernel_is_one_launch_and_rejects_bad_views():
     view.mode = 0
     assert lib.gear_compress_block(*args(0)) == 0
     torch.cuda.synchronize()
+
+
+def test_block_kernel_handoff_under_uneven_load():
+    """The V row hand-off (row-duty waves -> V tiles: write-through mask / mean, drained, flag; relaxed polls) checked word for
+    word while other work competes for the chip: a second stream streams 1 GiB through HBM, the block kernel runs 25 times on
+    fresh data with a varying number of tiles per launch, and every launch's V payload must equal the kernel chain's (whose
+    selection happens in a separate launch).  Uniformly idle chips hide hand-off bugs (MI355X_MICROARCH.md)."""
+    from gear_amd import cache as gc
+    torch.manual_seed(11)
+    cc = dict(compress_method="gearslKIVI", group_size=64, residual=64, quantize_bit=2, rank=4, rankv=4, loop=3, left=0.02)
+    noise = torch.empty(1 << 28, dtype=torch.float16, device="cuda")
+    side = torch.cuda.Stream()
+    for it in range(25):
+        layers, H = (1 + it % 5), (4, 8, 12, 32)[it % 4]
+        out = {}
+        for use_block in (True, False):
+            pool, caches = _mk(layers, 1, H, cc, 256, use_block, seed=it)
+            torch.manual_seed(1000 + it)
+            pool.buf["kwin"].copy_(torch.randn(pool.buf["kwin"].shape, device="cuda").half())
+            pool.buf["vwin"].copy_(torch.randn(pool.buf["vwin"].shape, device="cuda").half())
+            for c in caches:
+                c.n_comp, c.n_win, c.seg0, c.kk0 = 64, 64, 64, 0
+            torch.cuda.synchronize()
+            if use_block:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        noise.mul_(1.0001)
+            gc.USE_BLOCK_KERNEL = use_block
+            pool.compress_all()
+            torch.cuda.synchronize()
+            out[use_block] = pool
+        for name in ("vcode", "vscale", "vmn", "voidx", "voval", "vochunk", "vcnt", "kcode", "kscale", "kmn", "koidx", "koval"):
+            a, b = host(out[False].buf[name]), host(out[True].buf[name])
+            if a.dtype == np.float16:
+                a, b = a.view(np.uint16), b.view(np.uint16)
+            assert np.array_equal(a, b), (it, name)
+    assert gc.block_kernel_status() == 0
