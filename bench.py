@@ -246,9 +246,15 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
     res = {"context": T, "batch": 1, "weights": f"random init, {cfg['model']} shapes",
            "method": "gearslKIVI %d-bit, rank %d per block, %.0f%% outliers (V rows: reference count%s; K prompt rows: reference "
                      "count, K 64-token blocks: nominal count), residual 64" % (bits, rnk, s * 100, " / world per shard" if world > 1 else ""),
-           "parallelism": f"head-shard x{world}" + (", all_gather_into_tensor of the attention output per layer" if world > 1 else "")}
+           "parallelism": f"head-shard x{world}"}
     from gear_amd.fast_decode import FastGearDecoder
     fast = FastGearDecoder(model, T + 2 * new_tokens + 8, tp_rank=rank, tp_world=world)
+    capturable = fast.gather is None or fast.gather.capturable
+    if world > 1:
+        res["exchange"] = ("gear_xchg_allgather: stores into the peers' hipIpc-mapped memory, one launch per layer inside the "
+                           "token-step graph" if capturable else
+                           "all_gather_into_tensor of the attention output per layer, eager (peer mapping failed: %s)"
+                           % (fast.exchange_error,))
     nxt = fast.prefill(ids).argmax(-1, keepdim=True)
     for _ in range(2):
         nxt = fast.step(nxt).argmax(-1, keepdim=True)
@@ -262,7 +268,7 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
     res.update({"eager_tokens_per_s": (new_tokens - 2) / dt, "outliers_per_side": {"v_row": c0.kv, "k_prompt_row": c0.kk0,
                                                                                  "k_block_row": c0.kk_blk}})
     best = res["eager_tokens_per_s"]
-    if world == 1:
+    if capturable:
         # the same token step captured once as a HIP graph (device-side pos / slot / T / W) and replayed
         n_graph = new_tokens - 2
         fast.tok.copy_(nxt)
@@ -274,10 +280,13 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
         torch.cuda.synchronize()
         res["graph_replay_tokens_per_s"] = n_graph / (time.perf_counter() - t0)
         best = max(best, res["graph_replay_tokens_per_s"])
+        if world > 1:
+            fast.gather.check()
     # headline = the faster launch mode of the same token step (both reported)
     res.update({"tokens_per_s": best, "ms_per_token": 1e3 / best,
                 "path": "FastGearDecoder (GearKVCache with in-place block compress + fused GEMVs + gear_attn_decode_cache)",
                 "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20})
+    fast.close()
     del fast
     torch.cuda.empty_cache()
     if world == 1 and cfg["layers"] * cfg["hidden"] <= 32 * 4096:

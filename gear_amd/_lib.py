@@ -67,9 +67,16 @@ SIGNATURES = {
     "gear_compress_block_workspace": (_sz, [_i64, _i]),
     "gear_compress_block": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
     "gear_compress_block_status_ptr": (_vp, [_vp]),
+    "gear_xchg_bytes": (_sz, [_i, _sz]),
+    "gear_xchg_alloc": (_i, [_sz, C.POINTER(_vp)]),
+    "gear_xchg_free": (_i, [_vp]),
+    "gear_xchg_export": (_i, [_vp, _vp]),
+    "gear_xchg_open": (_i, [_vp, C.POINTER(_vp)]),
+    "gear_xchg_close": (_i, [_vp]),
+    "gear_xchg_allgather": (_i, [_vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 3      # what this table was written against (gear_abi_version() of the library must match)
+ABI_VERSION = 4      # what this table was written against (gear_abi_version() of the library must match)
 
 
 def _source_hash() -> str:

@@ -20,11 +20,14 @@ from .modeling_llamagear import apply_rotary_pos_emb
 
 class FastGearDecoder:
     def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0, tp_rank: int = 0, tp_world: int = 1,
-                 tp_group=None):
+                 tp_group=None, tp_exchange: str = "peer"):
         """tp_world > 1: the cache and the attention are sharded head-wise: this rank owns
         Hq / tp_world query heads with their KV heads -- local q/k/v projection rows, local compressed cache, local attention --
         and all-gathers the per-rank attention output (parallel.HeadGather, pre-allocated) in front of the replicated
-        o_proj / MLP, which every rank computes in full.  The model passed in holds the full (replicated) weights."""
+        o_proj / MLP, which every rank computes in full.  The model passed in holds the full (replicated) weights.
+        tp_exchange: "peer" = parallel.PeerHeadGather (stores into the peers' memory from one launch per layer, capturable in
+        the token-step graph; falls back to the collective, on every rank alike, when the peer mappings cannot be set up),
+        "collective" = parallel.HeadGather (all_gather_into_tensor, eager steps only)."""
         self.model = model
         cfg = model.config
         self.cfg = cfg
@@ -77,9 +80,19 @@ class FastGearDecoder:
         self.tok = torch.zeros((batch, 1), dtype=torch.long, device=dev)
         self.logits_static = None
         self.gather = None
+        self.exchange_error = None
         if tp_world > 1:
-            from .parallel import HeadGather
-            self.gather = HeadGather(tp_world, batch, self.Hq * self.D, torch.float16, dev, tp_group)
+            from .parallel import HeadGather, PeerHeadGather
+            if tp_exchange not in ("peer", "collective"):
+                raise ValueError(f"tp_exchange {tp_exchange!r}: 'peer' or 'collective'")
+            if tp_exchange == "peer":
+                g = PeerHeadGather(tp_world, tp_rank, batch, self.Hq * self.D, torch.float16, dev, tp_group)
+                if g.ok:
+                    self.gather = g
+                else:
+                    self.exchange_error = g.error
+            if self.gather is None:
+                self.gather = HeadGather(tp_world, batch, self.Hq * self.D, torch.float16, dev, tp_group)
 
     def _attn_out(self, a):
         """[B, Hq_local, 1, D] of this rank -> [B, Hq_full * D] (all-gather over the head shards when sharded)."""
@@ -214,10 +227,9 @@ class FastGearDecoder:
         """One greedy decode token by replaying the captured graph.  token_ids (optional) overrides the token the graph
         produced itself; returns the NEXT token [B,1] (the graph's own argmax).  Block compression (every `residual`
         tokens) runs eagerly between replays."""
-        if self.gather is not None:
-            raise NotImplementedError("step_graph() with tp_world > 1: the per-layer all-gather of the attention output is not "
-                                      "captured (the one-GPU gloo staging path copies through the host; with RCCL the "
-                                      "communicator and its buffers would have to be registered for the graph) -- use step()")
+        if self.gather is not None and not self.gather.capturable:
+            raise NotImplementedError("step_graph() with tp_world > 1 needs tp_exchange='peer': the collective exchange is not "
+                                      "captured (its one-GPU gloo staging path copies through the host) -- use step()")
         if token_ids is not None:
             self.tok.copy_(token_ids.view(self.batch, 1))
         if self.graph is None:
@@ -242,6 +254,11 @@ class FastGearDecoder:
             self.pool.compress_all()
             self._sync_state()
         return self.tok
+
+    def close(self):
+        """Release the peer mappings of a sharded decoder (collective: every rank calls it)."""
+        if self.gather is not None and hasattr(self.gather, "close"):
+            self.gather.close()
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, max_length: int, graph: bool = False) -> torch.Tensor:

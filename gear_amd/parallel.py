@@ -47,6 +47,8 @@ class HeadGather:
     and latency-bound: a single hop over xGMI on MI355X, where backend "nccl" is RCCL).
     x [B, H_local*D] on every rank -> [B, world*H_local*D] with rank r's heads at slot r."""
 
+    capturable = False      # (eager only: the staging path goes through the host, and nothing registers RCCL for a capture)
+
     def __init__(self, world: int, batch: int, width: int, dtype, device, group=None):
         import torch.distributed as dist
         self.world, self.B, self.width, self.group = world, batch, width, group
@@ -65,6 +67,107 @@ class HeadGather:
         if self.B == 1:
             return self.buf.view(1, self.world * self.width)          # rank-major == head-major for one row
         return self.buf.view(self.world, self.B, self.width).permute(1, 0, 2).reshape(self.B, self.world * self.width)
+
+
+class PeerHeadGather:
+    """The same exchange without a collective call: every rank's slice is STORED into every rank's exchange area (uncached
+    device memory mapped across processes with hipIpc -- xGMI peer memory on an MI355X node) by one single-workgroup launch per
+    layer per token (gear_xchg_allgather, include/gear_hip.h), flags and epoch counter on the device.  No host involvement, so
+    the launch sits inside the hipGraph of the token step (FastGearDecoder.step_graph with tp_world > 1).
+    x [B, H_local*D] on every rank -> [B, world*H_local*D] with rank r's heads at slot r.
+
+    The handles travel through all_gather_object of whatever process group is up (gloo or RCCL); nothing else uses the group.
+    Construction is collective; `ok` says whether the areas could be set up AND a first exchange returned what the peers sent,
+    agreed across ranks, so every rank takes the same decision when it falls back to HeadGather."""
+
+    capturable = True
+
+    def __init__(self, world: int, rank: int, batch: int, width: int, dtype, device, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib as L
+        self.world, self.rank, self.B, self.width, self.group = world, rank, batch, width, group
+        self.row_bytes = width * torch.empty((), dtype=dtype).element_size()
+        self.lib = L.load()
+        self.base, self.mapped, self.ok = None, [], False
+        err = None
+        try:
+            area = self.lib.gear_xchg_bytes(world, batch * self.row_bytes)
+            if area == 0 or self.row_bytes % 16:
+                raise ValueError(f"exchange of {batch} x {self.row_bytes} bytes over {world} ranks is not supported")
+            with torch.cuda.device(device):
+                base = C.c_void_p()
+                L.check(self.lib.gear_xchg_alloc(area, C.byref(base)), "gear_xchg_alloc")
+                self.base = base.value
+                h = C.create_string_buffer(64)
+                L.check(self.lib.gear_xchg_export(self.base, h), "gear_xchg_export")
+        except Exception as e:                                  # the decision below is collective: no early exit
+            err, h = e, None
+        handles = [None] * world
+        dist.all_gather_object(handles, None if h is None else h.raw, group=group)
+        ptrs = []
+        if err is None and all(x is not None for x in handles):
+            try:
+                with torch.cuda.device(device):
+                    for r in range(world):
+                        if r == rank:
+                            ptrs.append(self.base)
+                            continue
+                        p = C.c_void_p()
+                        L.check(self.lib.gear_xchg_open(handles[r], C.byref(p)), "gear_xchg_open")
+                        self.mapped.append(p.value)
+                        ptrs.append(p.value)
+            except Exception as e:
+                err = e
+        self.error = err
+        self.table = torch.tensor(ptrs if len(ptrs) == world else [0] * world, dtype=torch.int64, device=device)
+        self.out = torch.empty((batch, world * width), dtype=dtype, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        good = [None] * world
+        dist.all_gather_object(good, err is None, group=group)          # (also: every area is mapped before anyone stores)
+        if all(good):
+            # first exchange: rank r sends the value r + 1 everywhere
+            probe = torch.full((batch, width), float(rank + 1), dtype=dtype, device=device)
+            got = self(probe).view(batch, world, width)
+            want = torch.arange(1, world + 1, dtype=dtype, device=device).view(1, world, 1).expand_as(got)
+            fine = bool(torch.equal(got, want)) and int(self.status.item()) == 0
+            dist.all_gather_object(good, fine, group=group)
+            self.ok = all(good)
+            if not fine and self.error is None:
+                self.error = RuntimeError(f"first exchange returned wrong data (status {int(self.status.item())})")
+        if not self.ok:
+            self.close()
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        from . import _lib as L
+        x = x.contiguous()
+        assert x.shape == (self.B, self.width) and x.dtype == self.out.dtype
+        L.check(self.lib.gear_xchg_allgather(L.ptr(x), self.B, self.row_bytes, self.world, self.rank, L.ptr(self.table),
+                                             L.ptr(self.out), L.ptr(self.status), L.stream_ptr(x)), "gear_xchg_allgather")
+        return self.out
+
+    def check(self):
+        """Raise if an exchange ever gave up waiting for a peer (reads one word from the device: not for the token loop)."""
+        if int(self.status.item()):
+            raise RuntimeError("gear_xchg_allgather: a peer did not deliver its slice within the time limit")
+
+    def close(self):
+        """Unmap the peers' areas and free the own one.  Collective in spirit: call it on every rank once no exchange is in
+        flight (the owner's free comes after a barrier so no peer still has stores under way)."""
+        import torch.distributed as dist
+        if self.base is None and not self.mapped:
+            return
+        torch.cuda.synchronize()
+        for p in self.mapped:
+            self.lib.gear_xchg_close(p)
+        self.mapped = []
+        try:
+            dist.barrier(group=self.group)
+        except Exception:
+            pass
+        if self.base is not None:
+            self.lib.gear_xchg_free(self.base)
+            self.base = None
 
 
 def shard_attention_weights(full_attn, local_attn):

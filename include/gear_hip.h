@@ -379,6 +379,32 @@ int gear_gemv_qkv_rope(const void* x, const void* delta, const void* norm_w, flo
                        int Hq, int Hkv, int D, int pos, int slot, int wcap, float theta, const void* dyn_state,
                        void* res_out, void* q_out, void* kwin, void* vwin, void* stream);
 
+/* ---- the exchange step of the head-sharded decode path (the reference has no distributed code) -------
+ * With the KV heads split across ranks (one process per GPU) the only data any rank needs from the others is their slice of
+ * the attention output in front of o_proj (cuda_supported_gear/modeling_llamagear.py:478-482 merges the heads).  Instead of a
+ * collective call per layer per token, every rank owns an "exchange area" of uncached device memory that its peers map with
+ * hipIpc (xGMI peer memory; the same calls work between two processes on one GPU, which is how the tests run it) and
+ * gear_xchg_allgather is ONE single-workgroup launch that stores the local slice into every area, raises a flag, waits for
+ * the peers' flags and copies the gathered rows out -- nothing in it needs the host, so it lives inside the hipGraph of the
+ * token step.
+ *   gear_xchg_bytes     size of an area for `world` ranks and slices of bytes_per_rank (0: world out of range, max 64)
+ *   gear_xchg_alloc     uncached, zeroed, exportable; gear_xchg_free releases it (after the peers closed their mappings)
+ *   gear_xchg_export    64-byte handle to send to the peers (any byte transport); gear_xchg_open maps a peer's area in this
+ *                       process, gear_xchg_close unmaps it
+ *   gear_xchg_allgather src [rows, row_bytes] of this rank -> out [rows, world, row_bytes] (rank r's bytes at slot r of every
+ *                       row); peers = DEVICE array of `world` area pointers as mapped in this process (peers[rank] = the own
+ *                       area); row_bytes % 16 == 0.  Every rank must issue the same sequence of calls.  A rank whose peers do
+ *                       not show up within 3 s sets bit 0 of *status (device int32, may be NULL) and returns garbage rather
+ *                       than hang. */
+size_t gear_xchg_bytes(int world, size_t bytes_per_rank);
+int gear_xchg_alloc(size_t bytes, void** ptr);
+int gear_xchg_free(void* ptr);
+int gear_xchg_export(const void* ptr, void* handle64);
+int gear_xchg_open(const void* handle64, void** ptr);
+int gear_xchg_close(void* ptr);
+int gear_xchg_allgather(const void* src, int rows, size_t row_bytes, int world, int rank, const void* peers, void* out,
+                        void* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
