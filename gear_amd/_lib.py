@@ -33,6 +33,7 @@ SIGNATURES = {
     "gear_cache_tiles_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "gear_outlier_chunk_index_ex": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
     "gear_quant_rows_whole": (_i, [_vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "gear_quant_rows_ragged": (_i, [_vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gear_quant_pack_lastdim": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_quant_pack_k": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gear_unpack_dequant_lastdim": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),

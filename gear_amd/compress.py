@@ -337,6 +337,26 @@ def quant_whole_rows(x: torch.Tensor, layout: str, bits: int, mode="fp32", oidx:
     return (y, err) if want_err else y
 
 
+def quant_rows_ragged(x: torch.Tensor, layout: str, bits: int, group: int, k_out: int = 0, mode="fp32", want_err: bool = False):
+    """gears_channelQ / gears_tokenQ on rows of any length (csrc/rows_ragged.hip): selection of the k_out smallest / largest and
+    the fill mean over the WHOLE row, quantization of the first floor(len / group) * group elements in groups of `group`, the
+    tail untouched (compress_function.py:107-122, :261-333).  x fp16 [B,H,T,D]; layout "k": a row = one channel over the T
+    tokens, "v": a row = one token across the heads.  Returns y fp16 [B,H,T,D] (and the error x - y when want_err)."""
+    assert x.dim() == 4 and x.dtype == torch.float16 and layout in ("k", "v")
+    x = x.contiguous()
+    L.require_gpu(x)
+    B, H, T, D = x.shape
+    y = torch.empty_like(x)
+    err = torch.empty_like(x) if want_err else None
+    if layout == "k":
+        geom = (B * H * D, D, T * D, 1, T, 1, D)
+    else:
+        geom = (B * T, T, H * T * D, D, H, D, T * D)
+    rc = L.load().gear_quant_rows_ragged(L.ptr(x), *geom, group, bits, _MODES[mode], k_out, L.ptr(y), L.ptr(err), L.stream_ptr(x))
+    L.check(rc, "gear_quant_rows_ragged")
+    return (y, err) if want_err else y
+
+
 def decompress(p: Payload, transposed_out: bool = False) -> torch.Tensor:
     """Payload -> fp16 [B,H,T,D] (or K^T [B,H,D,T] when transposed_out and kind == 'k')."""
     B, H, T, D = p.shape

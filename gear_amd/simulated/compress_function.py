@@ -9,8 +9,10 @@ where the result is a pure quantize/dequantize (KIVI_V2).
 All of the dispatcher's methods are built: KIVI_V2, KCVT, GEAR, GEAR-KCVT, GEARL, GEARL-KCVT (the -KCVT variants quantize
 with ONE group per channel row over the whole sequence / per token row over all heads: gear_quant_rows_whole) and the
 token_preserving window of the KCVT / KIVI_V2 branches (:433-464).  Restrictions (the reference has none of them, it is torch
-eager): head_dim-local group sizes must divide head_dim, sequence lengths must be a multiple of the group size (of 16 where
-outliers are selected), tensors are fp16-representable.  The GEAR paths return fp16 (the reference returns the unrounded
+eager): head_dim-local group sizes must divide head_dim, tensors are fp16-representable.  Sequence lengths: the GEAR method takes
+any length like the reference (K: the tail past the last whole group stays unquantized, compress_function.py:107-122 -- csrc/
+rows_ragged.hip; V rows are tokens); the methods whose reference reshapes T into whole groups (KIVI_V2, GEARL: :49-52) need a
+multiple of the group here as there.  The GEAR paths return fp16 (the reference returns the unrounded
 fp32 sum and its caller applies .half(), compress_function.py:481, :494).
 """
 from __future__ import annotations
@@ -84,6 +86,8 @@ def gears_channelQ(input, quantize_bit, group_size=128, sparsity=0.0):
     k = _k_rows(B, H, T, D, sparsity)
     if group_size == T and group_size not in (32, 64):
         return _gears_whole(input, "k", quantize_bit, k)[0]
+    if T % group_size:      # the tail past the last whole group stays unquantized (:107-122)
+        return C.quant_rows_ragged(_half(input), "k", quantize_bit, group_size, k_out=k, mode="fp32")
     p = C.compress_key(_half(input), quantize_bit, group_size, k_out=k, mode="fp32")
     return C.decompress(p)
 
@@ -121,6 +125,19 @@ def _gear_whole(input, layout, bits, k, rank, loop, P0):
     return (y.float() + torch.matmul(Q, P.transpose(2, 3))).half()
 
 
+def _gear_ragged(input, bits, group, k, rank, loop, P0):
+    """gearslkivi_channelQ_new for a sequence length that is not a multiple of the group: gears_channelQ with the unquantized
+    tail (rows_ragged.hip) + rank-r approximation of input - output over ALL tokens (the tail's error rows are zero)."""
+    y, err = C.quant_rows_ragged(_half(input), "k", bits, group, k_out=k, mode="fp32", want_err=True)
+    if rank <= 0:
+        return y
+    B, H, T, D = y.shape
+    if P0 is None:
+        P0 = C.draw_p0(B, H, T, D, rank, y.device)
+    P, Q = C.lowrank(err, rank, loop, P0, out_dtype=torch.float32)
+    return (y.float() + torch.matmul(Q, P.transpose(2, 3))).half()
+
+
 def gears_tokenQ(input, quantize_bit, group_size=128, sparsity=0.0):
     """compress_function.py:297-333: V outliers per token row (across heads) + fp32 token quantization -> fp16."""
     B, H, T, D = input.shape
@@ -139,6 +156,8 @@ def gearslkivi_channelQ_new(input, quantize_bit, group_size=128, sparsity=0.0, r
     k = _k_rows(B, H, T, D, sparsity)
     if group_size == T and group_size not in (32, 64):
         return _gear_whole(input, "k", quantize_bit, k, rank, loop, P0)
+    if T % group_size:
+        return _gear_ragged(input, quantize_bit, group_size, k, rank, loop, P0)
     p = C.compress_key(_half(input), quantize_bit, group_size, k_out=k, rank=rank, loop=loop, mode="fp32", P0=P0)
     return C.decompress(p)
 

@@ -181,6 +181,19 @@ int gear_quant_rows_whole(const void* x, int64_t n_rows, int rows_inner, int64_t
                           int seglen, int64_t seg_stride, int bits, int mode, const void* oidx, int k, void* y, void* err,
                           void* stream);
 
+/* ---- a11 / a12 with a sequence length that is not a multiple of the group ------------------------------------------------
+ * gears_channelQ / gears_tokenQ (GenerationBench/.../Simulated/compress_function.py:261-333) on rows of ANY length: the k
+ * smallest / k largest of the WHOLE row are selected inside the kernel (ties: lower index first) and replaced by the whole
+ * row's mean for the quantization; fake_groupwise_channel_asymmetric_quantization_cluster then quantizes the first
+ * floor(len / group) * group elements in groups of `group` consecutive elements and leaves the tail untouched (:107-122).
+ * Geometry as gear_compress_rows; len = nseg * seglen <= 16384, at most 2048 groups per row, 2k <= len.
+ *   y   fp16, same geometry: quantize -> dequantize of the prefix, outliers and tail keep their original value
+ *   err optional fp16 x - y (0 at the outliers and in the tail)
+ */
+int gear_quant_rows_ragged(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride, int nseg,
+                           int seglen, int64_t seg_stride, int group, int bits, int mode, int k, void* y, void* err,
+                           void* stream);
+
 /* ---- a4 / a10: low-rank power iteration ---------------------------------------------------------------------
  * Replaces headwise_lrap (cuda_supported_gear/quant/new_pack.py:291-311) and fake_poweriteration_group
  * (compress_function.py:69-98).  for i < loop: [last: P = orth(P)] Q = E P [last: Q = orth(Q)] P = E^T Q.

@@ -14,6 +14,7 @@ Fixture map:
   f4_fakequant.npz    a9     token / channel fake quantizers (fp16 and fp32 arithmetic)
   f5_outlier.npz      a11    gears_channelQ / gears_tokenQ (+ an explicit tie case)
   f6_insert.npz       a12    compress_insert_function for KIVI_V2 / GEARL / GEAR
+  f10_ragged.npz      a11/a12 gears_channelQ and method GEAR at sequence lengths that are not a multiple of the group
   f9_kcvt.npz         a12    compress_insert_function for KCVT / GEAR-KCVT / GEARL-KCVT and the token_preserving window
   f7_gemv.npz         a6     inp @ dequant_weight_outer recipe of CSG/quant/gemv.py:93-126 (MHA + MQA)
 """
@@ -358,9 +359,38 @@ def f9():
     save("f9_kcvt.npz", **d)
 
 
+# ------------------------------------------------------------------------------------------- F10
+def f10():
+    """Sequence lengths that are NOT a multiple of the group (every real prompt of the simulated path): gears_channelQ leaves the
+    T mod g tail of a channel unquantized (compress_function.py:107-122) while selecting outliers and taking the fill mean over all
+    T tokens; method GEAR through the dispatcher on such a tensor (K and V, P0 captured)."""
+    d = {}
+    for (T, g) in ((200, 64), (150, 32), (70, 64)):
+        B, H, D = 1, 2, 128
+        ks = [outlier_k(B * H * T * D, B, T, s) for s in (0.02, 0.05)]
+        xn = detie(npy(randn_half(30 + T, (B, H, T, D))), ks, chan=True, tok=False)
+        x = torch.from_numpy(xn)
+        d[f"x_T{T}"] = xn
+        for (s, b) in ((0.0, 2), (0.02, 2), (0.02, 4), (0.05, 4)):
+            d[f"chan_T{T}_g{g}_s{int(s * 100)}_b{b}"] = npy(cf.gears_channelQ(x.clone(), b, g, s))
+    B, H, T, D = 1, 4, 200, 128
+    ks = [outlier_k(B * H * T * D, B, T, 0.02)]
+    k = torch.from_numpy(detie(npy(randn_half(41, (B, H, T, D))), ks, chan=True, tok=False))
+    v = torch.from_numpy(detie(npy(randn_half(42, (B, H, T, D))), ks, chan=False, tok=True))
+    d["k"], d["v"] = npy(k), npy(v)
+    for (b, r, left) in ((2, 8, 0.02), (4, 4, 0.02), (2, 4, 0.0)):
+        tag = f"GEAR_b{b}_r{r}_s{int(left * 100)}"
+        torch.manual_seed(1000 + b + r)
+        with RandCapture() as rc:
+            ko, vo = cf.compress_insert_function(k.clone(), v.clone(), _cfg("GEAR", b, 64, r, 3, left), 0, prefill=True)
+        d[tag + "_k"], d[tag + "_v"] = npy(ko), npy(vo)
+        d[tag + "_P0k"], d[tag + "_P0v"] = npy(rc.drawn[0]), npy(rc.drawn[2])
+    save("f10_ragged.npz", **d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (f1, f2, f3, f4, f5, f6, f7, f9):
+    for fn in (f1, f2, f3, f4, f5, f6, f7, f9, f10):
         if not only or fn.__name__ in only:
             fn()

@@ -370,3 +370,27 @@ def test_fused_cpu_gear_path_equals_the_glue_path(B, H, T, bits, g, s, r):
     gv = orc.gear_tensor(v, "v", bits, g, s, r, 3, P0v)
     assert np.array_equal(gk.view(np.uint16), rk.view(np.uint16))
     assert np.array_equal(gv.view(np.uint16), rv.view(np.uint16))
+
+
+F10_CHAN = [(T, g, s, b) for (T, g) in ((200, 64), (150, 32), (70, 64)) for (s, b) in ((0.0, 2), (0.02, 2), (0.02, 4), (0.05, 4))]
+
+
+@pytest.mark.parametrize("T,g,s,b", F10_CHAN)
+def test_f10_ragged_channel_rows_bit_exact(golden, T, g, s, b):
+    """Sequence length not a multiple of the group: the T mod g tail of every channel stays as it is, selection and fill mean use all
+    T tokens (compress_function.py:107-122, :261-296).  Oracle vs the reference-executed fixture, bit for bit."""
+    f = golden("f10_ragged.npz")
+    x = f[f"x_T{T}"]
+    got = orc.gears_channelQ(x, b, g, s)
+    assert np.array_equal(got.view(np.uint16), f[f"chan_T{T}_g{g}_s{int(s * 100)}_b{b}"].view(np.uint16))
+    assert np.array_equal(got[:, :, (T // g) * g:], x[:, :, (T // g) * g:])          # (the tail is the input)
+
+
+@pytest.mark.parametrize("case", ["GEAR_b2_r8_s2", "GEAR_b4_r4_s2", "GEAR_b2_r4_s0"])
+def test_f10_ragged_gear_method(golden, case):
+    f = golden("f10_ragged.npz")
+    b, r, left = int(case.split("_b")[1][0]), int(case.split("_r")[1][0]), int(case.split("_s")[1]) / 100
+    k, v = orc.compress_insert_function(f["k"], f["v"], "GEAR", b, 64, rank=r, rankv=r, loop=3, left=left,
+                                        P0k=f[case + "_P0k"], P0v=f[case + "_P0v"])
+    assert rel_fro(k, f[case + "_k"]) < 1e-3
+    assert rel_fro(v, f[case + "_v"]) < 1e-3
