@@ -625,7 +625,12 @@ def main():
     if rank == 0 and world == 1 and not args.layers and not args.emulate_world:
         res["attn_decode"]["one_layer_streaming_cache_by_batch"] = attn_decode_by_batch(cfg, dev)
     if not args.no_decode and not args.layers and not args.emulate_world:
-        dec = decode_tokens_per_s(cfg, dev, world, rank, args.decode_tokens)     # (every rank takes part when sharded)
+        try:
+            dec = decode_tokens_per_s(cfg, dev, world, rank, args.decode_tokens)     # (every rank takes part when sharded)
+        except Exception as e:           # the decode leg is a secondary figure: the line with `value` must still come out
+            if world == 1:
+                raise
+            dec = {"error": f"rank {rank}: {type(e).__name__}: {e}", "tokens_per_s": 1e-9}
         if dist is not None:
             t = torch.tensor([1.0 / dec["tokens_per_s"]], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)                           # slowest rank
