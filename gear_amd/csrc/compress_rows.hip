@@ -20,54 +20,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "rowgeom.h"
 
 namespace {
-
-struct RowGeom {
-    int rows_inner;            // row r -> (r / rows_inner, r % rows_inner)
-    int64_t outer_stride;      // elements
-    int64_t inner_stride;      // elements
-    int nseg, seglen;          // row = nseg segments of seglen contiguous elements
-    int64_t seg_stride;        // elements
-    int seglen_shift;          // log2(seglen) if it is a power of two, else -1
-    int group_shift;           // log2(group) (group is a power of two)
-    // geometry of code / scale / mn (elements of the fp16 tensor they describe): equal to the input's unless the payload is
-    // written in place into a larger pre-allocated tensor (the streaming cache); the error output follows the input.
-    int64_t o_outer_stride, o_inner_stride, o_seg_stride;
-    int o_list_outer;          // row r's sparse list is list row (r / rows_inner) * o_list_outer + r % rows_inner
-};
-
-// integer divisions by run-time values cost ~30-100 VALU instructions per lane on this VALU-bound kernel: every
-// geometry quotient goes through shifts (power-of-two group / segment length) or 32-bit scalar math (row index)
-__device__ __forceinline__ void seg_pos(const RowGeom& gm, int j, int& seg, int& pos) {
-    if (gm.nseg == 1) { seg = 0; pos = j; }
-    else if (gm.seglen_shift >= 0) { seg = j >> gm.seglen_shift; pos = j & (gm.seglen - 1); }
-    else { seg = j / gm.seglen; pos = j % gm.seglen; }
-}
-__device__ __forceinline__ int64_t row_base_of(const RowGeom& gm, int64_t r) {
-    const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;   // n_rows < 2^31 (checked on the host)
-    const uint32_t qo = ru / ri;
-    return (int64_t)qo * gm.outer_stride + (int64_t)(ru - qo * ri) * gm.inner_stride;
-}
-
-__device__ __forceinline__ int64_t lrow_of(const RowGeom& gm, int64_t r) {
-    const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;
-    const uint32_t qo = ru / ri;
-    return (int64_t)qo * gm.o_list_outer + (int64_t)(ru - qo * ri);
-}
-__device__ __forceinline__ int64_t row_base_out(const RowGeom& gm, int64_t r) {
-    const uint32_t ru = (uint32_t)r, ri = (uint32_t)gm.rows_inner;
-    const uint32_t qo = ru / ri;
-    return (int64_t)qo * gm.o_outer_stride + (int64_t)(ru - qo * ri) * gm.o_inner_stride;
-}
-
-__device__ __forceinline__ uint32_t sort_key(uint32_t hbits) {  // fp16 bits -> ascending-order key (16 bit)
-    if (hbits == 0x8000u) hbits = 0u;  // -0 == +0 (the oracle / torch.topk compare values)
-    return (hbits & 0x8000u) ? (~hbits & 0xFFFFu) : (hbits | 0x8000u);
-}
-__device__ __forceinline__ uint32_t key_to_bits(uint32_t key) {  // inverse of sort_key
-    return (key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu);
-}
 
 // inclusive scan over the block of a 64-bit packed counter (fields never overflow into each other)
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* wave_tot,
@@ -156,30 +111,6 @@ __device__ __forceinline__ uint32_t wave_bitonic_sort(uint32_t v) {
     }
     return v;  // lane i holds the i-th element of the sorted order
 }
-
-template <int BITS, int MODE>
-__device__ __forceinline__ int quant_fast(float v, float mn, float scale, float inv, int levels) {
-    if (scale == 0.0f) return 0;
-    if (MODE == 0) {
-        float t1 = hround(v - mn);
-        float c = hround(div_rn(t1, scale));
-        c = fminf(fmaxf(c, 0.0f), (float)levels);
-        return (int)rintf(c);
-    } else {
-        // (v - mn) / scale with an IEEE-exact result: multiply by the reciprocal, and redo the division only when the
-        // approximate quotient is within 1e-5 of a rounding tie (x.5) -- the only place the two can round differently.
-        float t = v - mn;
-        float c = t * inv;
-        float r = rintf(c);
-        if (fabsf(fabsf(c - r) - 0.5f) < (BITS == 8 ? 1e-3f : 1e-5f)) {   // (8-bit quotients reach 255: 1 ulp is 3e-5)
-            c = div_rn(t, scale);
-            r = rintf(c);
-        }
-        r = fminf(fmaxf(r, 0.0f), (float)levels);
-        return (int)r;
-    }
-}
-
 
 template <int BITS, int MODE, typename ST>
 __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
@@ -1414,6 +1345,10 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
 
 }  // namespace
 
+bool gear_rows_multi_supported(int64_t len, int group, int k);
+int gear_rows_multi_launch(const void* x, const void* gm, int64_t n_rows, int64_t len, int group, int bits, int mode, int k,
+                           void* code, void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, hipStream_t st);
+
 static double inv_norm_cdf(double p) {
     static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
                                1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
@@ -1465,6 +1400,12 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
         if (frac < 0.45) zthr = (float)(-inv_norm_cdf(frac));
     }
     hipStream_t st = (hipStream_t)stream;
+    // short rows (head shards: 128 .. 512 elements, a handful of outliers): eight rows per wave (rows_multi.hip)
+    if (!gear_options().rows_wg_only && !gear_options().rows_v1 && !gear_options().rows_hist_only && gear_rows_multi_supported(len, group, k)) {
+        gear_rows_multi_launch(x, &gm, n_rows, len, group, bits, mode, k, code, scale, mn, err, oidx, oval, omean, st);
+        GEAR_CHECK_LAUNCH("gear_compress_rows");
+        return 0;
+    }
     dim3 block(threads), grid((unsigned)n_rows);
 #define GO(B, M, STT)                                                                                                  \
     hipLaunchKernelGGL((compress_rows_kernel<B, M, STT>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, zthr, \

@@ -45,6 +45,7 @@ struct DGeom {
     int len, group, T, D, r, k, rpb;
     int patch;   // outliers: 1 = overwrite in global memory after the dense pass (no LDS table), 0 = LDS table
     int trows;   // rows covered by one fill of the LDS outlier table (divides rpb; the block refills it rpb / trows times)
+    int rpar;    // short rows (len / 16 < 64 lanes): rpar rows side by side in the block's one wave, lane = (row slot, 16 columns)
     int64_t n_rows;
 };
 
@@ -61,7 +62,10 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     constexpr int RVS = RV > 0 ? RV : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];   // [trows][len] fp16 outlier values (0xFFFF = none)
     const int tid = threadIdx.x;
-    const int j0 = tid * 16;
+    // short rows: the wave holds rpar rows at a time, lane = (row slot sub, 16-column chunk lc); otherwise one row, lane = chunk
+    const int lpr = g.len >> 4;
+    const int lc = g.rpar > 1 ? tid % lpr : tid, sub = g.rpar > 1 ? tid / lpr : 0;
+    const int j0 = lc * 16;
     const bool active = j0 < g.len;
     const int64_t row0 = (int64_t)blockIdx.x * g.rpb;
     const int r = g.r;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     // Blocks walk their 16 rows in a rotated order (a multiple of the table period, by block index) so that blocks running in
     // near lockstep do not all write at the same offset of their 128 KB regions (HBM channel camping, tools/ubench/
     // store_pattern.hip; worth 2 % here)
-    const int rot = (g.rpb == 16 && row0 + 16 <= g.n_rows) ? 4 * (int)((blockIdx.x ^ (blockIdx.x >> 2)) & 3) : 0;
+    const int rot = (g.rpb == 16 && g.rpar == 1 && row0 + 16 <= g.n_rows) ? 4 * (int)((blockIdx.x ^ (blockIdx.x >> 2)) & 3) : 0;
     auto phys = [&](int ri) { return rot ? ((ri + rot) & 15) : ri; };
     auto prefetch_entries = [&](int rbase) {
 #pragma unroll
@@ -253,19 +257,21 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     // Two named row buffers in ping-pong (no register copies between them: a copy of a buffer whose loads are still in flight
     // makes the compiler wait for them on the spot, which is what a rotating "cur = next" pipeline did): the loads of row
     // i + 1 are issued before row i is computed and stored.
+    // (step li of the loop: block rows li * rpar .. li * rpar + rpar - 1, this lane's is li * rpar + sub)
     RowIn bufA = {}, bufB = {};
-    if (nrows > 0) fetch(0, bufA);
-    for (int ri = 0; ri < nrows_blk; ri += 2) {
-        before_row(ri);
+    const int R = g.rpar;
+    if (sub < nrows) fetch(sub, bufA);
+    for (int rb = 0; rb < nrows_blk; rb += 2 * R) {
+        before_row(rb);
         if (active) {
-            if (ri + 1 < nrows) fetch(ri + 1, bufB);
-            compute_row(ri, bufA);
+            if (rb + R + sub < nrows) fetch(rb + R + sub, bufB);
+            if (rb + sub < nrows) compute_row(rb + sub, bufA);
         }
-        if (ri + 1 < nrows_blk) {
-            before_row(ri + 1);
+        if (rb + R < nrows_blk) {
+            before_row(rb + R);
             if (active) {
-                if (ri + 2 < nrows) fetch(ri + 2, bufA);
-                compute_row(ri + 1, bufB);
+                if (rb + 2 * R + sub < nrows) fetch(rb + 2 * R + sub, bufA);
+                if (rb + R + sub < nrows) compute_row(rb + R + sub, bufB);
             }
         }
     }
@@ -378,9 +384,15 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     int trows = rpb < 4 ? rpb : 4;            // rows per fill of the LDS outlier table (35 KB at 4096 columns)
     if (trows > rpb) trows = rpb;
     while (trows > 1 && (rpb % trows != 0 || (size_t)trows * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024)) trows >>= 1;
+    // short rows (head shards: 128 .. 512 elements): 8 / 4 / 2 rows side by side in the one wave of the block
+    int rpar = 1;
+    if (len / 16 < 64 && 64 % (len / 16) == 0 && rpb % (64 / (len / 16)) == 0) {
+        rpar = (int)(64 / (len / 16));
+        if (trows < rpar) trows = rpar;            // one fill of the table covers at least the rows in flight
+    }
     const size_t shmem = (k > 0 && !patch) ? (size_t)trows * len * 2 : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
-    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, n_rows};
+    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, rpar, n_rows};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));
