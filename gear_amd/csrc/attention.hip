@@ -569,61 +569,38 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
             vmv[i] = ok ? mv : 0.0f;
         }
     }
-    uint4 kq8 = {0, 0, 0, 0}, vq8 = {0, 0, 0, 0}, kp8 = {0, 0, 0, 0}, vp8 = {0, 0, 0, 0};
-    uint4 kq8b = {0, 0, 0, 0}, vq8b = {0, 0, 0, 0}, kp8b = {0, 0, 0, 0}, vp8b = {0, 0, 0, 0};   // columns 8..15 (rank 16)
-    if (a.rk) {
-        const uint16_t* kp_b = a.kP + (slab ? (int64_t)seg_s1 : (int64_t)seg_s0) * a.kP_seg_stride + bhk * AD * RW;
-        const uint4* pp = (const uint4*)(kp_b + (uint32_t)dq * RW);
-        kp8 = pp[0];
-        if (R16) kp8b = pp[1];
-        if (tid < tn) {
-            const uint4* qp = (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RW + (uint32_t)tid * RW);
-            kq8 = qp[0];
-            if (R16) kq8b = qp[1];
-        }
-    }
-    if (a.rv) {
-        const uint16_t* vp_b = a.vP + (slab ? (int64_t)seg_s1 : (int64_t)seg_s0) * a.vP_seg_stride + bhk * AD * RW;
-        const uint4* pp = (const uint4*)(vp_b + (uint32_t)dq * RW);
-        vp8 = pp[0];
-        if (R16) vp8b = pp[1];
-        if (tid < tn) {
-            const uint4* qp = (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RW + (uint32_t)tid * RW);
-            vq8 = qp[0];
-            if (R16) vq8b = qp[1];
-        }
-    }
+    // Every load below is UNCONDITIONAL (a dummy address -- the query row -- where the payload has no such part): a load inside an
+    // `if` whose result meets a default value at the join makes the compiler wait for it at the end of the block, and the four
+    // such blocks that stood here were four serialized memory round trips before the first score was computed (per-phase
+    // timestamps: 9.4 of the workgroup's 16.8 us with outliers in the cache; 7.5 of 14.0 now).  The values are only looked at
+    // under the same conditions further down.
+    const uint4* dummy16 = (const uint4*)(a.q + bhq * AD);
+    const uint8_t* dummy1 = (const uint8_t*)dummy16;
+    const uint32_t trow = (uint32_t)min(tid, tn - 1);                       // (threads past the chunk read its last row)
+    const int64_t fseg = slab ? (int64_t)seg_s1 : (int64_t)seg_s0;
+    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RW + (uint32_t)dq * RW) : dummy16;
+    const uint4* kqp = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RW + trow * RW) : dummy16;
+    const uint4* vpp = a.rv ? (const uint4*)(a.vP + fseg * a.vP_seg_stride + bhk * AD * RW + (uint32_t)dq * RW) : dummy16;
+    const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RW + trow * RW) : dummy16;
+    const uint4 kp8 = kpp[0], kq8 = kqp[0], vp8 = vpp[0], vq8 = vqp[0];
+    const uint4 kp8b = kpp[R16 ? 1 : 0], kq8b = kqp[R16 ? 1 : 0], vp8b = vpp[R16 ? 1 : 0], vq8b = vqp[R16 ? 1 : 0];   // columns 8..15 (rank 16)
 
     // outlier list ranges of this chunk (chunk index present): K list (channel dq, side tid >> 7), V list (token tid & 127,
     // side tid >> 7) -- two byte loads each, issued with everything else
-    int ki0 = 0, ki1 = 0, vi0 = 0, vi1 = 0;
-    if (a.kochunk && (a.kkb == 0 || t0 < a.seg0)) {
-        const int64_t list = (bhk * AD + dq) * 2 + (tid >> 7);
-        ki0 = a.kochunk[list * a.nbk + split];
-        ki1 = a.kochunk[list * a.nbk + split + 1];
-    }
-    if (a.vochunk && (tid & (SC - 1)) < tn) {
-        const int64_t list = ((int64_t)b * a.tcap_v + t0 + (tid & (SC - 1))) * 2 + (tid >> 7);
-        vi0 = a.vochunk[list * a.nbv + hkv];
-        vi1 = a.vochunk[list * a.nbv + hkv + 1];
-    }
+    const bool has_kidx = a.kochunk && (a.kkb == 0 || t0 < a.seg0);
+    const uint8_t* kip = has_kidx ? a.kochunk + ((bhk * AD + dq) * 2 + (tid >> 7)) * a.nbk + split : dummy1;
+    const uint8_t* vip = a.vochunk ? a.vochunk + (((int64_t)b * a.tcap_v + t0 + min(tid & (SC - 1), tn - 1)) * 2 + (tid >> 7)) * a.nbv + hkv : dummy1;
+    const int ki0 = kip[0], ki1 = kip[1], vi0 = vip[0], vi1 = vip[1];
 
     // sparse tiles of this chunk: counts + the first two K entries / one V entry per 64-token block and thread, position known
-    int kc_n = -1, vc_n0 = -1, vc_n1 = -1;
-    uint32_t ke0 = 0u, ke1 = 0u, ve0 = 0u, ve1 = 0u;
-    if (a.ktile && a.kk > 0) {
-        kc_n = a.kcnt[bhk * a.nck + split];
-        const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
-        ke0 = kt[tid];
-        ke1 = kt[tid + 256];
-    }
-    if (a.vtile && a.kv > 0) {
-        const int64_t vb = bhk * a.nblk + 2 * split;
-        vc_n0 = a.vcnt[vb];
-        vc_n1 = (tn > 64) ? a.vcnt[vb + 1] : 0;
-        ve0 = a.vtile[vb * a.vtile_cap + tid];
-        ve1 = (tn > 64) ? a.vtile[(vb + 1) * a.vtile_cap + tid] : 0u;
-    }
+    const bool has_ktile = a.ktile && a.kk > 0, has_vtile = a.vtile && a.kv > 0;
+    const int64_t vb = bhk * a.nblk + 2 * split;
+    const int* kcp = has_ktile ? a.kcnt + bhk * a.nck + split : (const int*)dummy16;
+    const uint32_t* ktp = has_ktile ? a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap + tid : (const uint32_t*)dummy16;
+    const int* vcp = has_vtile ? a.vcnt + vb : (const int*)dummy16;
+    const uint32_t* vtp = has_vtile ? a.vtile + vb * a.vtile_cap + tid : (const uint32_t*)dummy16;
+    const int kc_raw = kcp[0], vc_raw0 = vcp[0], vc_raw1 = vcp[1];
+    const uint32_t ke0 = ktp[0], ke1 = ktp[has_ktile ? 256 : 0], ve0 = vtp[0], ve1 = vtp[has_vtile ? a.vtile_cap : 0];
 
     // ------------------------------------------------------------------ 1. scores
     if (tid < AD) qs[tid] = qv;
@@ -682,6 +659,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     if (a.kk > 0) {   // K outliers inside the chunk: s[t] += q[d] (val - dequant(t, d))
         if (tid < SC) s[tid] = sv;
         __syncthreads();
+        const int kc_n = has_ktile ? kc_raw : -1;
         if (kc_n >= 0) {   // chunk-major tile: s[t] += q[d] * (value - dequant), entries prefetched above
             if (tid < kc_n) atomicAdd(&s[(ke0 >> 7) & 127u], qs[ke0 & 127u] * h2f_bits((uint16_t)(ke0 >> 16)));
             if (tid + 256 < kc_n) atomicAdd(&s[(ke1 >> 7) & 127u], qs[ke1 & 127u] * h2f_bits((uint16_t)(ke1 >> 16)));
@@ -800,6 +778,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         if (tid < AD) oacc[tid] = o;
         __syncthreads();
         const int tok = tid & (SC - 1), side = tid >> 7;   // one sorted list per (token, side) = per thread
+        const int vc_n0 = has_vtile ? vc_raw0 : -1, vc_n1 = has_vtile ? ((tn > 64) ? vc_raw1 : 0) : -1;
         if (vc_n0 >= 0 && vc_n1 >= 0) {   // block tiles: o[d] += p[t] * (value - dequant)
             if (tid < vc_n0) atomicAdd(&oacc[(ve0 >> 6) & 127u], s[ve0 & 63u] * h2f_bits((uint16_t)(ve0 >> 16)));
             if (tid < vc_n1) atomicAdd(&oacc[(ve1 >> 6) & 127u], s[64 + (ve1 & 63u)] * h2f_bits((uint16_t)(ve1 >> 16)));
