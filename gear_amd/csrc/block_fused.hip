@@ -161,8 +161,14 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
 #pragma unroll 1
     for (int h0 = 0; h0 < H; h0 += 8) {              // the values of eight heads are loaded together (an L2 round trip per head
         uint32_t xw8[8];                              // in a dependent loop was most of this function's time)
+        // (clamped indices, no load under a per-element condition: `h < H ? load : 0` compiles to a load and a full wait per head)
+        if (x_in_lds) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) xw8[j] = (h0 + j < H) ? (x_in_lds ? xs[(h0 + j) * 64 + lane] : xrow[(h0 + j) * hstride]) : 0u;
+            for (int j = 0; j < 8; j++) xw8[j] = xs[min(h0 + j, H - 1) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) xw8[j] = xrow[(int64_t)min(h0 + j, H - 1) * hstride];
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int h = h0 + j;

@@ -832,13 +832,25 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
     const int64_t bh = blockIdx.y;
     const int T = a.T, ntiles = T >> 6;
     uint16_t* etile = etiles + wave * 32 * ET_PITCH;
-    for (int idx = tid; idx < KD * RP; idx += 256) {
-        const int k = idx / RP, m = idx % RP;
-        const float w = a.W[(bh * KD + k) * RP + m];
-        const uint16_t hi = f2h_bits(w);
-        const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
-        Ah[pos] = hi;
-        Al[pos] = f2h_bits(w - h2f_bits(hi));
+    {   // W -> LDS as fp16 head + remainder (the KD * RP / 256 loads of a thread issued together)
+        constexpr int NWL = (KD * RP + 255) / 256;
+        float wv[NWL];
+#pragma unroll
+        for (int u = 0; u < NWL; u++) {
+            const int idx = tid + 256 * u;
+            wv[u] = a.W[bh * KD * RP + min(idx, KD * RP - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < NWL; u++) {
+            const int idx = tid + 256 * u;
+            if (idx < KD * RP) {
+                const int k = idx / RP, m = idx % RP;
+                const uint16_t hi = f2h_bits(wv[u]);
+                const int pos = ((k >> 3) * RP + m) * 8 + (k & 7);
+                Ah[pos] = hi;
+                Al[pos] = f2h_bits(wv[u] - h2f_bits(hi));
+            }
+        }
     }
     const int tile_lo = blockIdx.x * QP_TPW, tile_hi = min(ntiles, tile_lo + QP_TPW);
     // scale / mn of the workgroup's tiles through LDS, read once as whole sectors: fetched per tile they are 4 bytes per channel
@@ -849,8 +861,13 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
         const int arr = tid >> 7, ch = tid & 127;
         const ST* src = (const ST*)(arr ? a.mn : a.scale) + (bh * KD + ch) * a.lds + (a.t_off + tile_lo * 64) / G;
         const int nv = (tile_hi - tile_lo) * NG;
+        // (all NV loads in flight at once, from clamped addresses: `i < nv ? src[i] : 0` compiled to NV conditional loads with a
+        // full wait after each -- 16 serialized memory round trips at the head of every workgroup)
+        ST vals[NV];
 #pragma unroll
-        for (int i = 0; i < NV; i++) smz[(arr * KD + ch) * NV + i] = i < nv ? src[i] : (ST)0;
+        for (int i = 0; i < NV; i++) vals[i] = src[min(i, nv - 1)];
+#pragma unroll
+        for (int i = 0; i < NV; i++) smz[(arr * KD + ch) * NV + i] = i < nv ? vals[i] : (ST)0;
     }
     __syncthreads();
     const uint32_t* crow = a.code + (bh * KD + 2 * lane) * a.ldc;
