@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
 // grid (BH): G = sum of the slabs' partial Gram matrices, then the solve of lowrank_solve.h.
 // P_out head bh lives at (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * r elements.
 template <int RP>
-__global__ __launch_bounds__(256, 3) void k_solve_kernel(const float* __restrict__ gpart, int nslab, int loop,
+__global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict__ gpart, int nslab, int loop,
                                                          const float* __restrict__ P0, int r, float* __restrict__ Wout,
                                                          void* __restrict__ P_out, int out_f16, int64_t p_inner,
                                                          int64_t p_outer_stride) {
