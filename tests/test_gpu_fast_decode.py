@@ -120,6 +120,34 @@ def test_cache_attend_matches_reconstruction(attn_option, kernel, method, bits, 
         assert int(vcnt[:, :, :c.n_comp // 64].sum()) == B * c.n_comp * 2 * c.kv
 
 
+def test_cache_at_its_maximum_length(attn_option):
+    """GearKVCache at the longest context it takes (16384 tokens; the chunk kernel stops at 8192, the any-shape kernel takes over):
+    prompt of 16200 tokens, decoding across the last block boundaries up to the very last token, attention against the
+    reconstruction; a block past the capacity must be refused."""
+    from gear_amd.cache import GearKVCache
+    torch.manual_seed(73)
+    cc = dict(compress_method="gearslKIVI", group_size=64, residual=64, quantize_bit=2, rank=8, rankv=8, loop=3, left=0.02)
+    B, Hq, Hkv, D, T0 = 1, 2, 2, 128, 16200
+    c = GearKVCache(B, Hkv, 16384, cc, "cuda")
+    assert c.Tmax == 16384
+    c.prefill(torch.randn(B, Hkv, T0, D).half().cuda(), torch.randn(B, Hkv, T0, D).half().cuda())
+    worst = 0.0
+    for i in range(16384 - T0):
+        c.append(torch.randn(B, Hkv, 1, D).half().cuda(), torch.randn(B, Hkv, 1, D).half().cuda())
+        q = torch.randn(B, Hq, 1, D).half().cuda()
+        out = c.attend(q)
+        if i % 61 == 0 or c.seq_len == 16384:
+            K, V = _reconstruct_cache(c)
+            ref = _ref_attn(host(q), K, V, host(c.kwin[:, :, :c.n_win]), host(c.vwin[:, :, :c.n_win]), Hq // Hkv)
+            worst = max(worst, rel_fro(host(out).astype(np.float64), ref))
+        c.maybe_compress()
+    assert c.seq_len == 16384 and worst < 2e-3, worst
+    for _ in range(64):                                   # the fp16 window still takes a block's worth of tokens ...
+        c.append(torch.randn(B, Hkv, 1, D).half().cuda(), torch.randn(B, Hkv, 1, D).half().cuda())
+    with pytest.raises(AssertionError):                   # ... which can no longer be compressed into the full cache
+        c.maybe_compress()
+
+
 def _oracle_block(x, layout, k, g, bits):
     """Oracle (fp16-stepwise arithmetic, the fused path's mode) on one block: outlier selection on the block's rows, fill with the
     fp16-rounded row mean, group quantization.  x fp16 [B,H,T,128]; layout "k": rows = channels over T, "v": rows = tokens

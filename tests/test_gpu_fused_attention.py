@@ -84,7 +84,8 @@ def attn_kernel(request):
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,T,W,bits,mode,rank,k_out", CASES + [(1, 2, 1, 8320, 3, 2, "fp32", 8, 20),
-                                                                   (1, 8, 1, 8192, 5, 2, "fp32", 16, 20)])   # 70B-style GQA head, rank 16
+                                                                   (1, 8, 1, 8192, 5, 2, "fp32", 16, 20),   # 70B-style GQA head, rank 16
+                                                                   (1, 2, 2, 16384, 7, 2, "fp32", 8, 40)])  # the longest context the cache takes
 def test_fused_decode_attention(attn_kernel, B, Hq, Hkv, T, W, bits, mode, rank, k_out):
     from gear_amd import compress as C
     from gear_amd.attention import decode_attention

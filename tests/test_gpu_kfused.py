@@ -180,10 +180,11 @@ def test_fused_key_large_k_takes_slow_path(C):
         assert rel_fro(host(C.decompress(p)).astype(np.float32), orc.gears_channelQ(x.numpy(), 2, 64, 2 * k / 256 + 1e-9).astype(np.float32)) < 1e-6
 
 
-@pytest.mark.parametrize("T,H,k,r", [(8192, 1, 10, 16), (4096, 2, 25, 8), (4096, 1, 40, 8)])
+@pytest.mark.parametrize("T,H,k,r", [(8192, 1, 10, 16), (4096, 2, 25, 8), (4096, 1, 40, 8), (16384, 1, 40, 8), (64, 2, 1, 8)])
 def test_fused_key_c4_c5_shapes_vs_oracle(C, T, H, k, r):
     """BASELINE configs 4 / 5 at their per-GPU K geometry: 70B (T = 8192, k = 8*128*0.02/2 = 10 per channel row, rank 16),
-    13B (k = 40*128*0.01/2 = 25, rank 8) and 7B (k = 40) -- against the oracle, full context."""
+    13B (k = 40*128*0.01/2 = 25, rank 8) and 7B (k = 40) -- against the oracle, full context; plus the two ends of what the fused
+    path takes: T = 16384 (the longest row) and T = 64 (a single tile)."""
     x = randn_half(61, (1, H, T, 128))
     P0 = torch.rand(1, H, 128, r)
     p = C.compress_key_fused(x.cuda(), 2, 64, k_out=k, rank=r, loop=3, mode="fp32", P0=P0)
