@@ -147,8 +147,11 @@ def _block_sync_ws(lib, NB, H, dev):
 def block_kernel_status(dev="cuda") -> int:
     """OR of the status words of every block-compress hand-off buffer on `dev` (non-zero: a V tile gave up waiting)."""
     st = 0
-    for (d, _, _), ws in _BLOCK_WS.items():
-        if d == str(torch.device(dev)) or torch.device(d) == ws.device:
+    want = torch.device(dev)
+    if want.type == "cuda" and want.index is None:
+        want = torch.device("cuda", torch.cuda.current_device())
+    for ws in _BLOCK_WS.values():
+        if ws.device == want:
             off = (-ws.data_ptr()) % 256
             st |= int(ws[off:off + 4].view(torch.int32).item())
     return st

@@ -213,11 +213,17 @@ __device__ __forceinline__ void vrow_select(const BlkArgs& a, uint32_t* kw, int 
             }
         }
     }
-    if (lane == H) { chS = (uint32_t)kv; chL = (uint32_t)kv; }
-    if (a.vochunk && lane <= H) {
+    if (a.vochunk) {
         const int64_t id = ((int64_t)nb * a.tcap + a.t_off + t) * 2;
-        a.vochunk[id * (H + 1) + lane] = (uint8_t)chS;
-        a.vochunk[(id + 1) * (H + 1) + lane] = (uint8_t)chL;
+        if (lane < H) {
+            a.vochunk[id * (H + 1) + lane] = (uint8_t)chS;
+            a.vochunk[(id + 1) * (H + 1) + lane] = (uint8_t)chL;
+        }
+        // the terminal entry (end of the last head's range) from lane 0: with H == 64 there is no lane H
+        if (lane == 0) {
+            a.vochunk[id * (H + 1) + H] = (uint8_t)kv;
+            a.vochunk[(id + 1) * (H + 1) + H] = (uint8_t)kv;
+        }
     }
     // ---- hand-off to the V tiles: write-through (agent-scope) stores, drained, then the flag
     if (lane < H) {

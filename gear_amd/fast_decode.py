@@ -94,6 +94,28 @@ class FastGearDecoder:
             if self.gather is None:
                 self.gather = HeadGather(tp_world, batch, self.Hq * self.D, torch.float16, dev, tp_group)
 
+    def check_block_kernel(self):
+        """Raise if a V tile of gear_compress_block ever gave up waiting for its row duties (csrc/block_fused.hip: the poll is
+        bounded so that a shared / preempted GPU yields a status word instead of a hang; a tile that gave up has quantized with
+        stale masks).  One device word: called every 16th block boundary and at the end of generate()."""
+        from . import cache as gc
+        st = gc.block_kernel_status(self.dev)
+        if st:
+            raise RuntimeError(f"gear_compress_block: hand-off timed out (status {st}); the cache contents since the last "
+                               "check are not trustworthy -- set gear_amd.cache.USE_BLOCK_KERNEL = False to use the kernel chain")
+
+    def _after_boundary(self):
+        self._nbound = getattr(self, "_nbound", 0) + 1
+        self.check_exchange()
+        if self._nbound % 16 == 0:
+            self.check_block_kernel()
+
+    def check_exchange(self):
+        """Sharded decoder: raise if the peer exchange ever timed out (one device word; called at block boundaries, at the end
+        of generate() and by bench.py -- a latched timeout makes every later token silently wrong otherwise)."""
+        if self.gather is not None and hasattr(self.gather, "check"):
+            self.gather.check()
+
     def _attn_out(self, a):
         """[B, Hq_local, 1, D] of this rank -> [B, Hq_full * D] (all-gather over the head shards when sharded)."""
         a = a.view(a.shape[0], self.Hq * self.D)
@@ -199,6 +221,7 @@ class FastGearDecoder:
         self._state_dirty = True          # (the captured graph reads pos / slot / T / W from self.state)
         if self.layers[0]["cache"].n_win == self.layers[0]["cache"].R:
             self.pool.compress_all()
+            self._after_boundary()
         return self._norm_linear(res, self.w_head)
 
     # ------------------------------------------------------------------------------------------------ hipGraph decode
@@ -228,8 +251,9 @@ class FastGearDecoder:
         produced itself; returns the NEXT token [B,1] (the graph's own argmax).  Block compression (every `residual`
         tokens) runs eagerly between replays."""
         if self.gather is not None and not self.gather.capturable:
-            raise NotImplementedError("step_graph() with tp_world > 1 needs tp_exchange='peer': the collective exchange is not "
-                                      "captured (its one-GPU gloo staging path copies through the host) -- use step()")
+            raise NotImplementedError("step_graph() with tp_world > 1 needs a capturable exchange: tp_exchange='peer', or the "
+                                      "collective on the RCCL backend when its capture probe passed (the one-GPU gloo staging "
+                                      "path copies through the host) -- use step()")
         if token_ids is not None:
             self.tok.copy_(token_ids.view(self.batch, 1))
         if self.graph is None:
@@ -253,6 +277,7 @@ class FastGearDecoder:
         if full:
             self.pool.compress_all()
             self._sync_state()
+            self._after_boundary()
         return self.tok
 
     def close(self):
@@ -276,4 +301,6 @@ class FastGearDecoder:
             else:
                 nxt = self.step(nxt).argmax(-1, keepdim=True)
             out.append(nxt)
+        self.check_exchange()
+        self.check_block_kernel()
         return torch.cat(out, dim=1)

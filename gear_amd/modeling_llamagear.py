@@ -132,6 +132,11 @@ def matmul_withlrap(group_size, a, b, scale, mn, bits, pbase: list, qbase: list,
     L.require_gpu(a, b, scale, mn, p0, q0, p1, q1)
     if any(t is not None and t.dtype != torch.float16 for t in (a, p0, q0, p1, q1)):
         raise L.GearError("matmul_withlrap: activations and factors must be float16")
+    # the epilogue kernel's geometry (csrc/gemv.hip: blocks of 16 .. 64 tokens, rank <= 16, head_dim <= 256 / <= 128 columns);
+    # anything else -- e.g. residual = 128 blocks -- keeps the reference's shape: the HIP dequant GEMV + the factor terms as
+    # batched fp16 matmuls on the GPU (modeling_llamagear.py:71-108)
+    if not (16 <= blk <= 64 and r <= 16 and (K <= 256 if type == "key" else N <= 128)):
+        return _matmul_withlrap_general(group_size, a, b, scale, mn, bits, p0, q0, p1, q1, tp, nbuf, blk, type, Hq // Hkv)
     lib = L.load()
     BA = B * Hq
     wsb = lib.gear_gemv_outer_lrap_workspace(BA, K, N, bits)
@@ -141,6 +146,25 @@ def matmul_withlrap(group_size, a, b, scale, mn, bits, pbase: list, qbase: list,
                                   0 if scale.dtype == torch.float16 else 1, 0 if type == "key" else 1, L.ptr(p0), L.ptr(q0), tp,
                                   L.ptr(p1), L.ptr(q1), nbuf, blk, r, L.ptr(out), L.ptr(ws), wsb, L.stream_ptr(a))
     L.check(rc, "gear_gemv_outer_lrap")
+    return out
+
+
+def _matmul_withlrap_general(group_size, a, b, scale, mn, bits, p0, q0, p1, q1, tp, nbuf, blk, type, n_rep):
+    """matmul_withlrap for factor geometries outside the fused epilogue's limits: the dequant GEMV stays the HIP kernel, the
+    low-rank terms are the reference's own batched matmuls (modeling_llamagear.py:71-85 key, :87-108 value), GQA by repeating
+    the KV heads' factors."""
+    out = cuda_bmm_fA_qB_outer(group_size, a, b, scale, mn, bits)
+    if type == "key":
+        out[..., :tp] += (a @ _rep(q0, n_rep)) @ _rep(p0, n_rep).transpose(-1, -2)
+        if nbuf:
+            t = (a.unsqueeze(0) @ _rep(q1, n_rep)) @ _rep(p1, n_rep).transpose(-1, -2)       # [nbuf,B,Hq,1,blk]
+            out[..., tp:tp + nbuf * blk] += t.permute(1, 2, 3, 0, 4).reshape(*out.shape[:3], nbuf * blk)
+    else:
+        out += (a[..., :tp] @ _rep(q0, n_rep)) @ _rep(p0, n_rep).transpose(-1, -2)
+        if nbuf:
+            B, Hq = a.shape[:2]
+            ab = a[..., tp:tp + nbuf * blk].reshape(B, Hq, 1, nbuf, blk).permute(3, 0, 1, 2, 4)  # [nbuf,B,Hq,1,blk]
+            out += ((ab @ _rep(q1, n_rep)) @ _rep(p1, n_rep).transpose(-1, -2)).sum(0)
     return out
 
 

@@ -47,14 +47,46 @@ class HeadGather:
     and latency-bound: a single hop over xGMI on MI355X, where backend "nccl" is RCCL).
     x [B, H_local*D] on every rank -> [B, world*H_local*D] with rank r's heads at slot r."""
 
-    capturable = False      # (eager only: the staging path goes through the host, and nothing registers RCCL for a capture)
+    capturable = False      # (class default; an instance on the RCCL backend probes whether the collective can be captured)
 
-    def __init__(self, world: int, batch: int, width: int, dtype, device, group=None):
+    def __init__(self, world: int, batch: int, width: int, dtype, device, group=None, probe_capture: bool = True):
         import torch.distributed as dist
         self.world, self.B, self.width, self.group = world, batch, width, group
         self.buf = torch.empty((world * batch, width), dtype=dtype, device=device)       # ranks concatenated on dim 0
         # gloo cannot gather device tensors: the one-GPU debug mode of bench.py / the tests stage through the host
-        self.stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+        backend = dist.get_backend(group)
+        self.stage = backend == "gloo" and torch.device(device).type == "cuda"
+        self.capture_error = None
+        if backend == "nccl" and torch.device(device).type == "cuda" and probe_capture:
+            self.capturable = self._probe_capture(dtype, device)
+
+    def _probe_capture(self, dtype, device) -> bool:
+        """RCCL collectives can be recorded into a hipGraph; whether THIS build / communicator does it is found out once, on
+        every rank alike: capture two gathers, replay twice, compare with what the peers must have sent, agree across ranks.
+        Any exception or mismatch -> eager steps only (the state before round 4)."""
+        import torch.distributed as dist
+        fine = True
+        try:
+            rank = dist.get_rank(self.group)
+            src = torch.full((self.B, self.width), float(rank + 1), dtype=dtype, device=device)
+            self(src)                                            # warm-up: communicator set-up must not happen under capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self(src).clone()
+                out2 = self(src * 2).clone()
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize()
+            want = torch.arange(1, self.world + 1, dtype=dtype, device=device).view(1, self.world, 1)
+            fine = bool(torch.equal(out.view(self.B, self.world, self.width), want.expand(self.B, self.world, self.width)))
+            fine = fine and bool(torch.equal(out2.view(self.B, self.world, self.width), (2 * want).expand(self.B, self.world, self.width)))
+        except Exception as e:                                   # (capture refused: not an error of the exchange itself)
+            self.capture_error = e
+            fine = False
+        good = [None] * self.world
+        dist.all_gather_object(good, fine, group=self.group)
+        return all(good)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         import torch.distributed as dist
@@ -90,6 +122,7 @@ class PeerHeadGather:
         self.row_bytes = width * torch.empty((), dtype=dtype).element_size()
         self.lib = L.load()
         self.base, self.mapped, self.ok = None, [], False
+        self._closed = False
         err = None
         try:
             area = self.lib.gear_xchg_bytes(world, batch * self.row_bytes)
@@ -147,16 +180,22 @@ class PeerHeadGather:
         return self.out
 
     def check(self):
-        """Raise if an exchange ever gave up waiting for a peer (reads one word from the device: not for the token loop)."""
+        """Raise if an exchange ever gave up waiting for a peer (reads one word from the device: not for every token --
+        FastGearDecoder calls it at block boundaries and at the end of generate()).  The kernel latches the status: after a
+        timeout every later exchange copies out without waiting, so everything since the last clean check is suspect."""
         if int(self.status.item()):
-            raise RuntimeError("gear_xchg_allgather: a peer did not deliver its slice within the time limit")
+            raise RuntimeError("gear_xchg_allgather: a peer did not deliver its slice within the time limit; the tokens "
+                               "produced since the last check are not trustworthy")
 
     def close(self):
         """Unmap the peers' areas and free the own one.  Collective in spirit: call it on every rank once no exchange is in
         flight (the owner's free comes after a barrier so no peer still has stores under way)."""
         import torch.distributed as dist
-        if self.base is None and not self.mapped:
+        if self._closed:
             return
+        # (the barrier below is entered by EVERY rank that constructed the object, also one whose allocation failed and
+        # has nothing to free: an asymmetric early return would leave the healthy ranks waiting in it)
+        self._closed = True
         torch.cuda.synchronize()
         for p in self.mapped:
             self.lib.gear_xchg_close(p)

@@ -28,7 +28,6 @@ def cuda_bmm_fA_qB_outer(group_size: int, fA: torch.Tensor, qB: torch.Tensor, sc
         raise L.GearError(f"fA must be float16 (got {fA.dtype})")
     feat_per_int = 32 // bits
     N = qB.shape[-1] * feat_per_int
-    nkv = qB.shape[1] if qB.shape[0] == B else 1
     qB = qB.reshape(B, -1, K, qB.shape[-1])
     nkv = qB.shape[1]
     if mqa:

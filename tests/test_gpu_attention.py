@@ -305,6 +305,38 @@ def test_matmul_withlrap_gqa_matches_dense_reconstruction():
     assert rel_fro(host(got), host(ref)) < 3e-3
 
 
+def test_matmul_withlrap_blocks_of_128_tokens():
+    """Factor geometry outside the fused epilogue's limits (stacked blocks of 128 tokens: the hook with residual = 128, the
+    KIVI default): matmul_withlrap keeps the HIP GEMV and adds the factor terms as batched matmuls -- same result as the dense
+    reconstruction, GQA included."""
+    from gear_amd.modeling_llamagear import key_compression, matmul_withlrap, value_compression
+    from gear_amd.quant import new_pack
+    torch.manual_seed(10)
+    cc = dict(compress_method="gearlKIVI", group_size=64, residual=128, quantize_bit=2, rank=4, rankv=4, loop=3)
+    B, H, Hq, D = 1, 2, 4, 128
+    rp = lambda t: t.repeat_interleave(Hq // H, dim=1)
+    ks = [torch.randn(B, H, t, D).half().cuda() for t in (256, 128, 128)]
+    q = torch.randn(B, Hq, 1, D).half().cuda()
+    parts = [key_compression(k.transpose(2, 3).contiguous(), cc) for k in ks]
+    code, scale, mn = (torch.cat([p[i] for p in parts], 3) for i in range(3))
+    pbase = [parts[0][3], torch.stack([parts[1][3], parts[2][3]])]
+    qbase = [parts[0][4], torch.stack([parts[1][4], parts[2][4]])]
+    got = matmul_withlrap(64, q, code, scale, mn, 2, pbase, qbase, type="key").float()
+    deq = new_pack.unpack_and_dequant_vcache(code, scale.unsqueeze(-1), mn.unsqueeze(-1), 64, 2).float()
+    lr = torch.cat([(p[4].float() @ p[3].float().transpose(2, 3)) for p in parts], 3)
+    assert rel_fro(host(got), host(q.float() @ rp(deq + lr))) < 3e-3
+    vs = [torch.randn(B, H, t, D).half().cuda() for t in (256, 128, 128)]
+    a = torch.softmax(torch.randn(B, Hq, 1, 512).cuda(), -1).half()
+    vparts = [value_compression(v, cc) for v in vs]
+    vcode, vscale, vmn = (torch.cat([p[i] for p in vparts], 2) for i in range(3))
+    vp = [vparts[0][3], torch.stack([vparts[1][3], vparts[2][3]])]
+    vq = [vparts[0][4], torch.stack([vparts[1][4], vparts[2][4]])]
+    got = matmul_withlrap(64, a, vcode, vscale, vmn, 2, vp, vq, type="value").float()
+    vdeq = new_pack.unpack_and_dequant_vcache(vcode, vscale.unsqueeze(-1), vmn.unsqueeze(-1), 64, 2).float()
+    vlr = torch.cat([(p[4].float() @ p[3].float().transpose(2, 3)) for p in vparts], 2)
+    assert rel_fro(host(got), host(a.float() @ rp(vdeq + vlr))) < 3e-3
+
+
 def test_generate_runs_and_is_deterministic():
     """a14 counterpart: tiny random-weight model, prefill + greedy decode through the packed cache."""
     from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI

@@ -70,6 +70,7 @@ CASES = [
     (1, 2, 8, 4, 32, 2, 0.1, 64, 70),          # kk_blk = 3, rank below the register block
     (1, 1, 4, 2, 64, 8, 0.0, 128, 70),         # no outliers
     (1, 1, 4, 2, 64, 0, 0.02, 128, 70),        # no low-rank part (KIVI + outliers)
+    (1, 1, 64, 2, 64, 4, 0.01, 64, 70),        # 64 heads: the row-duty wave has no lane H for the terminal chunk-index entry
 ]
 
 
