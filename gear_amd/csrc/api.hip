@@ -33,6 +33,9 @@ GearOptions& gear_options() {
         v.kfused_generic = flag("GEAR_KFUSED_GENERIC");
         v.kselect_slow = flag("GEAR_KSELECT_SLOW");
         v.kfused_no_tr = flag("GEAR_KFUSED_NO_TR");
+        auto ival = [](const char* n) { const char* e = getenv(n); return (e && *e) ? atoi(e) : 0; };
+        v.gram_fused = ival("GEAR_GRAM_FUSED");
+        v.gram_nstg = ival("GEAR_GRAM_NSTG");
         return v;
     }();
     return o;
@@ -43,7 +46,7 @@ extern "C" int gear_set_option(const char* name, int value) {
     const struct { const char* n; int* p; } tab[] = {
         {"attn_generic", &o.attn_generic},     {"lowrank_generic", &o.lowrank_generic}, {"rows_hist_only", &o.rows_hist_only},
         {"rows_v1", &o.rows_v1}, {"rows_wg_only", &o.rows_wg_only},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
-        {"kfused_no_tr", &o.kfused_no_tr},
+        {"kfused_no_tr", &o.kfused_no_tr}, {"gram_fused", &o.gram_fused}, {"gram_nstg", &o.gram_nstg},
     };
     for (const auto& t : tab)
         if (name && !strcmp(name, t.n)) { *t.p = value; return 0; }

@@ -40,6 +40,9 @@ struct GearOptions {
     int kfused_generic;    // fused K path: the element-by-element tile body instead of the packed one
     int kselect_slow;      // fused K path: always the exact slow selection (no candidate lists)
     int kfused_no_tr;      // fused K path: 16-bit LDS reads for the MFMA operands instead of ds_read_b64_tr_b16
+    int gram_fused;        // low-rank step: 1 = Gram matrix and solve in ONE kernel per head (round 1-3); 2 = slab kernels with
+                           // workgroup barriers + solve; 0 = wave-private slab kernel + solve
+    int gram_nstg;         // wave-private Gram kernel: steps of loads in flight per wave (2, 3 = default, 4)
 };
 GearOptions& gear_options();
 
@@ -57,6 +60,14 @@ __device__ __forceinline__ float h2f_bits(uint16_t b) {
 __device__ __forceinline__ uint16_t f2h_bits(float f) {
     __half h = __float2half_rn(f);
     return __half_as_ushort(h);
+}
+
+// two floats -> packed fp16 pair (lo in bits 0..15), round to nearest even: ONE instruction on gfx950 (v_cvt_pk_f16_f32)
+// where two converts + a pack / SDWA write take two or three
+__device__ __forceinline__ uint32_t f2h2_bits(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 // IEEE-correct fp32 division (never the v_rcp approximation): torch semantics

@@ -841,10 +841,10 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     // ---------------- quantize: reciprocal multiply; a lane that sees a quotient within 1e-5 of a rounding tie (the only
     // place where t * (1/s) and t / s can round differently; 1e-3 for 8-bit codes) redoes its elements by division
     constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
-    float rq[16];
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float2v rq[8];                                       // codes as floats, (even, odd) element pairs: one register pair per word
     bool tie = false;
     const float one = 1.0f, negmn = -qmn;
-    typedef float float2v __attribute__((ext_vector_type(2)));
     float dmax = 0.0f;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
@@ -852,20 +852,23 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         const float2v c = t * inv;                       // v_pk_mul_f32
         float2v rr = {rintf(c.x), rintf(c.y)};
         const float2v d = c - rr;                        // v_pk_add_f32
-        rq[2 * w] = rr.x;
-        rq[2 * w + 1] = rr.y;
+        rq[w] = rr;
         asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
     }
     tie = dmax > TIE;
     if (tie) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float xv = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
-            rq[j] = (qscale != 0.0f) ? rintf(div_rn(xv - qmn, qscale)) : 0.0f;
+        for (int w = 0; w < 8; w++) {
+            const float xa = h2f_bits((uint16_t)(rw[w] & 0xFFFFu)), xb = h2f_bits((uint16_t)(rw[w] >> 16));
+            rq[w].x = (qscale != 0.0f) ? rintf(div_rn(xa - qmn, qscale)) : 0.0f;
+            rq[w].y = (qscale != 0.0f) ? rintf(div_rn(xb - qmn, qscale)) : 0.0f;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 16; j++) rq[j] = __builtin_amdgcn_fmed3f(rq[j], 0.0f, (float)LEVELS);
+    for (int w = 0; w < 8; w++) {
+        rq[w].x = __builtin_amdgcn_fmed3f(rq[w].x, 0.0f, (float)LEVELS);
+        rq[w].y = __builtin_amdgcn_fmed3f(rq[w].y, 0.0f, (float)LEVELS);
+    }
     // ---------------- pack: Horner chains in fp32 over the HC codes of each 16-bit half (exact: < 2^16)
     // (even, odd) element pairs ride one v_pk_fma_f32: A = sum 4^BITS^i code[2i], B = the same over the odd elements,
     // half word = A + 2^BITS B
@@ -875,14 +878,11 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
         uint32_t hw[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            const int e0 = w * CPW + hf * HC;
-            float2v ab = {rq[e0 + HC - 2], rq[e0 + HC - 1]};
+            const int p0 = (w * CPW + hf * HC) / 2;          // first element pair of the half word
+            float2v ab = rq[p0 + HC / 2 - 1];
             const float2v base2 = {(float)(1 << (2 * BITS)), (float)(1 << (2 * BITS))};
 #pragma unroll
-            for (int i = HC / 2 - 2; i >= 0; i--) {
-                const float2v dg = {rq[e0 + 2 * i], rq[e0 + 2 * i + 1]};
-                ab = __builtin_elementwise_fma(ab, base2, dg);
-            }
+            for (int i = HC / 2 - 2; i >= 0; i--) ab = __builtin_elementwise_fma(ab, base2, rq[p0 + i]);
             hw[hf] = (uint32_t)fmaf(ab.y, (float)(1 << BITS), ab.x);
         }
         words[w] = hw[0] | (hw[1] << 16);
@@ -906,10 +906,11 @@ __global__ void compress_rows_fp32_kernel(const uint16_t* __restrict__ x, RowGeo
     if (err) {
         // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
         uint32_t ew[8];
+        const float2v qs2 = {qscale, qscale}, mn2 = {qmn, qmn};
 #pragma unroll
         for (int w = 0; w < 8; w++) {
-            const float d0 = __fadd_rn(__fmul_rn(rq[2 * w], qscale), qmn), d1 = __fadd_rn(__fmul_rn(rq[2 * w + 1], qscale), qmn);
-            const uint32_t dw = (uint32_t)f2h_bits(d0) | ((uint32_t)f2h_bits(d1) << 16);
+            const float2v dq = rq[w] * qs2 + mn2;            // -ffp-contract=off: v_pk_mul_f32 then v_pk_add_f32 (two roundings)
+            const uint32_t dw = f2h2_bits(dq.x, dq.y);
             uint32_t e2;   // x - d in packed fp16 (the optimiser otherwise negates d in fp32 first), outlier halves cleared
             asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rw[w]), "v"(dw));
             ew[w] = vbfi(m[w], 0u, e2);
@@ -967,10 +968,10 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
     // ---------------- quantize: reciprocal multiply; a lane that sees a quotient within 1e-5 of a rounding tie (the only
     // place where t * (1/s) and t / s can round differently; 1e-3 for 8-bit codes) redoes its elements by division
     constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
-    float rq[16];
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float2v rq[8];                                       // codes as floats, (even, odd) element pairs: one register pair per word
     bool tie = false;
     const float one = 1.0f, negmn = -qmn;
-    typedef float float2v __attribute__((ext_vector_type(2)));
     float dmax = 0.0f;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
@@ -978,20 +979,23 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
         const float2v c = t * inv;                       // v_pk_mul_f32
         float2v rr = {rintf(c.x), rintf(c.y)};
         const float2v d = c - rr;                        // v_pk_add_f32
-        rq[2 * w] = rr.x;
-        rq[2 * w + 1] = rr.y;
+        rq[w] = rr;
         asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
     }
     tie = dmax > TIE;
     if (tie) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float xv = h2f_bits((uint16_t)((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
-            rq[j] = (qscale != 0.0f) ? rintf(div_rn(xv - qmn, qscale)) : 0.0f;
+        for (int w = 0; w < 8; w++) {
+            const float xa = h2f_bits((uint16_t)(rw[w] & 0xFFFFu)), xb = h2f_bits((uint16_t)(rw[w] >> 16));
+            rq[w].x = (qscale != 0.0f) ? rintf(div_rn(xa - qmn, qscale)) : 0.0f;
+            rq[w].y = (qscale != 0.0f) ? rintf(div_rn(xb - qmn, qscale)) : 0.0f;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 16; j++) rq[j] = __builtin_amdgcn_fmed3f(rq[j], 0.0f, (float)LEVELS);
+    for (int w = 0; w < 8; w++) {
+        rq[w].x = __builtin_amdgcn_fmed3f(rq[w].x, 0.0f, (float)LEVELS);
+        rq[w].y = __builtin_amdgcn_fmed3f(rq[w].y, 0.0f, (float)LEVELS);
+    }
     // ---------------- pack: Horner chains in fp32 over the HC codes of each 16-bit half (exact: < 2^16)
     // (even, odd) element pairs ride one v_pk_fma_f32: A = sum 4^BITS^i code[2i], B = the same over the odd elements,
     // half word = A + 2^BITS B
@@ -1001,14 +1005,11 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
         uint32_t hw[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            const int e0 = w * CPW + hf * HC;
-            float2v ab = {rq[e0 + HC - 2], rq[e0 + HC - 1]};
+            const int p0 = (w * CPW + hf * HC) / 2;          // first element pair of the half word
+            float2v ab = rq[p0 + HC / 2 - 1];
             const float2v base2 = {(float)(1 << (2 * BITS)), (float)(1 << (2 * BITS))};
 #pragma unroll
-            for (int i = HC / 2 - 2; i >= 0; i--) {
-                const float2v dg = {rq[e0 + 2 * i], rq[e0 + 2 * i + 1]};
-                ab = __builtin_elementwise_fma(ab, base2, dg);
-            }
+            for (int i = HC / 2 - 2; i >= 0; i--) ab = __builtin_elementwise_fma(ab, base2, rq[p0 + i]);
             hw[hf] = (uint32_t)fmaf(ab.y, (float)(1 << BITS), ab.x);
         }
         words[w] = hw[0] | (hw[1] << 16);
@@ -1032,10 +1033,11 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
     if (err_row) {
         // error = x - fp16(code * scale + mn) (mul then add, unfused, like the reference), 0 at the outlier positions
         uint32_t ew[8];
+        const float2v qs2 = {qscale, qscale}, mn2 = {qmn, qmn};
 #pragma unroll
         for (int w = 0; w < 8; w++) {
-            const float d0 = __fadd_rn(__fmul_rn(rq[2 * w], qscale), qmn), d1 = __fadd_rn(__fmul_rn(rq[2 * w + 1], qscale), qmn);
-            const uint32_t dw = (uint32_t)f2h_bits(d0) | ((uint32_t)f2h_bits(d1) << 16);
+            const float2v dq = rq[w] * qs2 + mn2;            // -ffp-contract=off: v_pk_mul_f32 then v_pk_add_f32 (two roundings)
+            const uint32_t dw = f2h2_bits(dq.x, dq.y);
             uint32_t e2;   // x - d in packed fp16 (the optimiser otherwise negates d in fp32 first), outlier halves cleared
             asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rw[w]), "v"(dw));
             ew[w] = vbfi(m[w], 0u, e2);

@@ -37,6 +37,7 @@
 int gear_lowrank_gram_ex(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
                          int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, int out_dtype,
                          void* workspace, hipStream_t st);
+size_t gear_lowrank_gram_workspace(int64_t bh, int S, int RP);
 int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride,
                             int nseg, int seglen, int64_t seg_stride, int64_t o_outer_stride, int64_t o_inner_stride,
                             int64_t o_seg_stride, int o_list_outer, int group, int bits, int mode, int k, void* code,
@@ -591,7 +592,7 @@ __device__ __forceinline__ void tile_fast(const uint32_t (&xr)[64], uint32_t mA0
 #pragma unroll
             for (int j = 0; j < HC; j++) {
                 const float2v dq = rq[j] * qs2 + mn2;        // -ffp-contract=off: v_pk_mul_f32, v_pk_add_f32
-                const uint32_t dw = (uint32_t)f2h_bits(dq.x) | ((uint32_t)f2h_bits(dq.y) << 16);
+                const uint32_t dw = f2h2_bits(dq.x, dq.y);
                 uint32_t e2;
                 asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tb + j]), "v"(dw));
                 ew[tb + j] = vbfi(mask_of(D[(tb + j) >> 4], (tb + j) & 15), 0u, e2);
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
                 const int gi = tk / G;
                 const int qa = (int)((cw[0][tk / CPW] >> (BITS * (tk % CPW))) & CMASK), qb = (int)((cw[1][tk / CPW] >> (BITS * (tk % CPW))) & CMASK);
                 const float da = dequant_one<MODE>(qa, sc[0][gi], zp[0][gi]), db = dequant_one<MODE>(qb, sc[1][gi], zp[1][gi]);
-                const uint32_t dw = (uint32_t)f2h_bits(da) | ((uint32_t)f2h_bits(db) << 16);
+                const uint32_t dw = f2h2_bits(da, db);
                 uint32_t e2;
                 asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tk]), "v"(dw));
                 ((uint32_t*)(etile + t2 * ET_PITCH))[lane] = vbfi(mask_of(D[tk >> 4], tk & 15), 0u, e2);
@@ -1045,6 +1046,24 @@ void launch_main(const MainArgs& a, int64_t BH, bool fast, bool lr, bool tr, hip
 
 }  // namespace
 
+// The per-head solve on partial Gram matrices, for callers outside this file (lowrank_gram.hip: the V-side / K^T Gram kernels
+// hand over [BH][nslab][128][128] complete (mirrored) matrices exactly as k_main_kernel does).
+int gear_ksolve_launch(const float* gpart, int nslab, int loop, const float* P0, int r, int64_t BH, float* Wout, void* P_out,
+                       int out_f16, int64_t p_inner, int64_t p_outer_stride, hipStream_t st) {
+    const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
+    const size_t shmem = gram_solve_lds_bytes(RP) - (size_t)GS_GD * GS_GP * 4;      // no G in LDS: it lives in registers
+#define KF_SOLVE(RPV)                                                                                                    \
+    do {                                                                                                                 \
+        auto kfn = k_solve_kernel<RPV>;                                                                                  \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);             \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)BH), dim3(256), shmem, st, gpart, nslab, loop, P0, r, Wout, P_out,        \
+                           out_f16, p_inner, p_outer_stride);                                                            \
+    } while (0)
+    if (RP == 4) KF_SOLVE(4); else if (RP == 8) KF_SOLVE(8); else KF_SOLVE(16);
+#undef KF_SOLVE
+    return 0;
+}
+
 extern "C" size_t gear_compress_key_fused_workspace(int64_t BH, int T, int k, int rank) {
     if (BH <= 0 || T <= 0 || T % 64) return 0;
     return kf_workspace(BH, T, k, rank).total;
@@ -1126,17 +1145,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     if (variant & 16) return 0;
     if (rank > 0) {
         const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
-        const int of16 = 1;
-        const size_t shmem = gram_solve_lds_bytes(RP) - (size_t)GS_GD * GS_GP * 4;      // no G in LDS: it lives in registers
-#define KF_SOLVE(RPV)                                                                                                    \
-        do {                                                                                                             \
-            auto kfn = k_solve_kernel<RPV>;                                                                              \
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
-            hipLaunchKernelGGL(kfn, dim3((unsigned)BH), dim3(256), shmem, st, gpart, ws.nslab, loop, (const float*)P0,   \
-                               rank, Wws, P_out, of16, p_inner, p_outer_stride);                                         \
-        } while (0)
-        if (RP == 4) KF_SOLVE(4); else if (RP == 8) KF_SOLVE(8); else KF_SOLVE(16);
-#undef KF_SOLVE
+        gear_ksolve_launch(gpart, ws.nslab, loop, (const float*)P0, rank, BH, Wws, P_out, 1, p_inner, p_outer_stride, st);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
         QpArgs qa;
         qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T;
@@ -1164,7 +1173,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
 extern "C" size_t gear_compress_value_fused_workspace(int64_t B, int H, int T, int rank) {
     if (B <= 0 || H <= 0 || T <= 0) return 0;
     const size_t RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
-    return (rank > 0 ? (size_t)B * H * T * KD * 2 + 256 + (size_t)B * H * KD * RP * 4 + 256 : 0) + 512;
+    return (rank > 0 ? (size_t)B * H * T * KD * 2 + 256 + gear_lowrank_gram_workspace(B * H, T, (int)RP) : 0) + 512;
 }
 
 extern "C" int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group, int bits, int mode, int k,

@@ -308,11 +308,16 @@ inline int pad_rank(int r) { return r <= 4 ? 4 : (r <= 8 ? 8 : 16); }
 
 int gear_lowrank_gram(const void* E, int transposed, int64_t bh, int S, int r, int loop, const void* P0, void* P_out,
                       void* Q_out, int out_dtype, void* workspace, hipStream_t st);
+size_t gear_lowrank_gram_workspace(int64_t bh, int S, int RP);
 
 extern "C" size_t gear_lowrank_workspace(int64_t bh, int S, int Dm, int r) {
     if (r < 1 || r > 16) return 0;
     size_t RP = (size_t)pad_rank(r);
     size_t n = (size_t)bh * ((size_t)S + (size_t)Dm) * RP * sizeof(float) + (size_t)bh * RP * RP * sizeof(double);
+    if (Dm == 128) {                   // the Gram formulation: W + the slabs' partial Gram matrices (lowrank_gram.hip)
+        const size_t g = gear_lowrank_gram_workspace(bh, S, (int)RP);
+        if (g > n) n = g;
+    }
     return n + 256;
 }
 

@@ -16,6 +16,10 @@
 
 #include "common.h"
 #include "lowrank_solve.h"
+#include "ktile.h"
+
+int gear_ksolve_launch(const float* gpart, int nslab, int loop, const float* P0, int r, int64_t BH, float* Wout, void* P_out,
+                       int out_f16, int64_t p_inner, int64_t p_outer_stride, hipStream_t st);
 
 namespace {
 
@@ -23,6 +27,14 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
 constexpr int GD = GS_GD;        // head_dim (the Gram trick is built for 128)
+
+// four 16-byte staging registers with compile-time selection (an array passed by reference into the staging lambdas ended up in
+// scratch memory: 144 bytes of private segment, every tile through scratch_store / scratch_load)
+struct Stg4 {
+    uint4 a, b, c, d;
+    __device__ __forceinline__ void set(int p, const uint4& v) { if (p == 0) a = v; else if (p == 1) b = v; else if (p == 2) c = v; else d = v; }
+    __device__ __forceinline__ uint4 get(int p) const { return p == 0 ? a : (p == 1 ? b : (p == 2 ? c : d)); }
+};
 constexpr int KT_PITCH = 72;     // halfs per LDS row of the K^T staging tile [128][64 (+8 pad)]
 constexpr int TM_PITCH = 136;    // halfs per LDS row of the token-major staging tile [64][128 (+8 pad)]
 constexpr int GP = GS_GP;        // float pitch of G in LDS: rows AND columns are bank-conflict-free
@@ -33,11 +45,17 @@ __host__ __device__ constexpr int blk_index(int I, int J) {  // upper-triangular
 
 // LDS layout (bytes): [0, 65536) G fp32 (its head doubles as the staging tile while the Gram matrix is
 // still in registers), then Pa, Pb fp32 [128][RP], then small fp64 scratch.
-template <int RP, bool TOKEN_MAJOR>
+// SPLIT = false: one workgroup per head, Gram matrix + solve (rounds 1-3; option gram_fused).
+// SPLIT = true (round 4): grid (nslab, heads) -- the workgroup streams ITS SLAB of the head's tokens, writes the complete (mirrored)
+// partial Gram matrix to gpart [head][slab][128][128] and is done; the solve is kfused.hip's k_solve_kernel (G in registers, 10 KB of
+// LDS: every head resident at once).  In the fused form the two workgroups of a CU start together and reach their solve phases
+// together: HBM idles for ~60 us per round of 512 heads, twice per 32-layer call; and a head shard's 128 heads fill half the chip.
+template <int RP, bool TOKEN_MAJOR, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* __restrict__ E, int S, int loop,
                                                                const float* __restrict__ P0, int r,
                                                                float* __restrict__ Wout, void* __restrict__ P_out,
-                                                               int out_f16, int64_t p_inner, int64_t p_outer_stride) {
+                                                               int out_f16, int64_t p_inner, int64_t p_outer_stride,
+                                                               float* __restrict__ gpart, int tok_per_slab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* G = (float*)smem;                                  // [128][GP]
     uint16_t* tile = (uint16_t*)smem;                         // staging (aliases G during phase 1)
@@ -46,10 +64,14 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
     double* Md = (double*)(Pb + GD * RP);                     // [RP][RP]
     double* Rinv = Md + RP * RP;                              // [RP][RP]
 
-    const int64_t bh = blockIdx.x;
+    const int64_t bh = SPLIT ? blockIdx.y : blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 31, kg = lane >> 5;
     const uint16_t* Eb = E + bh * (int64_t)S * GD;
+    // the slab's token range [s_lo, s_hi) (the whole head when fused)
+    const int s_lo = SPLIT ? (int)blockIdx.x * tok_per_slab : 0;
+    const int S_full = S;
+    if (SPLIT) S = min(S_full, s_lo + tok_per_slab);
 
     float16_t acc[10];
 #pragma unroll
@@ -59,35 +81,50 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
 
     // ------------------------------------------------------------------ phase 1: G = E^T E on the matrix cores
     // staging: global -> registers (issued one tile ahead) -> LDS; the loads of tile t+1 fly during the MFMAs of tile t
-    uint4 stgA[4], stgB[4];
-    auto stage_load = [&](int t0, uint4 (&stg)[4]) {
-        if (TOKEN_MAJOR) {   // tile [64 tokens][128 channels]: 16 lanes per token row, 16 rows per pass
+    // Every load of the main loop is UNCONDITIONAL: a load under a per-lane condition makes the compiler lose count of what is
+    // outstanding, and its s_waitcnt in front of the first LDS store of a trip became vmcnt(0) -- the pipeline of "three tiles in
+    // flight" drained once per trip (measured in round 4 with the solve split off: 314 us for the 1 GiB tensor = 3.4 TB/s).
+    // Token-major: thread (l16, rr) loads the four consecutive token rows 4 rr .. 4 rr + 3 of the tile from clamped (always
+    // valid) 32-bit offsets; what lies beyond the slab / the sequence is zeroed in LDS after the store.
+    const char* Ebc = (const char*)Eb;
+    auto stage_load = [&](int t0, Stg4& stg) {
+        if (TOKEN_MAJOR) {
             const int l16 = tid & 15, rr = tid >> 4;
+            // (ONE code path: a fast / clamped pair of branches made the compiler split the 16-byte loads into dwords)
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                int t = t0 + rr + 16 * p;
-                stg[p] = make_uint4(0, 0, 0, 0);
-                if (t < S) stg[p] = *(const uint4*)(Eb + (int64_t)t * GD + l16 * 8);
+                const uint32_t t = (uint32_t)min(t0 + 4 * rr + p, S_full - 1);
+                stg.set(p, *(const uint4*)(Ebc + (size_t)((t * GD + (uint32_t)l16 * 8) * 2u)));
             }
         } else {             // K^T: E^T [128 channels][S tokens]; tile [128][64]: 8 lanes per channel row, 32 rows per pass
             const int l8 = tid & 7, rr = tid >> 3;
+            const int t = min(t0 + l8 * 8, S_full - 8);                             // (S % 8 == 0: checked by the host)
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                int d = rr + 32 * p, t = t0 + l8 * 8;
-                stg[p] = make_uint4(0, 0, 0, 0);
-                if (t < S) stg[p] = *(const uint4*)(Eb + (int64_t)d * S + t);
-            }
+            for (int p = 0; p < 4; p++) stg.set(p, *(const uint4*)(Eb + (int64_t)(rr + 32 * p) * S_full + t));
         }
     };
-    auto stage_store = [&](const uint4 (&stg)[4]) {
+    auto stage_store = [&](int t0, const Stg4& stg) {
+        // (no select on the loaded registers: `cond ? stg : 0` is scheduled right behind the load and waits for it there)
         if (TOKEN_MAJOR) {
             const int l16 = tid & 15, rr = tid >> 4;
 #pragma unroll
-            for (int p = 0; p < 4; p++) *(uint4*)(tile + (rr + 16 * p) * TM_PITCH + l16 * 8) = stg[p];
+            for (int p = 0; p < 4; p++) *(uint4*)(tile + (4 * rr + p) * TM_PITCH + l16 * 8) = stg.get(p);
         } else {
             const int l8 = tid & 7, rr = tid >> 3;
 #pragma unroll
-            for (int p = 0; p < 4; p++) *(uint4*)(tile + (rr + 32 * p) * KT_PITCH + l8 * 8) = stg[p];
+            for (int p = 0; p < 4; p++) *(uint4*)(tile + (rr + 32 * p) * KT_PITCH + l8 * 8) = stg.get(p);
+        }
+        if (t0 + 64 > S) {   // block-uniform, last tile of a ragged slab (or a tile beyond it) only: its tail is zeroed in LDS
+            const uint4 zero = make_uint4(0, 0, 0, 0);
+            if (TOKEN_MAJOR) {
+                const int l16 = tid & 15, rr = tid >> 4;
+                for (int p = 0; p < 4; p++)
+                    if (t0 + 4 * rr + p >= S) *(uint4*)(tile + (4 * rr + p) * TM_PITCH + l16 * 8) = zero;
+            } else {
+                const int l8 = tid & 7, rr = tid >> 3;
+                for (int p = 0; p < 4; p++)
+                    if (t0 + l8 * 8 >= S) *(uint4*)(tile + (rr + 32 * p) * KT_PITCH + l8 * 8) = zero;
+            }
         }
     };
     auto tile_mfma = [&]() {
@@ -112,30 +149,24 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
             for (int J = I; J < 4; J++)
                 acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
     };
-    uint4 stgC[4];
-    stage_load(0, stgA);
-    if (64 < S) stage_load(64, stgB);
-    if (128 < S) stage_load(128, stgC);
-    for (int t0 = 0; t0 < S; t0 += 192) {       // three tiles per trip, three tiles (48 KB per workgroup) of loads in flight
+    // two staging sets, two tiles (32 KB per workgroup, 64 KB per CU) of loads in flight, no branch around a load inside a trip (a
+    // tile beyond the slab is loaded from a clamped, valid position and zeroed in LDS: at most one per slab), so the waits in
+    // front of the LDS stores are exact counts.  (Three sets spilled: the accumulators alone are 160 of the 256 registers.)
+    Stg4 stgA, stgB;
+    const int t_last = max(s_lo, ((S_full >> 6) << 6) - 64);          // a tile start that is valid to load from
+    stage_load(s_lo, stgA);
+    stage_load(s_lo + 64 < S_full ? s_lo + 64 : t_last, stgB);
+    for (int t0 = s_lo; t0 < S; t0 += 128) {
         __syncthreads();
-        stage_store(stgA);
+        stage_store(t0, stgA);
         __syncthreads();
-        if (t0 + 192 < S) stage_load(t0 + 192, stgA);
+        stage_load(t0 + 128 < S_full ? t0 + 128 : t_last, stgA);
         tile_mfma();
-        if (t0 + 64 < S) {
-            __syncthreads();
-            stage_store(stgB);
-            __syncthreads();
-            if (t0 + 256 < S) stage_load(t0 + 256, stgB);
-            tile_mfma();
-        }
-        if (t0 + 128 < S) {
-            __syncthreads();
-            stage_store(stgC);
-            __syncthreads();
-            if (t0 + 320 < S) stage_load(t0 + 320, stgC);
-            tile_mfma();
-        }
+        __syncthreads();
+        stage_store(t0 + 64, stgB);
+        __syncthreads();
+        stage_load(t0 + 192 < S_full ? t0 + 192 : t_last, stgB);
+        tile_mfma();
     }
     // the four waves hold partial Gram matrices over disjoint token subsets: add them into LDS one wave at a time
     // (deterministic, no fp32 LDS atomics); the mirrored lower blocks are written too -- with pitch 129 neither the
@@ -158,13 +189,146 @@ __global__ __launch_bounds__(256, 2) void lr_gram_solve_kernel(const uint16_t* _
                 }
         }
     }
-    // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS (lowrank_solve.h)
     __syncthreads();
+    if (SPLIT) {
+        // the slab's partial Gram matrix, complete (the solve reads whole rows): 32 lanes cover one 512-byte row
+        float* gp = gpart + (bh * gridDim.x + blockIdx.x) * (int64_t)(GD * GD);
+        for (int idx = tid; idx < GD * 32; idx += 256) {
+            const int d = idx >> 5, e0 = (idx & 31) * 4, dlow = d & ~31;      // columns below the diagonal block: mirrored
+            float4 v;
+            if (e0 < dlow) v = make_float4(G[e0 * GP + d], G[(e0 + 1) * GP + d], G[(e0 + 2) * GP + d], G[(e0 + 3) * GP + d]);
+            else v = make_float4(G[d * GP + e0], G[d * GP + e0 + 1], G[d * GP + e0 + 2], G[d * GP + e0 + 3]);
+            *(float4*)&gp[d * GD + e0] = v;
+        }
+        return;
+    }
+    // ------------------------------------------------------------------ phase 2: the solve, entirely in LDS (lowrank_solve.h)
     // head bh of P_out lives at (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * r (a per-segment factor tensor of a cache)
     const int64_t po = (bh / p_inner) * p_outer_stride + (bh % p_inner) * (int64_t)(GD * r);
     gram_solve_phase2<RP>(G, Pa, Pb, Md, Rinv, P0 + bh * GD * r, r, loop, Wout + bh * GD * RP,
                           out_f16 ? (void*)((uint16_t*)P_out + po) : (void*)((float*)P_out + po), out_f16);
 }
+
+// ---------------------------------------------------------------------------------------------- Gram matrix, wave-private streaming
+// Token-major E, round 4.  grid (nslab, heads).  The 16-token steps of the slab are dealt out to the four waves round-robin and a
+// wave does everything for ITS steps alone: four 16-byte loads per lane (16 token rows = 4 KB, contiguous in memory) -> its own
+// 16-row LDS tile -> the transposing LDS read (ds_read_b64_tr_b16, ktile.h) -> the ten 32x32x16 matrix-core products.  No
+// workgroup barrier inside the stream (the version above has two per 64-token tile, and every wave waits for the slowest load of
+// the workgroup), NSTG steps of loads in flight per wave, every load unconditional from a clamped address.  The waves' partial
+// sums meet in LDS at the end, the complete (mirrored) matrix goes to gpart [head][slab][128][128] for k_solve_kernel.
+template <int NSTG, bool ROTATE, int VAR = 0>
+__global__ __launch_bounds__(256, 2) void lr_gram_wave_kernel(const uint16_t* __restrict__ E, int S_full, float* __restrict__ gpart,
+                                                              int tok_per_slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t bh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t* tile = (uint16_t*)smem + wave * 16 * ET_PITCH;  // this wave's [16 tokens][ET_PITCH]
+    const int x = lane & 31, kg = lane >> 5;
+    const char* Ebc = (const char*)(E + bh * (int64_t)S_full * GD);
+    const int s_lo = (int)blockIdx.x * tok_per_slab, S = min(S_full, s_lo + tok_per_slab);
+    const int nstep = (S - s_lo + 15) >> 4;                   // 16-token steps of the slab; wave w takes steps w, w + 4, ...
+    const int r4 = lane >> 4, l16 = lane & 15;                // load p of a step: token row 4 p + r4, bytes 16 l16 .. + 15
+
+    float16_t acc[10];
+#pragma unroll
+    for (int b = 0; b < 10; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
+
+    // Workgroups of different heads start at DIFFERENT places of their slab (G is a sum: any order): the heads lie 2^k bytes apart,
+    // and workgroups marching in lockstep through the same offsets of such regions keep hitting the same few HBM channels
+    // (tools/ubench/store_pattern.hip measured it for stores; here: 295 us -> see DESIGN section 6).  Logical step j -> physical
+    // step: 64-token groups rotated by a per-head amount.
+    const int ngrp = (nstep + 3) >> 2;
+    const int rotg = ROTATE ? (int)((((uint32_t)bh * 2654435761u) >> 12) % (uint32_t)ngrp) : 0;
+    auto phys = [&](int j) {
+        int g = (j >> 2) + rotg;
+        if (g >= ngrp) g -= ngrp;
+        return 4 * g + (j & 3);
+    };
+    Stg4 stg[NSTG];
+    auto issue = [&](int j, Stg4& st) {                       // (a step beyond the slab re-reads a valid row: never consumed)
+        const int step = j < 4 * ngrp ? phys(j) : 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t t = (uint32_t)min(s_lo + 16 * step + 4 * p + r4, S_full - 1);
+            st.set(p, *(const uint4*)(Ebc + (size_t)((t * GD + (uint32_t)l16 * 8) * 2u)));
+        }
+    };
+    auto consume = [&](int j, const Stg4& st) {
+        const int t0 = s_lo + 16 * phys(j);
+        if (VAR == 2) {                                       // (elimination build: loads only)
+#pragma unroll
+            for (int p = 0; p < 4; p++) { const uint4 v = st.get(p); acc[0][p] += __builtin_bit_cast(float, v.x ^ v.y ^ v.z ^ v.w); }
+            return;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) *(uint4*)(tile + (4 * p + r4) * ET_PITCH + l16 * 8) = st.get(p);
+        if (t0 + 16 > S) {                                    // wave-uniform: the ragged last step only
+            for (int p = 0; p < 4; p++)
+                if (t0 + 4 * p + r4 >= S) *(uint4*)(tile + (4 * p + r4) * ET_PITCH + l16 * 8) = make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        half8_t f[4];
+#pragma unroll
+        for (int I = 0; I < 4; I++) f[I] = load_operand<true>(tile, 0, I, lane);
+        if (VAR == 1) {                                       // (elimination build: no matrix-core work)
+#pragma unroll
+            for (int I = 0; I < 4; I++) acc[I][0] += (float)f[I][0];
+            return;
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I++)
+#pragma unroll
+            for (int J = I; J < 4; J++)
+                acc[blk_index(I, J)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[I], f[J], acc[blk_index(I, J)], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();                      // (the tile is read before the next step overwrites it)
+    };
+#pragma unroll
+    for (int i = 0; i < NSTG; i++) issue(wave + 4 * i, stg[i]);
+    // the ring is walked with compile-time slots: NSTG steps per trip
+    for (int st0 = wave; st0 < 4 * ngrp; st0 += 4 * NSTG) {
+#pragma unroll
+        for (int i = 0; i < NSTG; i++) {
+            const int j = st0 + 4 * i;
+            if (j < 4 * ngrp && phys(j) < nstep) consume(j, stg[i]);     // wave-uniform
+            issue(j + 4 * NSTG, stg[i]);
+        }
+    }
+    if (VAR == 3) return;                                     // (elimination build: no cross-wave sum, no output)
+    // ---- the four waves' partial Gram matrices meet in LDS BLOCK BY BLOCK, all waves working at once (the first version added
+    // whole matrices one wave at a time: four serialized turns of 160 LDS read-modify-writes, ~35 us per workgroup during which its
+    // share of HBM idled -- 75 us of a 295 us kernel): every wave drops its 32 x 32 partial of block (I, J) into its own
+    // [32][33] buffer, after a barrier thread (r, c) adds the four and writes element (r, c) of the block and, for an
+    // off-diagonal block, element (r, c) of the mirrored block (read transposed from the same buffers) -- both stores are rows.
+    __syncthreads();                                          // every wave is done with its tile: the buffers alias them
+    float* buf = (float*)smem;                                // [4 waves][32][33]
+    float* gp = gpart + (bh * gridDim.x + blockIdx.x) * (int64_t)(GD * GD);
+#pragma unroll
+    for (int I = 0; I < 4; I++)
+#pragma unroll
+        for (int J = I; J < 4; J++) {
+            const int b = blk_index(I, J);
+#pragma unroll
+            for (int q = 0; q < 16; q++) buf[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg) * 33 + x] = acc[b][q];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = tid + 256 * i, r = e >> 5, c = e & 31;
+                const float v = (buf[r * 33 + c] + buf[(32 + r) * 33 + c]) + (buf[(64 + r) * 33 + c] + buf[(96 + r) * 33 + c]);
+                gp[(32 * I + r) * GD + 32 * J + c] = v;
+                if (I != J) {
+                    const float w = (buf[c * 33 + r] + buf[(32 + c) * 33 + r]) + (buf[(64 + c) * 33 + r] + buf[(96 + c) * 33 + r]);
+                    gp[(32 * J + r) * GD + 32 * I + c] = w;
+                }
+            }
+            __syncthreads();
+        }
+}
+
 
 template <int N>
 __device__ __forceinline__ void store_halfs(uint16_t* p, const float* f) {  // N in {4, 8, 16}, p aligned to 2N bytes
@@ -326,30 +490,68 @@ __global__ __launch_bounds__(256) void lr_qpass_tm_mfma_kernel(const uint16_t* _
     }
 }
 
+// slabs per head of the split Gram kernel: enough workgroups for the chip (two per CU) when a call has few heads (head shards),
+// at least four 64-token tiles per slab; one slab when the heads alone fill it
+inline int gram_nslab(int64_t bh, int S) {
+    int n = 1;
+    while (n < 8 && bh * n < 512 && S / (2 * n) >= 256) n *= 2;
+    return n;
+}
+
 template <int RP>
 int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int loop, const float* P0, void* P_out,
              void* Q_out, int out_dtype, float* Wws, hipStream_t st, int64_t p_inner, int64_t p_outer_stride, int q_tcap,
              int q_toff) {
     const int of16 = out_dtype == GEAR_DTYPE_F16;
     size_t shmem = (size_t)GD * GP * 4 + 2 * (size_t)GD * RP * 4 + 3 * (size_t)RP * RP * 8 + 16;
+    const bool split = gear_options().gram_fused != 1;   // 1: fused kernel (rounds 1-3); 2: split, barrier kernel
+    const int nslab = gram_nslab(bh, S), tps = ((S + 63) / 64 + nslab - 1) / nslab * 64;
+    float* gpart = (float*)((char*)Wws + (((size_t)bh * GD * RP * 4 + 255) & ~(size_t)255));
+#define GRAM_GO(TM)                                                                                                      \
+    do {                                                                                                                 \
+        if (split && TM && gear_options().gram_fused != 2) {                                                             \
+            const int nstg = gear_options().gram_nstg;                                                                   \
+            auto kfn = nstg == 2 ? lr_gram_wave_kernel<2, true> : (nstg == 4 ? lr_gram_wave_kernel<4, true>                \
+                       : (nstg == 5 ? lr_gram_wave_kernel<3, false> : (nstg == 6 ? lr_gram_wave_kernel<3, true, 1>          \
+                       : (nstg == 7 ? lr_gram_wave_kernel<3, true, 2> : (nstg == 8 ? lr_gram_wave_kernel<3, true, 3>      \
+                       : lr_gram_wave_kernel<3, true>)))));                                                               \
+            const size_t wsh = (size_t)4 * 16 * ET_PITCH * 2 > (size_t)4 * 32 * 33 * 4 ? (size_t)4 * 16 * ET_PITCH * 2 : (size_t)4 * 32 * 33 * 4; \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsh);           \
+            hipLaunchKernelGGL(kfn, dim3((unsigned)nslab, (unsigned)bh), dim3(256), wsh, st, E, S, gpart, tps);          \
+            gear_ksolve_launch(gpart, nslab, loop, P0, r, bh, Wws, P_out, of16, p_inner, p_outer_stride, st);            \
+        } else if (split) {                                                                                              \
+            auto kfn = lr_gram_solve_kernel<RP, TM, true>;                                                               \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
+            hipLaunchKernelGGL(kfn, dim3((unsigned)nslab, (unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws,   \
+                               P_out, of16, p_inner, p_outer_stride, gpart, tps);                                        \
+            gear_ksolve_launch(gpart, nslab, loop, P0, r, bh, Wws, P_out, of16, p_inner, p_outer_stride, st);            \
+        } else {                                                                                                         \
+            auto kfn = lr_gram_solve_kernel<RP, TM, false>;                                                              \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
+            hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16,       \
+                               p_inner, p_outer_stride, (float*)nullptr, 0);                                             \
+        }                                                                                                                \
+    } while (0)
     if (transposed) {
-        auto kfn = lr_gram_solve_kernel<RP, false>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16, p_inner, p_outer_stride);
+        GRAM_GO(false);
         hipLaunchKernelGGL((lr_qpass_kt_kernel<RP>), dim3((S + 2047) / 2048, (unsigned)bh), dim3(256), 0, st, E, Wws, S, r,
                            Q_out, of16);
     } else {
-        auto kfn = lr_gram_solve_kernel<RP, true>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)bh), dim3(256), shmem, st, E, S, loop, P0, r, Wws, P_out, of16, p_inner, p_outer_stride);
+        GRAM_GO(true);
         hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<RP>), dim3((S + 511) / 512, (unsigned)bh), dim3(256), 0, st, E, Wws, S,
                                r, Q_out, of16, q_tcap, q_toff);
     }
+#undef GRAM_GO
     GEAR_CHECK_LAUNCH("gear_lowrank(gram)");
     return 0;
 }
 
 }  // namespace
+
+// workspace of the Gram path: W [bh][128][RP] floats, then the slabs' partial Gram matrices [bh][nslab][128][128]
+size_t gear_lowrank_gram_workspace(int64_t bh, int S, int RP) {
+    return (((size_t)bh * GD * RP * 4 + 255) & ~(size_t)255) + (size_t)bh * gram_nslab(bh, S) * GD * GD * 4 + 512;
+}
 
 // Called by gear_lowrank() when the fast path applies: fp16 error, Dm == 128, S % 8 == 0 (K^T layout).  The _ex form writes
 // P at a per-head offset and Q at a row offset of a larger tensor (token-major E only): the streaming cache's layouts.
