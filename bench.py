@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the full-model decode tokens/s leg")
     ap.add_argument("--decode-tokens", type=int, default=64)
+    ap.add_argument("--exchange", default="both", choices=("peer", "collective", "both"),
+                    help="world > 1, decode leg: the head-shard exchange -- 'peer' = stores into hipIpc-mapped peer memory "
+                         "(gear_xchg_allgather), 'collective' = all_gather_into_tensor (RCCL), 'both' = one decode leg each")
     return ap.parse_args()
 
 
@@ -219,7 +222,7 @@ def attn_decode_by_batch(cfg, dev):
     return out
 
 
-def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
+def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64, exchange="both"):
     """a14 counterpart (cuda_supported_gear/test.py:95-102): random-weight model of the named shapes through the GEAR cache
     (packed cache with per-block low-rank factors and sparse outliers, fused decode attention, block compression every 64
     tokens), greedy decode, one synchronize before the clock stops.  Prefill = context - new_tokens so that decoding happens
@@ -248,47 +251,67 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64):
                      "count, K 64-token blocks: nominal count), residual 64" % (bits, rnk, s * 100, " / world per shard" if world > 1 else ""),
            "parallelism": f"head-shard x{world}"}
     from gear_amd.fast_decode import FastGearDecoder
-    fast = FastGearDecoder(model, T + 2 * new_tokens + 8, tp_rank=rank, tp_world=world)
-    capturable = fast.gather is None or fast.gather.capturable
-    if world > 1:
-        res["exchange"] = ("gear_xchg_allgather: stores into the peers' hipIpc-mapped memory, one launch per layer inside the "
-                           "token-step graph" if capturable else
-                           "all_gather_into_tensor of the attention output per layer, eager (peer mapping failed: %s)"
-                           % (fast.exchange_error,))
-    nxt = fast.prefill(ids).argmax(-1, keepdim=True)
-    for _ in range(2):
-        nxt = fast.step(nxt).argmax(-1, keepdim=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(new_tokens - 2):
-        nxt = fast.step(nxt).argmax(-1, keepdim=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    c0 = fast.layers[0]["cache"]
-    res.update({"eager_tokens_per_s": (new_tokens - 2) / dt, "outliers_per_side": {"v_row": c0.kv, "k_prompt_row": c0.kk0,
-                                                                                 "k_block_row": c0.kk_blk}})
-    best = res["eager_tokens_per_s"]
-    if capturable:
-        # the same token step captured once as a HIP graph (device-side pos / slot / T / W) and replayed
-        n_graph = new_tokens - 2
-        fast.tok.copy_(nxt)
-        fast.step_graph()                                    # capture + first replay
+
+    def leg(mode):
+        """One decode leg: eager token steps, then (when the exchange can be captured) the same step replayed as a hipGraph."""
+        out = {}
+        fast = FastGearDecoder(model, T + 2 * new_tokens + 8, tp_rank=rank, tp_world=world, tp_exchange=mode)
+        capturable = fast.gather is None or fast.gather.capturable
+        if world > 1:
+            kind = type(fast.gather).__name__
+            out["exchange"] = ("gear_xchg_allgather: stores into the peers' hipIpc-mapped memory, one launch per layer inside the "
+                               "token-step graph" if kind == "PeerHeadGather" else
+                               "all_gather_into_tensor of the attention output per layer (%s)%s"
+                               % ("captured in the token-step graph" if capturable else "eager steps",
+                                  "" if mode == "collective" else "; peer mapping failed: %s" % (fast.exchange_error,)))
+            out["exchange_class"] = kind
+        nxt = fast.prefill(ids).argmax(-1, keepdim=True)
+        for _ in range(2):
+            nxt = fast.step(nxt).argmax(-1, keepdim=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n_graph):
-            fast.step_graph()
+        for _ in range(new_tokens - 2):
+            nxt = fast.step(nxt).argmax(-1, keepdim=True)
         torch.cuda.synchronize()
-        res["graph_replay_tokens_per_s"] = n_graph / (time.perf_counter() - t0)
-        best = max(best, res["graph_replay_tokens_per_s"])
-        if world > 1:
-            fast.gather.check()
+        dt = time.perf_counter() - t0
+        c0 = fast.layers[0]["cache"]
+        out.update({"eager_tokens_per_s": (new_tokens - 2) / dt,
+                    "outliers_per_side": {"v_row": c0.kv, "k_prompt_row": c0.kk0, "k_block_row": c0.kk_blk}})
+        best = out["eager_tokens_per_s"]
+        if capturable:
+            # the same token step captured once as a HIP graph (device-side pos / slot / T / W) and replayed
+            n_graph = new_tokens - 2
+            fast.tok.copy_(nxt)
+            fast.step_graph()                                    # capture + first replay
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_graph):
+                fast.step_graph()
+            torch.cuda.synchronize()
+            out["graph_replay_tokens_per_s"] = n_graph / (time.perf_counter() - t0)
+            best = max(best, out["graph_replay_tokens_per_s"])
+        fast.check_exchange()
+        fast.check_block_kernel()
+        out["tokens_per_s"] = best
+        fast.close()
+        del fast
+        torch.cuda.empty_cache()
+        return out
+
+    modes = ["peer"] if world == 1 else (["peer", "collective"] if exchange == "both" else [exchange])
+    legs = {m: leg(m) for m in modes}
+    head = legs[modes[0]]
+    res.update({k: v for k, v in head.items() if k != "exchange_class"})
+    if world > 1:
+        # both exchanges of the head-sharded token step, each measured: north_star names the RCCL all-gather, the peer-store
+        # kernel is the build's default
+        res["exchange_modes"] = {m: {k: v for k, v in l.items() if k != "outliers_per_side"} for m, l in legs.items()}
+        res["exchange_default"] = modes[0]
+    best = head["tokens_per_s"]
     # headline = the faster launch mode of the same token step (both reported)
     res.update({"tokens_per_s": best, "ms_per_token": 1e3 / best,
                 "path": "FastGearDecoder (GearKVCache with in-place block compress + fused GEMVs + gear_attn_decode_cache)",
                 "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20})
-    fast.close()
-    del fast
-    torch.cuda.empty_cache()
     if world == 1 and cfg["layers"] * cfg["hidden"] <= 32 * 4096:
         # the reference-shaped attention hook (17-slot tuple cache, torch.cat appends, ~60 eager ops per layer): what a
         # reference user gets from the documented import swap alone (no outliers: the reference's fused path stores none)
@@ -626,7 +649,7 @@ def main():
         res["attn_decode"]["one_layer_streaming_cache_by_batch"] = attn_decode_by_batch(cfg, dev)
     if not args.no_decode and not args.layers and not args.emulate_world:
         try:
-            dec = decode_tokens_per_s(cfg, dev, world, rank, args.decode_tokens)     # (every rank takes part when sharded)
+            dec = decode_tokens_per_s(cfg, dev, world, rank, args.decode_tokens, args.exchange)     # (every rank takes part when sharded)
         except Exception as e:           # the decode leg is a secondary figure: the line with `value` must still come out
             if world == 1:
                 raise

@@ -43,7 +43,7 @@ def _sparsity(cc) -> float:
     return float(cc.get("left", cc.get("sparsity", 0.0)) or 0.0)
 
 
-def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=None):
+def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=None, v_exact=False):
     bits, group, R = cc["quantize_bit"], cc["group_size"], cc["residual"]
     m = cc["compress_method"]
     lowrank = ("gearl" in m) or ("gearsl" in m)
@@ -64,6 +64,10 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=Non
     # (a K row lives inside one head, so its outlier count must not depend on how the heads are spread over GPUs; a V row
     # spans the heads, so a shard selects k / world inside its own heads: see parallel.py)
     Ht = heads_total or H
+    if v_exact and Ht != H:
+        # exact cross-shard V selection (parallel.exact_v_selection): the row's outliers are chosen over ALL heads, a shard keeps
+        # the ones that fall into its heads -- anything between 0 and the full count, so its lists hold the full count per side
+        kv = int(int(B * Ht * T * D * s) / B / T / 2) if s > 0 else 0
     kk0_max = int(int(B * Ht * T * D * s) / B / T / 2) if s > 0 else 0
     # K outliers per side and channel row of a decode block: "nominal" = the sparsity applied to the row's own length; "reference" =
     # the reference's formula (B7: it depends on H*D, not on the row length), capped at half the row -- what gears_channelQ does to a
@@ -157,7 +161,49 @@ def block_kernel_status(dev="cuda") -> int:
     return st
 
 
-def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_off, loop, gen, kk0=0, seg0=0):
+def _draw_p0(shape_local, gen, dev, tp):
+    """Random start bases [NB, H_local, D, r].  Head-sharded: every rank draws the bases of ALL heads from the same stream and keeps
+    its own (so that a head's factors do not depend on how the heads are spread over GPUs)."""
+    NB, H, D, r = shape_local
+    if tp is None or tp["world"] == 1:
+        return torch.rand(shape_local, device=dev, generator=gen)
+    full = torch.rand((NB, H * tp["world"], D, r), device=dev, generator=gen)
+    return full[:, tp["rank"] * H:(tp["rank"] + 1) * H].contiguous()
+
+
+def _compress_value_exact(bufs, d, lead, B, H, D, v_src, T, t_off, seg, loop, P0v, tp, kk0, seg0):
+    """V payload of a head shard with the outliers selected over the WHOLE token row (all ranks' heads), bit-identical to the matching
+    head slice of the unsharded payload (tests/test_gpu_parallel.py).  parallel.exact_v_selection gives the local share of every
+    row's outliers + the global fill value; in the cache's fp16-stepwise arithmetic the fill is an fp16 number, so the quantizer sees
+    the row with its outliers REPLACED by the fill (HIP: quantize + pack + error, new_pack.py:253-288), the error is zeroed at the
+    outliers (they are restored exactly: compress_function.py:216-219), then the usual low-rank step, lists, chunk index, tiles."""
+    from .parallel import exact_v_selection
+    from .quant.new_pack import triton_quantize_and_pack_along_last_dim_witherror
+    lib = L.load()
+    p = L.ptr
+    NB = lead * B
+    Tmax, g, bits, kv = d["Tmax"], d["group"], d["bits"], d["kv"]
+    v4 = v_src.reshape(NB, H, -1, D)[:, :, :T]
+    filled, mask, oidx, oval = exact_v_selection(v4, kv, tp["rank"], tp["world"], tp.get("group"))
+    code, scale, mn, err = triton_quantize_and_pack_along_last_dim_witherror(filled, g, bits)
+    bufs["vcode"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = code
+    bufs["vscale"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = scale
+    bufs["vmn"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = mn
+    bufs["voidx"].view(NB, Tmax, 2 * kv)[:, t_off:t_off + T] = oidx
+    bufs["voval"].view(NB, Tmax, 2 * kv)[:, t_off:t_off + T] = oval
+    if d["lowrank"]:
+        err = err.view(NB, H, T, D).masked_fill_(mask, 0)
+        P, Q = C.lowrank(err, d["rv"], loop, P0v)
+        bufs["vPseg"].view(lead, d["nseg"], B, H, D, d["rv"])[:, seg] = P.view(lead, B, H, D, d["rv"])
+        bufs["vQtok"].view(NB, H, Tmax, d["rv"])[:, :, t_off:t_off + T] = Q
+    st = L.stream_ptr(v_src)
+    if "vochunk" in bufs:     # (the sentinel index 0xFFFF of an unused list slot lies beyond every head bound: the terminal entry is the count)
+        rc = lib.gear_outlier_chunk_index_ex(p(bufs["voidx"]), NB, 2 * T, 2 * Tmax, 2 * t_off, kv, kv, 128, H + 1,
+                                             p(bufs["vochunk"]), H + 1, st)
+        L.check(rc, "gear_outlier_chunk_index_ex(V)")
+
+
+def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_off, loop, gen, kk0=0, seg0=0, tp=None):
     """Compress K / V [lead*B, H, T, 128] (lead = layers riding in the batch dimension of pooled storage) and write the
     payload behind token t_off of the cache tensors in `bufs` (same leading dimension), factors into segment `seg`, K outlier
     lists at position o_off.  fp16-stepwise arithmetic (the fused path's mode)."""
@@ -168,9 +214,10 @@ def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_of
     Tmax, g, fpi, bits = d["Tmax"], d["group"], d["fpi"], d["bits"]
     P0k = P0v = None
     if d["lowrank"]:
-        P0k = torch.rand((NB, H, D, d["rk"]), device=dev, generator=gen)
-        P0v = torch.rand((NB, H, D, d["rv"]), device=dev, generator=gen)
-    if (USE_BLOCK_KERNEL and T == d["R"] == 64 and k_src is bufs.get("kwin") and v_src is bufs.get("vwin") and H <= 64
+        P0k = _draw_p0((NB, H, D, d["rk"]), gen, dev, tp)
+        P0v = _draw_p0((NB, H, D, d["rv"]), gen, dev, tp)
+    v_exact = tp is not None and tp["world"] > 1 and tp.get("exact", True) and d["kv"] > 0
+    if (USE_BLOCK_KERNEL and not v_exact and T == d["R"] == 64 and k_src is bufs.get("kwin") and v_src is bufs.get("vwin") and H <= 64
             and kk <= 16 and (d["kv"] <= 255 or "vochunk" not in bufs) and (H >= BLOCK_KERNEL_MIN_HEADS or not d["kv"])):
         # the decode-time block boundary: ONE launch over all (layer, head, K | V) tiles (csrc/block_fused.hip) instead of the
         # chain below (select, fused quantize + Gram, solve, Q pass; row compressor, Gram + solve, Q pass; chunk index; 2 tile
@@ -204,14 +251,17 @@ def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_of
         t_off, d["rk"], loop, p(P0k), p(kP), B * H, kP_stride, p(bufs.get("kQtok")), Tmax, t_off,
         p(bufs.get("koidx")) if kk else None, p(bufs.get("koval")) if kk else None, d["kcap"], o_off, 0, p(ws), ws.numel(), st)
     L.check(rc, "gear_compress_key_fused")
-    rc = lib.gear_compress_value_fused(
-        p(v_src), NB, H, T, g, bits, 0, d["kv"], p(bufs["vcode"]), p(bufs["vscale"]), p(bufs["vmn"]), Tmax, t_off, d["rv"],
-        loop, p(P0v), p(vP), B * H, vP_stride, p(bufs.get("vQtok")), Tmax, t_off, p(bufs.get("voidx")), p(bufs.get("voval")),
-        p(ws), ws.numel(), st)
-    L.check(rc, "gear_compress_value_fused")
+    if v_exact:
+        _compress_value_exact(bufs, d, lead, B, H, D, v_src, T, t_off, seg, loop, P0v, tp, kk0, seg0)
+    else:
+        rc = lib.gear_compress_value_fused(
+            p(v_src), NB, H, T, g, bits, 0, d["kv"], p(bufs["vcode"]), p(bufs["vscale"]), p(bufs["vmn"]), Tmax, t_off, d["rv"],
+            loop, p(P0v), p(vP), B * H, vP_stride, p(bufs.get("vQtok")), Tmax, t_off, p(bufs.get("voidx")), p(bufs.get("voval")),
+            p(ws), ws.numel(), st)
+        L.check(rc, "gear_compress_value_fused")
     # chunk indices of the sparse lists (what lets a 128-token attention chunk find its outliers without a search):
     # V: one row of H + 1 head bounds per new (token row, side); K: the prompt segment's entries, once, at prefill
-    if d["kv"] and "vochunk" in bufs:
+    if d["kv"] and "vochunk" in bufs and not v_exact:
         rc = lib.gear_outlier_chunk_index_ex(p(bufs["voidx"]), NB, 2 * T, 2 * Tmax, 2 * t_off, d["kv"], d["kv"], 128, H + 1,
                                              p(bufs["vochunk"]), H + 1, st)
         L.check(rc, "gear_outlier_chunk_index_ex(V)")
@@ -234,8 +284,13 @@ class GearKVCachePool:
     of every layer in place (compress_all): 7 launches per block boundary."""
 
     def __init__(self, n_layers: int, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device,
-                 head_dim: int = 128, seed: int = 0, heads_total: int = None):
-        shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim, heads_total)
+                 head_dim: int = 128, seed: int = 0, heads_total: int = None, tp: dict = None):
+        """tp = dict(rank, world, group[, exact=True]): this pool holds one head shard of `world`; with exact (default) the V outliers
+        of a token row are selected over all ranks' heads (one small all-gather per compress call, parallel.exact_v_selection)
+        instead of k / world inside the shard."""
+        self.tp = tp
+        v_exact = tp is not None and tp["world"] > 1 and tp.get("exact", True)
+        shapes, self.dims = _cache_dims(batch, n_kv_heads, max_tokens, compress_config, head_dim, heads_total, v_exact)
         if batch * n_kv_heads > 65535:
             raise L.GearError(f"GearKVCachePool: batch * kv heads = {batch * n_kv_heads} exceeds 65535 (one layer's heads ride on a "
                               "grid dimension of the prefill kernels)")
@@ -267,7 +322,7 @@ class GearKVCachePool:
         for l0, l1 in groups:
             sub = b if (l0, l1) == (0, self.L) else {n: t[l0:l1] for n, t in b.items()}
             _compress_into(sub, d, l1 - l0, self.B, self.H, self.D, sub["kwin"], sub["vwin"], R, t0, seg, d["kk_blk"], o_off,
-                           self.loop, self.gen, c0.kk0, c0.seg0)
+                           self.loop, self.gen, c0.kk0, c0.seg0, self.tp)
         for c in self.caches:
             c.n_comp += R
             c.n_win = 0
@@ -276,10 +331,12 @@ class GearKVCachePool:
 class GearKVCache:
     def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, compress_config: dict, device, head_dim: int = 128,
                  seed: int = 0, state: torch.Tensor = None, pool: GearKVCachePool = None, layer: int = 0,
-                 heads_total: int = None):
+                 heads_total: int = None, tp: dict = None):
         assert head_dim == 128
         cc = compress_config
-        shapes, d = _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim, heads_total)
+        self.tp = tp
+        v_exact = tp is not None and tp["world"] > 1 and tp.get("exact", True)
+        shapes, d = _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim, heads_total, v_exact)
         self.dims = d
         self.B, self.H, self.D = batch, n_kv_heads, head_dim
         self.bits, self.group, self.R = d["bits"], d["group"], d["R"]
@@ -326,7 +383,7 @@ class GearKVCache:
     def _store(self, k_src, v_src, T, seg, kk, o_off):
         assert self.n_comp + T <= self.Tmax, "cache capacity exceeded"
         _compress_into(self.bufs, self.dims, 1, self.B, self.H, self.D, k_src, v_src, T, self.n_comp, seg, kk, o_off, self.loop,
-                       self.gen, self.kk0, self.seg0)
+                       self.gen, self.kk0, self.seg0, self.tp)
         self.n_comp += T
 
     def prefill(self, k: torch.Tensor, v: torch.Tensor):

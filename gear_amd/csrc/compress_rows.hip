@@ -122,7 +122,7 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     constexpr int CPW = 32 / BITS;
     __shared__ uint32_t hist[3][256];
     __shared__ unsigned long long wave_tot[16];
-    __shared__ float wave_sum[16];
+    __shared__ double wave_sum[16];
     __shared__ int sh[8];  // 0 bin_hi, 1 need_hi, 2 bin_lo, 3 need_lo, 4 thr_hi, 5 take_hi, 6 thr_lo, 7 take_lo
     __shared__ uint32_t cand[2][CAND_CAP];   // composite (key, index) of the hi / lo candidates
     __shared__ uint32_t omask[2][512];       // per-element outlier bitmaps (hi / lo), row length <= 16384
@@ -159,10 +159,13 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     uint32_t flag_lo = 0, flag_hi = 0;  // bit j: element j of this lane is an outlier (small / large side)
     if (k > 0) {
         // ---------------- row mean (of the ORIGINAL row, compress_function.py:276 / :312)
-        float s = 0.0f;
+        // summed in fp64: fp16 values add exactly there, so the mean is the correctly rounded one whatever the order -- the oracle's,
+        // the block compressor's and the short-row kernel's, and the one a head-sharded job reconstructs from per-rank sums
+        // (cache.py: exact cross-shard V selection; an fp32 tree sum moved the fp16 fill value about once in 500 rows)
+        double s = 0.0;
         if (active) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) s += v[j];
+            for (int j = 0; j < 16; j++) s += (double)v[j];
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
@@ -337,9 +340,9 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
             }
         }
         // every path has crossed a barrier since wave_sum was written
-        float tot = 0.0f;
+        double tot = 0.0;
         for (int w = 0; w < nw; w++) tot += wave_sum[w];
-        const float mean = tot / (float)len;
+        const float mean = (float)(tot / (double)len);
         // ---------------- output slots (sorted by index) and the sparse payload
         if (!payload_done) {
             unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);

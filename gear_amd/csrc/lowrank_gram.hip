@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256, 2) void lr_gram_wave_kernel(const uint16_t* __
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
 
-    // Workgroups of different heads start at DIFFERENT places of their slab (G is a sum: any order): the heads lie 2^k bytes apart,
-    // and workgroups marching in lockstep through the same offsets of such regions keep hitting the same few HBM channels
-    // (tools/ubench/store_pattern.hip measured it for stores; here: 295 us -> see DESIGN section 6).  Logical step j -> physical
-    // step: 64-token groups rotated by a per-head amount.
+    // ROTATE (measurement builds only): workgroups of different heads start at different places of their slab, in case lockstep
+    // marching through the same offsets of regions 2^k bytes apart camped on a few HBM channels (tools/ubench/store_pattern.hip saw
+    // that for stores).  Measured here: 2 % -- and the summation order then depends on the head's index in the call, which a head
+    // shard's bit-for-bit comparison with the unsharded run cannot have.  Off in the product.  Logical step j -> physical step:
     const int ngrp = (nstep + 3) >> 2;
     const int rotg = ROTATE ? (int)((((uint32_t)bh * 2654435761u) >> 12) % (uint32_t)ngrp) : 0;
     auto phys = [&](int j) {
@@ -511,10 +511,13 @@ int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int lo
     do {                                                                                                                 \
         if (split && TM && gear_options().gram_fused != 2) {                                                             \
             const int nstg = gear_options().gram_nstg;                                                                   \
-            auto kfn = nstg == 2 ? lr_gram_wave_kernel<2, true> : (nstg == 4 ? lr_gram_wave_kernel<4, true>                \
-                       : (nstg == 5 ? lr_gram_wave_kernel<3, false> : (nstg == 6 ? lr_gram_wave_kernel<3, true, 1>          \
-                       : (nstg == 7 ? lr_gram_wave_kernel<3, true, 2> : (nstg == 8 ? lr_gram_wave_kernel<3, true, 3>      \
-                       : lr_gram_wave_kernel<3, true>)))));                                                               \
+            /* default: 3 steps in flight, NO rotation of the start position (a head's summation order must not depend on where the  \
+               head sits in the call: a head shard's factors are compared bit for bit with the unsharded run's); the other          \
+               instantiations are the measurement builds of tools/exp_gram_elim.py */                                              \
+            auto kfn = nstg == 2 ? lr_gram_wave_kernel<2, false> : (nstg == 4 ? lr_gram_wave_kernel<4, false>              \
+                       : (nstg == 5 ? lr_gram_wave_kernel<3, true> : (nstg == 6 ? lr_gram_wave_kernel<3, false, 1>          \
+                       : (nstg == 7 ? lr_gram_wave_kernel<3, false, 2> : (nstg == 8 ? lr_gram_wave_kernel<3, false, 3>    \
+                       : lr_gram_wave_kernel<3, false>)))));                                                              \
             const size_t wsh = (size_t)4 * 16 * ET_PITCH * 2 > (size_t)4 * 32 * 33 * 4 ? (size_t)4 * 16 * ET_PITCH * 2 : (size_t)4 * 32 * 33 * 4; \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsh);           \
             hipLaunchKernelGGL(kfn, dim3((unsigned)nslab, (unsigned)bh), dim3(256), wsh, st, E, S, gpart, tps);          \

@@ -20,14 +20,17 @@ from .modeling_llamagear import apply_rotary_pos_emb
 
 class FastGearDecoder:
     def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0, tp_rank: int = 0, tp_world: int = 1,
-                 tp_group=None, tp_exchange: str = "peer"):
+                 tp_group=None, tp_exchange: str = "peer", v_selection: str = "exact"):
         """tp_world > 1: the cache and the attention are sharded head-wise: this rank owns
         Hq / tp_world query heads with their KV heads -- local q/k/v projection rows, local compressed cache, local attention --
         and all-gathers the per-rank attention output (parallel.HeadGather, pre-allocated) in front of the replicated
         o_proj / MLP, which every rank computes in full.  The model passed in holds the full (replicated) weights.
         tp_exchange: "peer" = parallel.PeerHeadGather (stores into the peers' memory from one launch per layer, capturable in
         the token-step graph; falls back to the collective, on every rank alike, when the peer mappings cannot be set up),
-        "collective" = parallel.HeadGather (all_gather_into_tensor, eager steps only)."""
+        "collective" = parallel.HeadGather (all_gather_into_tensor; captured too when the RCCL capture probe passes).
+        v_selection: "exact" = the V outliers of a token row are selected over ALL ranks' heads (the reference's row spans the heads:
+        compress_function.py:304-311; parallel.exact_v_selection, one small all-gather per compress call), "per_shard" = k / world
+        inside the shard's own heads (rounds 1-3)."""
         self.model = model
         cfg = model.config
         self.cfg = cfg
@@ -44,8 +47,11 @@ class FastGearDecoder:
         self.layers = []
         cc0 = model.model.layers[0].self_attn.compress_config
         # pooled cache storage: block boundaries compress every layer's window in one launch sequence
+        if v_selection not in ("exact", "per_shard"):
+            raise ValueError(f"v_selection {v_selection!r}: 'exact' or 'per_shard'")
+        tp = dict(rank=tp_rank, world=tp_world, group=tp_group, exact=v_selection == "exact") if tp_world > 1 else None
         self.pool = GearKVCachePool(len(model.model.layers), batch, self.Hkv, max_tokens, cc0, dev, self.D, seed=seed,
-                                    heads_total=self.Hkv_full)
+                                    heads_total=self.Hkv_full, tp=tp)
         for i, layer in enumerate(model.model.layers):
             at, mlp = layer.self_attn, layer.mlp
             assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
@@ -65,7 +71,7 @@ class FastGearDecoder:
             self.layers.append(dict(
                 wqkv=wqkv.contiguous(), wqkv_full=wqkv_full if tp_world > 1 else None, wo=at.o_proj.weight, wgu=wgu.contiguous(), wd=mlp.down_proj.weight,
                 cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i,
-                                  pool=self.pool, layer=i, heads_total=self.Hkv_full),
+                                  pool=self.pool, layer=i, heads_total=self.Hkv_full, tp=tp),
                 rotary=at.rotary_emb))
         self.w_head = (model.lm_head.weight * model.model.norm.weight[None, :]).contiguous()
         self.pos = 0

@@ -206,6 +206,78 @@ def _append_factor(lst: list, new: torch.Tensor):
         lst[1] = torch.cat([lst[1], new], dim=0)
 
 
+class GearHookCache:
+    """The 17-slot cache tuple of LlamaAttention_GEAR (modeling_llamagear.py:458-466) as a VIEW of a pre-allocated, kernel-native
+    GearKVCache: slot 8 (kv_seq_len, the one slot the model reads, :624 / :838) is a plain int, every other slot is materialised
+    when somebody indexes it -- slices of the cache tensors with the lengths this step had, the factor lists re-shaped into the
+    reference's [prefill, stacked [nbuf,B,H,.,r]] form.  The attention hook recognises the object and takes its fast decode path
+    (window append in place, ONE fused attention call over the packed cache, compress of a full window in place): no torch.cat of
+    the payload, no per-token GEMV pair + eager softmax.  len() == 17, iteration and indexing behave like the tuple."""
+
+    def __init__(self, cache, lowrank: bool, seq_len: int):
+        self.cache, self.lowrank = cache, lowrank
+        self.n_comp, self.n_win, self.seg0, self.seq_len = cache.n_comp, cache.n_win, cache.seg0, seq_len
+
+    def __len__(self):
+        return 17
+
+    def __iter__(self):
+        return (self[i] for i in range(17))
+
+    def _factors(self, tok, seg):
+        """token-side [B,H,T,r] + per-segment channel-side [nseg,B,H,D,r] -> (token list, channel list) in the reference's form."""
+        c = self.cache
+        if not self.lowrank or self.n_comp == 0:
+            return [None], [None]
+        R = c.R
+        if self.seg0:
+            first_t, first_c, t1, s1 = tok[:, :, :self.seg0], seg[0], self.seg0, 1
+        else:
+            first_t, first_c, t1, s1 = tok[:, :, :R], seg[1], R, 2
+        tl, cl = [first_t], [first_c]
+        nb = (self.n_comp - t1) // R
+        if nb > 0:
+            B, H, r = tok.shape[0], tok.shape[1], tok.shape[-1]
+            tl.append(tok[:, :, t1:self.n_comp].reshape(B, H, nb, R, r).permute(2, 0, 1, 3, 4))
+            cl.append(seg[s1:s1 + nb])
+        return tl, cl
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(17)))
+        if i < 0:
+            i += 17
+        c, n, w = self.cache, self.n_comp, self.n_win
+        if i == 8:
+            return self.seq_len
+        if i in (11, 12, 15, 16):
+            return None
+        if i in (1, 5):
+            return None if w == 0 else (c.kwin if i == 1 else c.vwin)[:, :, :w]
+        if i in (0, 2, 3):
+            if n == 0:
+                return None
+            t, div = ((c.kcode, c.fpi), (c.kscale, c.group), (c.kmn, c.group))[(0, 2, 3).index(i)]
+            return t[..., :n // div]
+        if i in (4, 6, 7):
+            return None if n == 0 else (c.vcode, c.vscale, c.vmn)[(4, 6, 7).index(i)][:, :, :n]
+        if i in (9, 10):
+            tl, cl = self._factors(c.kQtok, c.kPseg) if self.lowrank else ([None], [None])
+            return tl if i == 9 else cl                   # K: P = token side (:227-230), Q = channel side
+        if i in (13, 14):
+            tl, cl = self._factors(c.vQtok, c.vPseg) if self.lowrank else ([None], [None])
+            return cl if i == 13 else tl                  # V: P = channel side, Q = token side
+        raise IndexError(i)
+
+    def materialize(self) -> tuple:
+        """The plain tuple (own storage): what the tuple-based path of the hook continues from."""
+        def own(x):
+            if isinstance(x, list):
+                return [own(y) for y in x]
+            return x.contiguous().clone() if torch.is_tensor(x) else x
+        return tuple(own(self[i]) for i in range(17))
+
+
 class LlamaAttention_GEAR(nn.Module):
     """modeling_llamagear.py:113-484: attention whose cache is the packed GEAR payload plus an fp16 residual
     window of `residual` tokens; a block is compressed whenever the window fills."""
@@ -275,6 +347,113 @@ class LlamaAttention_GEAR(nn.Module):
                 v_full = None
         return (kc, k_full, ks, km, vc, v_full, vs, vm, T, kp, kq, None, None, vp, vq, None, None)
 
+    # ---- the fast decode path over a pre-allocated cache (round 4) ---------------------------------------------
+    fast_decode = True              # class-wide switch (tests compare with the tuple path)
+    decode_mask_is_zero = False     # set True when the caller's decode-step attention_mask is known to be all zeros (no padding)
+    fused_rope = True               # decode steps with implicit positions: RoPE + window append in one launch (gear_rope_append)
+
+    def _fast_eligible(self, T: int) -> bool:
+        cc = self.compress_config
+        R = self.residual_length
+        return (self.fast_decode and self.head_dim == 128 and R in (64, 128) and cc["group_size"] in (32, 64)
+                and R % cc["group_size"] == 0 and cc["quantize_bit"] in (2, 4)
+                and T != R                  # (the reference strands V in fp16 for a prompt of exactly `residual` tokens, :416)
+                and T < 16384 and not (cc.get("left") or cc.get("sparsity")))
+
+    def _store_block(self, c, k_src, v_src, T: int):
+        """Compress T tokens (K [B,H,T,128], V alike) with the hook's own operators -- the reference's order of operations and of
+        random draws (key first, :265-286, then value, :335-378) -- and put the payload behind token c.n_comp of the cache."""
+        cc = self.compress_config
+        t0, seg = c.n_comp, c._segment_of(c.n_comp)
+        kc, ks, km, kp, kq = key_compression(k_src.transpose(2, 3).contiguous(), cc)
+        vc, vs, vm, vp, vq = value_compression(v_src.contiguous(), cc)
+        c.kcode[..., t0 // c.fpi:(t0 + T) // c.fpi] = kc
+        c.kscale[..., t0 // c.group:(t0 + T) // c.group] = ks
+        c.kmn[..., t0 // c.group:(t0 + T) // c.group] = km
+        c.vcode[:, :, t0:t0 + T] = vc
+        c.vscale[:, :, t0:t0 + T] = vs
+        c.vmn[:, :, t0:t0 + T] = vm
+        if kp is not None:
+            c.kQtok[:, :, t0:t0 + T] = kp
+            c.kPseg[seg] = kq
+            c.vQtok[:, :, t0:t0 + T] = vq
+            c.vPseg[seg] = vp
+        c.n_comp += T
+
+    def _fast_prefill_cache(self, key_states, value_states):
+        from .cache import GearKVCache
+        cc = self.compress_config
+        B, T = key_states.shape[0], key_states.shape[-2]
+        R = self.residual_length
+        cap = max(int(getattr(self.config, "max_position_embeddings", 4096)), T + R)
+        c = GearKVCache(B, self.num_key_value_heads, min(cap, 16384), dict(cc), key_states.device, self.head_dim)
+        nq = T - T % R
+        if nq:
+            c.seg0 = nq
+            self._store_block(c, key_states[:, :, :nq], value_states[:, :, :nq], nq)
+        c.n_win = T - nq
+        if c.n_win:
+            c.kwin[:, :, :c.n_win] = key_states[:, :, nq:]
+            c.vwin[:, :, :c.n_win] = value_states[:, :, nq:]
+        return GearHookCache(c, _uses_lowrank(cc), T)
+
+    def fused_weights(self):
+        """q/k/v projection weights as ONE [Nq + 2 Nkv, hidden] matrix for the fused token-step GEMV.  No second copy: the three
+        nn.Linear parameters are re-pointed at row slices of the fused buffer (contiguous row ranges, so every other user of the
+        modules sees ordinary weights).  Rebuilt if somebody replaced a weight's storage since."""
+        q, k, v = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
+        w = getattr(self, "_wqkv", None)
+        nq, nk = q.shape[0], k.shape[0]
+        if (w is None or q.data_ptr() != w.data_ptr() or k.data_ptr() != w[nq:].data_ptr()
+                or v.data_ptr() != w[nq + nk:].data_ptr()):
+            with torch.no_grad():
+                w = torch.cat([q.data, k.data, v.data], 0).contiguous()
+                q.data, k.data, v.data = w[:nq], w[nq:nq + nk], w[nq + nk:]
+            self._wqkv = w
+        return w
+
+    def decode_token_fused(self, res, delta, norm_weight, eps: float, hc: GearHookCache):
+        """The hook's decode step for the decoder layer's fused path (batch <= 4, implicit positions, stock rotary, no bias, one
+        rank): [residual add + RMSNorm + q/k/v GEMV + RoPE + window append] = ONE launch (gear_gemv_qkv_rope), fused attention over
+        the packed cache, compress of a full window in place.  Returns (res + delta, attention output [B, Hq * 128], new cache) or
+        None when the cache is full (the caller takes the tuple path)."""
+        c = hc.cache
+        if c.n_comp + c.n_win + 1 > c.Tmax:
+            return None
+        B, K = res.shape
+        kv_seq_len = hc.seq_len + 1
+        res1 = torch.empty_like(res) if delta is not None else res
+        q = torch.empty((B, self.num_heads, 1, self.head_dim), dtype=res.dtype, device=res.device)
+        rc = L.load().gear_gemv_qkv_rope(L.ptr(res), L.ptr(delta), L.ptr(norm_weight), eps, L.ptr(self.fused_weights()), B, K,
+                                         self.num_heads, self.num_key_value_heads, self.head_dim, kv_seq_len - 1, c.n_win, c.R,
+                                         float(self.rope_theta), None, L.ptr(res1) if delta is not None else None, L.ptr(q),
+                                         L.ptr(c.kwin), L.ptr(c.vwin), L.stream_ptr(res))
+        L.check(rc, "gear_gemv_qkv_rope")
+        c.n_win += 1
+        out = c.attend(q)
+        if c.n_win == c.R:
+            self._store_block(c, c.kwin, c.vwin, c.R)
+            c.n_win = 0
+        return res1, out.view(B, self.num_heads * self.head_dim), GearHookCache(c, hc.lowrank, kv_seq_len)
+
+    def _fast_decode_step(self, query_states, key_states, value_states, hc: GearHookCache, kv_seq_len: int, qkv_flat=None):
+        """One token over the pre-allocated cache: window append, fused attention (packed K / V + factors + fp16 window: one call of
+        gear_attn_decode_cache where the tuple path runs two GEMV pairs, the eager softmax and ~40 small ops), compress of a full window."""
+        c = hc.cache
+        if c.n_comp + c.n_win + 1 > c.Tmax:
+            return None                                  # capacity: the caller continues on the tuple path
+        if qkv_flat is not None:
+            # RoPE at position kv_seq_len - 1 on q and k + window append in ONE launch (gear_rope_append: the reference's
+            # rotary arithmetic op by op, :203-205) instead of ~25 eager ops
+            query_states = c.append_rope(qkv_flat, self.num_heads, kv_seq_len - 1, float(self.rope_theta))
+        else:
+            c.append(key_states, value_states)
+        out = c.attend(query_states)
+        if c.n_win == c.R:
+            self._store_block(c, c.kwin, c.vwin, c.R)
+            c.n_win = 0
+        return out, GearHookCache(c, hc.lowrank, kv_seq_len)
+
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.LongTensor] = None, past_key_value: Optional[Tuple] = None,
                 output_attentions: bool = False, use_cache: bool = False, **kwargs):
@@ -287,14 +466,37 @@ class LlamaAttention_GEAR(nn.Module):
         kv_seq_len = key_states.shape[-2]
         if past_key_value is not None:
             kv_seq_len += past_key_value[8]
-        if position_ids is None:
-            position_ids = torch.arange(kv_seq_len - q_len, kv_seq_len, device=hidden_states.device).unsqueeze(0)
-        cos, sin = self.rotary_emb(value_states, position_ids)
-        query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
         n_rep = self.num_key_value_groups
         inv_norm = math.sqrt(self.head_dim)   # the reference divides (:261, :387)
+        fast_ok = (isinstance(past_key_value, GearHookCache) and q_len == 1
+                   and (attention_mask is None or self.decode_mask_is_zero))
+        # implicit positions (the model passes none at decode: the token sits at kv_seq_len - 1) and the stock rotary module:
+        # RoPE is fused with the window append below; anything else takes the reference's rotary code
+        fused_rope = (fast_ok and self.fused_rope and position_ids is None and type(self.rotary_emb) is LlamaRotaryEmbedding
+                      and hidden_states.dtype == torch.float16)
+        if not fused_rope:
+            if position_ids is None:
+                position_ids = torch.arange(kv_seq_len - q_len, kv_seq_len, device=hidden_states.device).unsqueeze(0)
+            cos, sin = self.rotary_emb(value_states, position_ids)
+            query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
 
-        if past_key_value is not None:
+        fast = None
+        if isinstance(past_key_value, GearHookCache):
+            if fast_ok:
+                qkv_flat = None
+                if fused_rope:
+                    qkv_flat = torch.cat([query_states.reshape(bsz, -1), key_states.reshape(bsz, -1),
+                                          value_states.reshape(bsz, -1)], dim=-1)
+                fast = self._fast_decode_step(query_states, key_states, value_states, past_key_value, kv_seq_len, qkv_flat)
+                if fast is None and fused_rope:          # (capacity fallback: rotate for the tuple path after all)
+                    position_ids = torch.arange(kv_seq_len - q_len, kv_seq_len, device=hidden_states.device).unsqueeze(0)
+                    cos, sin = self.rotary_emb(value_states, position_ids)
+                    query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+            if fast is None:
+                past_key_value = past_key_value.materialize()   # capacity / mask / q_len: the tuple path takes over
+        if fast is not None:
+            attn_output, new_cache = fast
+        elif past_key_value is not None:
             if q_len != 1:
                 raise ValueError("decode steps take one token at a time (the packed-cache GEMV is q_len == 1)")
             (kc, k_full, ks, km, vc, v_full, vs, vm, _, kp, kq, _, _, vp, vq, _, _) = past_key_value
@@ -361,7 +563,10 @@ class LlamaAttention_GEAR(nn.Module):
                                          torch.tensor(torch.finfo(attn_weights.dtype).min, device=attn_weights.device))
             attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)
             attn_output = torch.matmul(attn_weights, _rep(value_states, n_rep))
-            new_cache = self._prefill_cache(key_states, value_states) if use_cache else None
+            if use_cache and self._fast_eligible(kv_seq_len):
+                new_cache = self._fast_prefill_cache(key_states, value_states)
+            else:
+                new_cache = self._prefill_cache(key_states, value_states) if use_cache else None
 
         if attn_output.size() != (bsz, self.num_heads, q_len, self.head_dim):
             raise ValueError(f"`attn_output` should be of size {(bsz, self.num_heads, q_len, self.head_dim)}, but is"
@@ -415,8 +620,72 @@ class LlamaDecoderLayer_GEAR(nn.Module):
         hidden_states = hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
         return hidden_states, present
 
+    def fused_gate_up(self):
+        """gate_proj / up_proj weights as ONE [2 I, hidden] matrix ([gate rows | up rows]); like the attention's q/k/v: the two
+        parameters are re-pointed at slices of it, no second copy."""
+        g, u = self.mlp.gate_proj.weight, self.mlp.up_proj.weight
+        w = getattr(self, "_wgu", None)
+        I = g.shape[0]
+        if w is None or g.data_ptr() != w.data_ptr() or u.data_ptr() != w[I:].data_ptr():
+            with torch.no_grad():
+                w = torch.cat([g.data, u.data], 0).contiguous()
+                g.data, u.data = w[:I], w[I:]
+            self._wgu = w
+        return w
+
+    def decode_step(self, res: torch.Tensor, delta: Optional[torch.Tensor], past):
+        """One token through the layer with the glue fused (csrc/decode_ops.hip; the same fp16 arithmetic op by op as the modules
+        above): res [B, hidden] is the residual stream BEFORE `delta` (the previous layer's MLP output, or None) is added.
+        [residual add + RMSNorm] -> attention hook (its reference signature) -> [residual add + RMSNorm] -> gate / up ->
+        [SiLU * up] -> down: 15 launches where forward() issues ~50.  Returns (res', delta', present)."""
+        lib = L.load()
+        B, Hd = res.shape
+        st = L.stream_ptr(res)
+        ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
+        at, mlp = self.self_attn, self.mlp
+        if (B <= 4 and isinstance(past, GearHookCache) and at.tp_world == 1 and at.q_proj.bias is None and at.fused_rope
+                and at.fast_decode and type(at.rotary_emb) is LlamaRotaryEmbedding and mlp.down_proj.bias is None):
+            # 7 launches: [add + norm + qkv + RoPE + append] -> attention (2) -> [o_proj + add] -> [norm + gate/up] -> [SiLU * up]
+            # -> [down + add]; the weights are the modules' own (q/k/v and gate/up fused by re-pointing the parameters at slices)
+            r = at.decode_token_fused(res, delta, ln1.weight, ln1.variance_epsilon, past)
+            if r is not None:
+                res1, a, present = r
+                res2 = torch.empty_like(res)
+                L.check(lib.gear_gemv_f16_add(L.ptr(a), L.ptr(at.o_proj.weight), B, a.shape[1], Hd, L.ptr(res1), L.ptr(res2), st),
+                        "gear_gemv_f16_add")
+                wgu = self.fused_gate_up()
+                I = wgu.shape[0] // 2
+                gu = torch.empty((B, 2 * I), dtype=res.dtype, device=res.device)
+                L.check(lib.gear_gemv_f16_norm(L.ptr(res2), None, L.ptr(ln2.weight), ln2.variance_epsilon, L.ptr(wgu), B, Hd,
+                                               2 * I, 0, None, L.ptr(gu), st), "gear_gemv_f16_norm")
+                act = torch.empty((B, I), dtype=res.dtype, device=res.device)
+                L.check(lib.gear_silu_mul(L.ptr(gu), B, I, L.ptr(act), st), "gear_silu_mul")
+                res3 = torch.empty_like(res)
+                L.check(lib.gear_gemv_f16_add(L.ptr(act), L.ptr(mlp.down_proj.weight), B, I, Hd, L.ptr(res2), L.ptr(res3), st),
+                        "gear_gemv_f16_add")
+                return res3, None, present
+        x, res1 = torch.empty_like(res), torch.empty_like(res)
+        L.check(lib.gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(ln1.weight), B, Hd, ln1.variance_epsilon, L.ptr(res1),
+                                     L.ptr(x), st), "gear_add_rmsnorm")
+        a, _, present = self.self_attn(x.unsqueeze(1), None, None, past, use_cache=True)
+        x2, res2 = torch.empty_like(res), torch.empty_like(res)
+        L.check(lib.gear_add_rmsnorm(L.ptr(res1), L.ptr(a.reshape(B, Hd)), L.ptr(ln2.weight), B, Hd, ln2.variance_epsilon,
+                                     L.ptr(res2), L.ptr(x2), st), "gear_add_rmsnorm")
+        I = mlp.gate_proj.weight.shape[0]
+        if B == 1:
+            gu = torch.empty((1, 2 * I), dtype=res.dtype, device=res.device)
+            torch.mm(x2, mlp.gate_proj.weight.t(), out=gu[:, :I])
+            torch.mm(x2, mlp.up_proj.weight.t(), out=gu[:, I:])
+        else:
+            gu = torch.cat([mlp.gate_proj(x2), mlp.up_proj(x2)], dim=-1)
+        act = torch.empty((B, I), dtype=res.dtype, device=res.device)
+        L.check(lib.gear_silu_mul(L.ptr(gu), B, I, L.ptr(act), st), "gear_silu_mul")
+        return res2, mlp.down_proj(act), present
+
 
 class LlamaModel_GEAR(nn.Module):
+    fused_decode_glue = True        # decode steps over GearHookCache layers use LlamaDecoderLayer_GEAR.decode_step
+
     def __init__(self, config, compress_config):
         super().__init__()
         self.config = config
@@ -427,6 +696,21 @@ class LlamaModel_GEAR(nn.Module):
 
     def forward(self, input_ids, past_key_values=None, use_cache=True):
         bsz, q_len = input_ids.shape
+        if (q_len == 1 and use_cache and past_key_values is not None and self.fused_decode_glue
+                and all(isinstance(pk, GearHookCache) for pk in past_key_values)
+                and self.embed_tokens.weight.dtype == torch.float16 and self.embed_tokens.weight.is_cuda
+                and self.config.hidden_size % 8 == 0 and self.config.hidden_size <= 8192
+                and self.layers[0].mlp.gate_proj.bias is None):
+            # decode step over pre-allocated caches: fused glue around the attention hook (LlamaDecoderLayer_GEAR.decode_step)
+            res, delta = self.embed_tokens(input_ids[:, 0]), None
+            presents = []
+            for layer, pk in zip(self.layers, past_key_values):
+                res, delta, present = layer.decode_step(res, delta, pk)
+                presents.append(present)
+            y = torch.empty_like(res)
+            L.check(L.load().gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(self.norm.weight), bsz, res.shape[1],
+                                              self.norm.variance_epsilon, None, L.ptr(y), L.stream_ptr(res)), "gear_add_rmsnorm")
+            return y.unsqueeze(1), tuple(presents)
         past_len = past_key_values[0][8] if past_key_values is not None else 0     # slot 8 (:624)
         position_ids = torch.arange(past_len, past_len + q_len, device=input_ids.device).unsqueeze(0)
         hidden_states = self.embed_tokens(input_ids)

@@ -31,6 +31,76 @@ def outliers_per_shard(k_full: int, world: int) -> int:
     return max(1, k_full // world) if k_full > 0 else 0
 
 
+def all_gather_stack(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """t [...] on every rank -> [world, ...] (rank r's tensor at slot r).  gloo cannot gather device tensors: staged through the host
+    there (the one-GPU tests); RCCL gathers in place."""
+    import torch.distributed as dist
+    t = t.contiguous()
+    shp = (world * t.shape[0],) + tuple(t.shape[1:])      # (ranks concatenated on dim 0: the one output shape gloo accepts too)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        out = torch.empty(shp, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t.cpu(), group=group)
+        return out.view((world,) + tuple(t.shape)).to(t.device)
+    out = torch.empty(shp, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.view((world,) + tuple(t.shape))
+
+
+def _order_key(bits: torch.Tensor) -> torch.Tensor:
+    """fp16 bit patterns (int64, 0 .. 65535) -> ascending 16-bit order keys, -0 == +0 (csrc/ktile.h sort_key16)."""
+    bits = torch.where(bits == 0x8000, torch.zeros_like(bits), bits)
+    return torch.where((bits & 0x8000) != 0, (~bits) & 0xFFFF, bits | 0x8000)
+
+
+def exact_v_selection(v: torch.Tensor, k: int, rank: int, world: int, group=None):
+    """Exact cross-shard outlier selection of V token rows (the simulated path's gears_tokenQ: the k smallest and k largest of a
+    token's row ACROSS ALL heads, compress_function.py:297-333; ties: lower index first, the build's rule).
+
+    v fp16 [NB, H_local, T, 128]: this rank's heads (ranks hold contiguous head ranges in rank order).  Every rank contributes, per
+    row and side, its k best candidates as unique composites (order key, then lower GLOBAL column first) and its exact fp64 row sum;
+    after ONE all-gather every rank finds the row's k-th composite per side and keeps the local elements at or beyond it.
+    Exchange: 8 (2 k + 1) bytes per row and rank -- 64 rows per layer at a decode-time block boundary; a prompt's rows go in one go
+    too (for Llama-2-7B at 4k tokens on 8 GPUs that is 42 MB sent and 0.3 GB received per rank, once per prompt).
+
+    Returns (filled [NB,H,T,128] fp16: outliers replaced by the fp16 global row mean, mask [NB,H,T,128] bool,
+             oidx int16 [NB,T,2k]: local column h*128 + d of this rank's outliers, small side then large side, each ascending,
+             unused slots 0xFFFF (lies beyond every head bound, so the chunk index's terminal entry becomes the count),
+             oval fp16 [NB,T,2k])."""
+    NB, H, T, D = v.shape
+    Ll = H * D
+    rows = v.permute(0, 2, 1, 3).reshape(NB * T, Ll)                       # row (nb, t): this rank's segment
+    bits = rows.view(torch.int16).to(torch.int64) & 0xFFFF
+    key = _order_key(bits)
+    col = torch.arange(Ll, device=v.device, dtype=torch.int64)
+    inv_g = 0xFFFFF - (rank * Ll + col)                                    # lower global column first (20 bits: <= 8192 * 128 columns)
+    cl = (key << 20) | inv_g                                               # large side: bigger composite = selected first
+    cs = ((0xFFFF - key) << 20) | inv_g                                    # small side
+    kc = min(k, Ll)
+    cand = torch.full((NB * T, 2 * k + 1), -1, dtype=torch.int64, device=v.device)
+    cand[:, :kc] = torch.topk(cl, kc, dim=1).values
+    cand[:, k:k + kc] = torch.topk(cs, kc, dim=1).values
+    cand[:, 2 * k] = rows.double().sum(1).view(torch.int64)                # exact: fp16 values add exactly in fp64
+    allc = all_gather_stack(cand, world, group) if world > 1 else cand[None]
+    thr_l = torch.topk(allc[:, :, :k].permute(1, 0, 2).reshape(NB * T, world * k), k, dim=1).values[:, k - 1]
+    thr_s = torch.topk(allc[:, :, k:2 * k].permute(1, 0, 2).reshape(NB * T, world * k), k, dim=1).values[:, k - 1]
+    total = allc[:, :, 2 * k].contiguous().view(torch.float64).sum(0)
+    fill = (total / float(Ll * world)).to(torch.float32).to(torch.float16)  # the kernels' fill: fp16(float(exact sum / length))
+    m_l, m_s = cl >= thr_l[:, None], cs >= thr_s[:, None]
+    mask_rows = m_l | m_s
+    filled = torch.where(mask_rows, fill[:, None], rows)
+    big = torch.full_like(col, 0xFFFF)
+    i_s = torch.topk(torch.where(m_s, col, big), k, dim=1, largest=False).values if k <= Ll else None
+    i_l = torch.topk(torch.where(m_l, col, big), k, dim=1, largest=False).values
+    idx = torch.cat([i_s, i_l], 1)                                         # [rows, 2k], 0xFFFF = unused
+    val = torch.gather(bits, 1, idx.clamp(max=Ll - 1))
+    val = torch.where(idx == 0xFFFF, torch.zeros_like(val), val)
+    to4 = lambda t: t.view(NB, T, H, D).permute(0, 2, 1, 3).contiguous()
+    u16 = lambda t: ((t + 0x8000) % 0x10000 - 0x8000).to(torch.int16)      # 0 .. 65535 -> the int16 with the same bits
+    oidx = u16(idx).view(NB, T, 2 * k)
+    oval = u16(val).view(torch.float16).view(NB, T, 2 * k)
+    return to4(filled), to4(mask_rows), oidx, oval
+
+
 def all_gather_heads(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
     """x [B, q, H_local*D] on every rank -> [B, q, world*H_local*D] with rank r's heads at slot r."""
     import torch.distributed as dist

@@ -47,6 +47,7 @@ def _trace(attn, cfg, prefill_len, n_decode, seed):
     vcap = []
     h2 = attn.v_proj.register_forward_hook(lambda m, i, o: vcap.append(o))
     M.apply_rotary_pos_emb = spy
+    attn.fused_rope = False                        # (the spy needs the rotary call: the fused RoPE + append launch has its own test)
     import gear_amd.modeling_llama_kivi as MK      # (imports the function by name: patch its reference too)
     MK.apply_rotary_pos_emb = spy
     try:
@@ -335,6 +336,105 @@ def test_matmul_withlrap_blocks_of_128_tokens():
     vdeq = new_pack.unpack_and_dequant_vcache(vcode, vscale.unsqueeze(-1), vmn.unsqueeze(-1), 64, 2).float()
     vlr = torch.cat([(p[4].float() @ p[3].float().transpose(2, 3)) for p in vparts], 2)
     assert rel_fro(host(got), host(a.float() @ rp(vdeq + vlr))) < 3e-3
+
+
+def _tiny_model(cc, layers=2, heads=4, kv=2):
+    from gear_amd.modeling_llamagear import LlamaConfigLite, LlamaForCausalLM_GEARKIVI
+    cfg = LlamaConfigLite(vocab_size=512, hidden_size=heads * 128, intermediate_size=1024, num_hidden_layers=layers,
+                          num_attention_heads=heads, num_key_value_heads=kv, max_position_embeddings=512,
+                          k_bits=cc["quantize_bit"], v_bits=cc["quantize_bit"], residual_length=cc["residual"])
+    torch.manual_seed(3)
+    return LlamaForCausalLM_GEARKIVI(cfg, cc).half().cuda().eval()
+
+
+@pytest.mark.parametrize("method,bits,prompt", [("gearlKIVI", 2, 150), ("KIVI", 4, 40), ("gearlKIVI", 4, 128)])
+def test_hook_fast_decode_path_equals_tuple_path(method, bits, prompt):
+    """Round 4: the hook's decode branch over a pre-allocated cache (GearHookCache: in-place window append, ONE fused attention
+    call, in-place block compress; fused RoPE + append; fused residual / RMSNorm / SwiGLU glue in the decoder layer) against the
+    tuple path (the reference's shape: torch.cat payloads, GEMV pairs, eager softmax), teacher-forced on the same tokens with the
+    same random bases: logits agree step by step, slot 8 and the window / compressed split are the same, and the packed K / V
+    codes of LAYER 0 -- whose inputs do not depend on any attention output of the other path -- are bit-identical."""
+    import gear_amd.compress as Cm
+    from gear_amd.modeling_llamagear import GearHookCache, LlamaAttention_GEAR, LlamaModel_GEAR
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
+    model = _tiny_model(cc)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 512, (2, prompt), generator=g).cuda()
+    steps = torch.randint(0, 512, (2, 90), generator=g).cuda()
+    runs = {}
+    orig = Cm.draw_p0
+    try:
+        for fast in (False, True):
+            LlamaAttention_GEAR.fast_decode = fast
+            LlamaModel_GEAR.fused_decode_glue = fast
+            gen = torch.Generator().manual_seed(11)           # the same bases in the same order for both paths
+            Cm.draw_p0 = lambda B, H, S, Dm, rank, device: torch.rand((B, H, Dm, rank), generator=gen).to(device)
+            with torch.no_grad():
+                logits, past = model(ids, None, True)
+                outs = [logits]
+                for i in range(steps.shape[1]):
+                    logits, past = model(steps[:, i:i + 1], past, True)
+                    outs.append(logits)
+            runs[fast] = (torch.cat(outs, 1).float(), past)
+    finally:
+        Cm.draw_p0 = orig
+        LlamaAttention_GEAR.fast_decode = True
+        LlamaModel_GEAR.fused_decode_glue = True
+    (la, pa), (lb, pb) = runs[False], runs[True]
+    assert isinstance(pb[0], GearHookCache) and isinstance(pa[0], tuple)
+    cos = torch.nn.functional.cosine_similarity(la, lb, dim=-1)
+    assert float(cos.min()) > 0.999, float(cos.min())
+    assert rel_fro(host(lb), host(la)) < 1e-2
+    for l in range(2):
+        assert len(pb[l]) == 17 and pb[l][8] == pa[l][8] == prompt + 90
+        for slot in (0, 1, 2, 3, 4, 5, 6, 7):
+            assert (pa[l][slot] is None) == (pb[l][slot] is None), (l, slot)
+            if pa[l][slot] is not None:
+                assert tuple(pa[l][slot].shape) == tuple(pb[l][slot].shape), (l, slot)
+        for slot in (9, 10, 13, 14):
+            assert len(pa[l][slot]) == len(pb[l][slot])
+            for x, y in zip(pa[l][slot], pb[l][slot]):
+                assert (x is None) == (y is None) and (x is None or tuple(x.shape) == tuple(y.shape)), (l, slot)
+    # layer 0, prompt segment: the same inputs on both paths -> the same payload bits (the decode tokens' K / V come out of the
+    # fused RMSNorm + GEMV + RoPE launch, whose fp32 accumulation differs from the eager chain in the last fp16 bit)
+    nq = prompt - prompt % 64
+    fpi = 32 // bits
+    for slot, axis, div in ((0, 3, fpi), (2, 3, 64), (3, 3, 64), (4, 2, 1), (6, 2, 1), (7, 2, 1)):
+        if pa[0][slot] is not None and nq:
+            a = host(pa[0][slot].narrow(axis, 0, nq // div))
+            b = host(pb[0][slot].narrow(axis, 0, nq // div))
+            assert np.array_equal(a.view(np.uint16) if a.dtype == np.float16 else a, b.view(np.uint16) if b.dtype == np.float16 else b), slot
+    # ... and the decode blocks' codes agree except where that last bit moved an element across a rounding boundary
+    if pa[0][4] is not None and pa[0][4].shape[2] > nq:
+        a, b = host(pa[0][4][:, :, nq:]), host(pb[0][4][:, :, nq:])
+        assert (a != b).mean() < 0.05
+
+
+def test_hook_cache_materialize_and_tuple_fallback():
+    """A GearHookCache handed to a decode step that the fast path cannot take (here: an attention mask) is materialised into the
+    plain 17-slot tuple and the tuple path continues from it: same output as a run that was on the tuple path all along."""
+    from gear_amd.modeling_llamagear import GearHookCache, LlamaAttention_GEAR
+    cc = dict(compress_method="KIVI", group_size=64, residual=64, quantize_bit=2, rank=0, rankv=0, loop=3)
+    model = _tiny_model(cc, layers=1)
+    attn = model.model.layers[0].self_attn
+    torch.manual_seed(2)
+    x = (torch.randn(1, 100, 512) * 0.5).half().cuda()
+    xt = (torch.randn(1, 1, 512) * 0.5).half().cuda()
+    mask = torch.full((100, 100), torch.finfo(torch.float16).min, dtype=torch.float16, device="cuda").triu(1)[None, None]
+    outs = {}
+    try:
+        for fast in (True, False):
+            LlamaAttention_GEAR.fast_decode = fast
+            with torch.no_grad():
+                _, _, cache = attn(x, attention_mask=mask, use_cache=True)
+                assert isinstance(cache, GearHookCache) == fast
+                zero = torch.zeros((1, 1, 1, 101), dtype=torch.float16, device="cuda")
+                o, _, cache2 = attn(xt, attention_mask=zero, past_key_value=cache, use_cache=True)
+            assert isinstance(cache2, tuple) and cache2[8] == 101
+            outs[fast] = host(o)
+    finally:
+        LlamaAttention_GEAR.fast_decode = True
+    assert np.array_equal(outs[True].view(np.uint16), outs[False].view(np.uint16))
 
 
 def test_generate_runs_and_is_deterministic():

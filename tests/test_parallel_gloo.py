@@ -71,3 +71,67 @@ def test_sharded_attention_matches_unsharded_world2():
         assert err < 1e-4, err
         assert ok_gather
         assert tmax == 2.0
+
+
+def _sel_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)                                   # the same full tensor on every rank
+        NB, Ht, T, D, k = 2, 4, 24, 128, 5
+        v = torch.randn(NB, Ht, T, D).half()
+        v[0, :, 3, :10] = 0.5                                  # ties across the two ranks' heads
+        v[1, 1, 2, 7] = -0.0
+        v[0, 0, 0, :] = 1.0
+        v[1, :, 5, :] = 0.25                                   # a constant row: every element ties
+        Hl = Ht // world
+        mine = v[:, rank * Hl:(rank + 1) * Hl].contiguous()
+        filled, mask, oidx, oval = parallel.exact_v_selection(mine, k, rank, world)
+        # brute force on the full rows: k smallest / k largest by (order key, lower column first), fill = fp16(float(exact mean))
+        rows = v.permute(0, 2, 1, 3).reshape(NB * T, Ht * D)
+        key = parallel._order_key(rows.view(torch.int16).to(torch.int64) & 0xFFFF)
+        col = torch.arange(Ht * D)
+        want = torch.zeros_like(rows, dtype=torch.bool)
+        want_side = [torch.zeros_like(want), torch.zeros_like(want)]           # [small, large]
+        for r in range(rows.shape[0]):
+            comp_l = key[r] * 65536 + (65535 - col)
+            comp_s = (65535 - key[r]) * 65536 + (65535 - col)
+            want_side[1][r, torch.topk(comp_l, k).indices] = True
+            want_side[0][r, torch.topk(comp_s, k).indices] = True
+        want = want_side[0] | want_side[1]
+        lo = rank * Hl * D
+        got_rows = mask.permute(0, 2, 1, 3).reshape(NB * T, Hl * D)
+        ok_mask = bool(torch.equal(got_rows, want[:, lo:lo + Hl * D]))
+        fill = (rows.double().sum(1) / rows.shape[1]).float().half()
+        f_rows = filled.permute(0, 2, 1, 3).reshape(NB * T, Hl * D)
+        ok_fill = bool(torch.equal(f_rows[got_rows], fill[:, None].expand_as(f_rows)[got_rows]))
+        ok_keep = bool(torch.equal(f_rows[~got_rows], rows[:, lo:lo + Hl * D][~got_rows]))
+        # lists: small side then large side, each ascending, unused slots 0xFFFF / value bits 0
+        idx = (oidx.view(NB * T, 2 * k).to(torch.int64) & 0xFFFF)
+        ok_lists = True
+        for r in range(rows.shape[0]):
+            for side in (0, 1):
+                ent = idx[r, side * k:(side + 1) * k]
+                used = ent[ent != 0xFFFF]
+                ok_lists &= bool((ent[len(used):] == 0xFFFF).all())
+                ok_lists &= bool(torch.equal(used, torch.nonzero(want_side[side][r, lo:lo + Hl * D]).flatten()))   # ascending
+                vals = oval.view(NB * T, 2 * k)[r, side * k:side * k + len(used)]
+                ok_lists &= bool(torch.equal(vals.view(torch.int16), rows[r, lo + used].view(torch.int16)))
+        ret[rank] = (ok_mask, ok_fill, ok_keep, ok_lists, int((idx != 0xFFFF).sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exact_cross_shard_v_selection_world2():
+    """SURVEY 8(e)'s candidate exchange (parallel.exact_v_selection): every rank ends up with exactly the elements of ITS heads that
+    the reference's whole-row top-k / bottom-k picks (compress_function.py:304-311), ties by lower global column, the global fp16
+    fill value, and sentinel-padded sorted lists; the ranks' list entries add up to 2 k per row."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sel_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert all(ret[r][:4]), (r, ret[r])
+    assert ret[0][4] + ret[1][4] == 2 * 24 * 2 * 5

@@ -1,6 +1,6 @@
 """Low-rank step on a bench-size token-major error tensor (GPU box): Gram kernel flavours (option gram_fused: 1 = one kernel per
 head with the solve inside, rounds 1-3; 2 = slab kernel with workgroup barriers + k_solve; 0 = wave-private slab kernel + k_solve)
-and, for the wave-private kernel, the elimination builds (gram_nstg 6 = no matrix-core work, 7 = loads only, 8 = no cross-wave
+and, for the wave-private kernel, the elimination builds (gram_nstg 5 = start positions rotated per head, 6 = no matrix-core work, 7 = loads only, 8 = no cross-wave
 sum / output)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
