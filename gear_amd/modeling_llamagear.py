@@ -358,7 +358,7 @@ class LlamaAttention_GEAR(nn.Module):
         return (self.fast_decode and self.head_dim == 128 and R in (64, 128) and cc["group_size"] in (32, 64)
                 and R % cc["group_size"] == 0 and cc["quantize_bit"] in (2, 4)
                 and T != R                  # (the reference strands V in fp16 for a prompt of exactly `residual` tokens, :416)
-                and T < 16384 and not (cc.get("left") or cc.get("sparsity")))
+                and T < 16384)
 
     def _store_block(self, c, k_src, v_src, T: int):
         """Compress T tokens (K [B,H,T,128], V alike) with the hook's own operators -- the reference's order of operations and of
@@ -386,7 +386,10 @@ class LlamaAttention_GEAR(nn.Module):
         B, T = key_states.shape[0], key_states.shape[-2]
         R = self.residual_length
         cap = max(int(getattr(self.config, "max_position_embeddings", 4096)), T + R)
-        c = GearKVCache(B, self.num_key_value_heads, min(cap, 16384), dict(cc), key_states.device, self.head_dim)
+        # (the hook stores no outliers -- slots 11, 12, 15, 16 are None in the reference's fused path -- so a sparsity in the config,
+        # the simulated path's `left`, does not reach the cache)
+        c = GearKVCache(B, self.num_key_value_heads, min(cap, 16384), dict(cc, left=0.0, sparsity=0.0), key_states.device,
+                        self.head_dim)
         nq = T - T % R
         if nq:
             c.seg0 = nq
