@@ -165,7 +165,7 @@ def block_boundary_cost(cfg, dev, Hl=None):
                 n = layers * H * 64 * D
                 alg = 2 * (2 * n) + 2 * (n * bits / 8 + 4 * n / group) + 2 * 2 * rnk * (64 + D) * layers * H \
                     + layers * H * D * 2 * d["kk_blk"] * 4 + layers * 64 * 2 * d["kv"] * 4
-                out["one_launch"] = bool(H >= gc.BLOCK_KERNEL_MIN_HEADS or not d["kv"])
+                out["one_launch"] = bool(H >= gc.BLOCK_KERNEL_MIN_HEADS or H == 1 or not d["kv"])
                 out["alg_bytes"] = alg
                 out["outliers_per_side"] = {"k_block_row": d["kk_blk"], "v_row": d["kv"]}
             del pool, caches
@@ -176,7 +176,7 @@ def block_boundary_cost(cfg, dev, Hl=None):
     out["frac"] = out["achieved_GBps"] / HBM_PEAK_GBS
     out["shape"] = f"{layers} layers x {H} KV heads x 64 tokens x {D}, K and V, at context {t_at}"
     out["kernel"] = "block_compress_kernel (one launch: V row selection + K / V tiles + low-rank step)" if out["one_launch"] else \
-        "kernel chain (fewer than 4 KV heads per rank: the row duties would serialize)"
+        "kernel chain (2 - 3 KV heads per rank: the row duties would serialize; one head or four and more take the block kernel)"
     out["amortized_us_per_token"] = out["block_kernel_us"] / 64
     return out
 
@@ -538,9 +538,9 @@ def main():
         kx["achieved"] = kx["alg_bytes"] / (kx["ms"] * 1e-3) / 1e9 if kx["ms"] else None
         kx["frac"] = kx["achieved"] / HBM_PEAK_GBS if kx["ms"] else None
     dom = max(kernels[:3], key=lambda kx: kx["ms"])
-    # HBM bytes from PMC counters: only from a profile taken on exactly this library (profiles/r3_traffic.json)
+    # HBM bytes from PMC counters: only from a profile taken on exactly this library (profiles/r4_traffic.json)
     traffic, tnote = None, "no profile for this library build"
-    tp = os.path.join(ROOT, "profiles", "r3_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r4_traffic.json")
     if os.path.exists(tp) and world == 1 and not args.layers and not args.emulate_world:
         prof = json.load(open(tp))
         if prof.get("lib_sha256") == lib_sha256() and prof.get("config") == args.config:
@@ -549,32 +549,32 @@ def main():
                    if kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")]
             # (both instantiations of the wave-per-row kernel -- fast and fallback pass -- share the base name and are added up)
             if hit:
-                traffic, tnote = float(sum(hit)), f"profiles/r3_traffic.json ({prof.get('how', '')})"
+                traffic, tnote = float(sum(hit)), f"profiles/r4_traffic.json ({prof.get('how', '')})"
         else:
-            tnote = "profiles/r3_traffic.json was measured on a different library build / config"
+            tnote = "profiles/r4_traffic.json was measured on a different library build / config"
     dominant = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac"], "traffic": traffic, "traffic_source": tnote, "alg_bytes_per_launch": dom["alg_bytes"],
                 "ms_per_launch": dom["ms"],
                 "note": "timed alone, back to back on one stream; inside the bench step the K and V chains share the chip on two "
-                        "streams and the same kernel takes longer (profiles/r3_kernel_stats_bench.md vs r3_kernel_stats_isolated.md)"}
+                        "streams and the same kernel takes longer (profiles/r4_kernel_stats_bench.md vs r4_kernel_stats_isolated.md)"}
     # the headline roofline object is what north_star names -- the fused K / V quant + low-rank + outlier COMPRESS, i.e. the chain
     # of launches per tensor kind -- not its fastest member: the chain with the lower fraction
     cname = min(("k_compress", "v_compress"), key=lambda c: chain[c]["frac"])
     # PMC traffic of the chain = the sum over its launches (same library-tied profile as above)
     chain_traffic = None
     members = {"k_compress": ("k_select_kernel", "k_select_fix_kernel", "k_main_kernel", "k_solve_kernel", "k_qpass_kernel"),
-               "v_compress": ("compress_rows_wave_kernel", "compress_rows_fp32_kernel", "lr_gram_solve_kernel<8, true>",
-                              "lr_gram_solve_kernel<4, true>", "lr_gram_solve_kernel<16, true>", "lr_qpass_tm_mfma_kernel")}
+               "v_compress": ("compress_rows_wave_kernel", "compress_rows_fp32_kernel", "lr_gram_wave_kernel", "k_solve_kernel",
+                              "lr_qpass_tm_mfma_kernel")}
     if traffic is not None:
         hit = [tb for kname, tb in prof.get("kernels", {}).items()
                if any(kname == mname or kname.startswith(mname + "<") or kname.startswith(mname) and "<" in mname for mname in members[cname])]
         if hit:
             chain_traffic = float(sum(hit))
     launches = {"k_compress": "k_select_kernel + k_select_fix_kernel + k_main_kernel + k_solve_kernel + k_qpass_kernel",
-                "v_compress": "compress_rows_wave_kernel (fast + fallback pass) + lr_gram_solve_kernel + lr_qpass_tm_mfma_kernel"}
+                "v_compress": "compress_rows_wave_kernel (fast + fallback pass) + lr_gram_wave_kernel + k_solve_kernel + lr_qpass_tm_mfma_kernel"}
     roofline = {"bound": "hbm", "kernel": f"{cname} chain: {launches[cname]}", "achieved": chain[cname]["achieved"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chain[cname]["frac"], "traffic": chain_traffic,
-                "traffic_source": tnote + " (sum over the chain's kernels; per kernel: profiles/r3_pmc_traffic.md)",
+                "traffic_source": tnote + " (sum over the chain's kernels; per kernel: profiles/r4_pmc_traffic.md)",
                 "alg_bytes_per_launch": chain[cname]["alg_bytes"],
                 "ms_per_launch": chain[cname]["ms"], "launch": "one chain = one call of gear_compress_%s_fused over all layers" % ("key" if cname == "k_compress" else "value"),
                 "bytes_definition": "SURVEY.md 8(d): read 2n + codes n*b/8 + scale/mn 8n/g + factors + outliers; no error term",

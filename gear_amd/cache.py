@@ -133,8 +133,9 @@ def _view(bufs, d, NB, H, D, kk0, seg0, kwin=True):
 
 
 USE_BLOCK_KERNEL = True      # tests switch it off to compare the single-launch block compressor with the chain
-# With V outliers every K tile's wave first selects 64 / H token rows (one after the other): at 1 - 3 KV heads per rank (70B head
-# shards) that serial part outweighs the saved launches (measured, 80 layers x 1 head: 367 us against the chain's 222).
+# With V outliers every K tile's wave first selects 64 / (2 H) token rows (one after the other): at 2 - 3 KV heads per rank that
+# serial part outweighs the saved launches (measured in round 3 at 80 layers x 1 head: 367 us against the chain's 222).  ONE KV head
+# per rank (70B on 8 GPUs) needs no hand-off at all -- the row is the tile's own -- and takes the block kernel (round 4).
 BLOCK_KERNEL_MIN_HEADS = 4
 _BLOCK_WS = {}
 
@@ -218,7 +219,7 @@ def _compress_into(bufs, d, lead, B, H, D, k_src, v_src, T, t_off, seg, kk, o_of
         P0v = _draw_p0((NB, H, D, d["rv"]), gen, dev, tp)
     v_exact = tp is not None and tp["world"] > 1 and tp.get("exact", True) and d["kv"] > 0
     if (USE_BLOCK_KERNEL and not v_exact and T == d["R"] == 64 and k_src is bufs.get("kwin") and v_src is bufs.get("vwin") and H <= 64
-            and kk <= 16 and (d["kv"] <= 255 or "vochunk" not in bufs) and (H >= BLOCK_KERNEL_MIN_HEADS or not d["kv"])):
+            and kk <= 16 and (d["kv"] <= 255 or "vochunk" not in bufs) and (H >= BLOCK_KERNEL_MIN_HEADS or H == 1 or not d["kv"])):
         # the decode-time block boundary: ONE launch over all (layer, head, K | V) tiles (csrc/block_fused.hip) instead of the
         # chain below (select, fused quantize + Gram, solve, Q pass; row compressor, Gram + solve, Q pass; chunk index; 2 tile
         # builders).  Same payload bits; the factors come from the token-side iteration (same subspace).

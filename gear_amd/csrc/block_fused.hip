@@ -646,7 +646,69 @@ __global__ __launch_bounds__(64) void block_compress_kernel(BlkArgs a) {
         for (int j = 0; j < 16; j++) trow[j] = ((const uint4*)xrow)[j];
         uint64_t mE = 0, mO = 0;                  // outlier bits of the even / odd channels (bit w = channel 2w / 2w + 1)
         float fill = 0.f;
-        if (a.kv > 0) {
+        if (a.kv > 0 && a.H == 1) {
+            // ONE KV head per rank (70B head shards): the token row IS this lane's 128 channels, so the tile selects for itself --
+            // no row duties, no flags, no waiting (with H < 4 the 64 / (2 H) serial row duties per workgroup cost more than the
+            // launches they saved: 367 us against the chain's 222 at 80 layers x 1 head).  Exact fp64 row mean; top / bottom-kv
+            // by repeated scans, ties: lower channel first; sorted lists, the chunk-index bytes, masks and fill as vrow_select.
+            double s = 0.0;
+#pragma unroll 1
+            for (int j = 0; j < 16; j++) {
+                float f[8];
+                unpack8(trow[j], f);
+#pragma unroll
+                for (int e = 0; e < 8; e++) s += (double)f[e];
+            }
+            fill = hround((float)(s / (double)KD));
+            const int kv = a.kv;
+            uint64_t selE[2] = {0ull, 0ull}, selO[2] = {0ull, 0ull};      // [0] = large side, [1] = small side
+#pragma unroll 1
+            for (int side = 0; side < 2; side++) {
+                const float sgn = side == 0 ? 1.0f : -1.0f;
+#pragma unroll 1
+                for (int rnd = 0; rnd < kv; rnd++) {
+                    float best = 0.f;
+                    int bi = KD;
+#pragma unroll 1
+                    for (int j = 0; j < 16; j++) {
+                        float f[8];
+                        unpack8(trow[j], f);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const int d = 8 * j + e;
+                            const bool taken = (((d & 1) ? selO[side] : selE[side]) >> (d >> 1)) & 1ull;
+                            const float v = sgn * f[e];
+                            const bool t = !taken && (bi == KD || v > best);      // strict: the first (lowest) channel wins a tie
+                            best = t ? v : best;
+                            bi = t ? d : bi;
+                        }
+                    }
+                    if (bi & 1) selO[side] |= 1ull << (bi >> 1); else selE[side] |= 1ull << (bi >> 1);
+                }
+            }
+            mE = selE[0] | selE[1];
+            mO = selO[0] | selO[1];
+            const int64_t lrow = (int64_t)nb * a.tcap + tok0 + lane;
+            uint16_t* oi = a.voidx + lrow * (2 * kv);
+            uint16_t* ov = a.voval + lrow * (2 * kv);
+#pragma unroll 1
+            for (int side = 0; side < 2; side++) {                        // list slot 0 = the small side, then the large side
+                uint64_t e = selE[1 - side], o = selO[1 - side];
+                int pos = side * kv;
+                while (e | o) {
+                    const int we = e ? __builtin_ctzll(e) : 64, wo = o ? __builtin_ctzll(o) : 64;
+                    int d;
+                    if (we <= wo) { d = 2 * we; e &= e - 1ull; } else { d = 2 * wo + 1; o &= o - 1ull; }
+                    oi[pos] = (uint16_t)d;
+                    ov[pos] = tile[lane * BT_PITCH + d];
+                    pos++;
+                }
+            }
+            if (a.vochunk) {                                              // head bounds of a one-head row: [0, kv] per side
+                uint8_t* vc = a.vochunk + lrow * 4;
+                vc[0] = 0; vc[1] = (uint8_t)kv; vc[2] = 0; vc[3] = (uint8_t)kv;
+            }
+        } else if (a.kv > 0) {
             gu32* fp = (gu32*)(a.flags + nb * 64 + lane);
             unsigned spins = 0;
             while (true) {
@@ -810,6 +872,7 @@ extern "C" int gear_compress_block(const gear_cache_view* c, int t_off, int o_of
     if (ep == 0u) ep = __atomic_add_fetch(&g_block_epoch, 1u, __ATOMIC_RELAXED);
     a.epoch = ep;
     a.rows_per_blk = (int)((NB * 64 + 2 * NB * H - 1) / (2 * NB * H));     // every workgroup (K and V tiles) takes its share
+    if (H == 1) a.rows_per_blk = 0;                                        // (one head: a V tile selects for itself, no row duties)
     const int rmax = a.rk > a.rv ? a.rk : a.rv;
     const int RP = rmax <= 4 ? 4 : (rmax <= 8 ? 8 : 16);
     const size_t shmem = (size_t)64 * BT_PITCH * 2 + (rmax > 0 ? blk_lr_lds_bytes(RP) : 0);
