@@ -1,4 +1,4 @@
-// rows_multi.hip -- the row compressor for SHORT rows: eight rows per wave, eight lanes per row.
+// rows_multi.hip -- the row compressor for SHORT rows: eight (or four) rows per wave, eight (or sixteen) lanes per row.
 //
 // Same function as compress_rows.hip (gears_tokenQ / gears_channelQ of GenerationBench/.../Simulated/compress_function.py:261-333
 // + group quantization + bit-pack + error, identical outputs), for the rows a head shard produces: with the KV heads split over
@@ -11,19 +11,23 @@
 // side -- a lane-local max over its elements and a 3-step DPP max over the 8 lanes per round; for the small k of a shard
 // (k = round(full-row k / N): 1 .. 5) that is a few hundred instructions per wave, shared by 8 rows.  Lists come out sorted by
 // index through a chunk-major prefix count over the row group.  Dispatch: gear_compress_rows_geom (compress_rows.hip).
+// Round 4: LPR = 16 lanes per row (four rows per wave) for rows of 256 / 512 / 768 elements -- the 512-element rows of Llama-2-7B on
+// 8 GPUs with TWO chunks per lane instead of four (187 registers -> two waves per SIMD was this kernel's limit): 176 -> ~150 us.
 #include "common.h"
 #include "rowgeom.h"
 
 namespace {
 
-__device__ __forceinline__ uint32_t grp8_max_u32(uint32_t v) {
+template <int LPR>
+__device__ __forceinline__ uint32_t grp_max_u32(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm: xor 1
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm: xor 2
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror: the other quad
+    if (LPR == 16) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror: the other 8 lanes
     return v;
 }
 
-template <int BITS, int MODE, typename ST, int NCH>
+template <int BITS, int MODE, typename ST, int NCH, int LPR>
 __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t* __restrict__ x, RowGeom gm, int64_t n_rows, int len,
                                                                   int group, int k, uint32_t* __restrict__ code,
                                                                   ST* __restrict__ scale, ST* __restrict__ mn,
@@ -35,8 +39,9 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
     __shared__ uint32_t rawlds[256 * 8 * NCH];   // a lane's raw words, for the (rare) list emission with a run-time element index
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = lane & 7, rg = lane >> 3;
-    int64_t r = ((int64_t)blockIdx.x * 4 + wave) * 8 + rg;
+    constexpr int RPW = 64 / LPR;       // rows per wave
+    const int l = lane & (LPR - 1), rg = lane / LPR;
+    int64_t r = ((int64_t)blockIdx.x * 4 + wave) * RPW + rg;
     const bool valid = r < n_rows;     // a row group past the end works on the last row and stores nothing
     if (!valid) r = n_rows - 1;
     const int64_t row_base = row_base_of(gm, r), orow_base = row_base_out(gm, r);
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
     uint32_t raw[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        j0[c] = (c * 8 + l) * 16;
+        j0[c] = (c * LPR + l) * 16;
         int seg, pos;
         seg_pos(gm, j0[c], seg, pos);
         off[c] = row_base + (int64_t)seg * gm.seg_stride + pos;
@@ -77,6 +82,7 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 4, 64);
+        if (LPR == 16) s += __shfl_xor(s, 8, 64);
         const float mean = (float)(s / (double)len);
         fill = (MODE == 0) ? hround(mean) : mean;
         if (valid && l == 0 && omean) omean[r] = mean;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
 #pragma unroll
                     for (int j = 0; j < 16; j++) m = max(m, comp[c][j] - prev);
                 }
-                prev += grp8_max_u32(m);
+                prev += grp_max_u32<LPR>(m);
             }
             // selected on this side: composite >= the last winner
 #pragma unroll
@@ -130,11 +136,11 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
                 const uint32_t cnt = (uint32_t)__popc(fl_lo[c]) | ((uint32_t)__popc(fl_hi[c]) << 16);
                 uint32_t inc = cnt;
 #pragma unroll
-                for (int d = 1; d < 8; d <<= 1) {
-                    const uint32_t t = __shfl_up(inc, d, 8);
+                for (int d = 1; d < LPR; d <<= 1) {
+                    const uint32_t t = __shfl_up(inc, d, LPR);
                     if (l >= d) inc += t;
                 }
-                const uint32_t tot = __shfl(inc, 7, 8);
+                const uint32_t tot = __shfl(inc, LPR - 1, LPR);
                 const uint32_t base = running + inc - cnt;
                 running += tot;
                 if (valid) {
@@ -210,25 +216,34 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
 
 }  // namespace
 
-// rows this kernel takes: 128 .. 512 elements in whole 128-element steps (8 lanes x NCH chunks of 16), groups of 16 .. 128, few outliers
+// rows this kernel takes: 128 .. 512 elements in whole 128-element steps (8 lanes x NCH chunks of 16) or 256 / 512 / 768 (16 lanes x
+// NCH <= 3 chunks), groups of 16 .. 128, few outliers
+// (1280-element rows -- 13B on 4 GPUs, five chunks per lane -- measured SLOWER here than the one-row-per-workgroup kernel: 0.72 against
+// 0.61 ms for config 4's V shard; they stay there)
+static bool rows_multi_lpr16(int64_t len) { return len % 256 == 0 && len >= 256 && len <= 768; }
 bool gear_rows_multi_supported(int64_t len, int group, int k) {
-    return len >= 128 && len <= 512 && len % 128 == 0 && group >= 16 && group <= 128 && k >= 0 && k <= 16;
+    const bool shape = (len >= 128 && len <= 512 && len % 128 == 0) || rows_multi_lpr16(len);
+    return shape && group >= 16 && group <= 128 && k >= 0 && k <= 16;
 }
 
 int gear_rows_multi_launch(const void* x, const void* gmv, int64_t n_rows, int64_t len, int group, int bits, int mode, int k,
                            void* code, void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, hipStream_t st) {
     const RowGeom gm = *(const RowGeom*)gmv;
-    const int nch = (int)(len / 128);
-    const dim3 grid((unsigned)((n_rows + 31) / 32)), block(256);
-#define GOM(B, M, STT, N)                                                                                                       \
-    hipLaunchKernelGGL((compress_rows_multi_kernel<B, M, STT, N>), grid, block, 0, st, (const uint16_t*)x, gm, n_rows, (int)len, group, k, \
+    const bool l16 = rows_multi_lpr16(len);
+    const int nch = (int)(len / (l16 ? 256 : 128));
+    const int rows_per_block = l16 ? 16 : 32;
+    const dim3 grid((unsigned)((n_rows + rows_per_block - 1) / rows_per_block)), block(256);
+#define GOM(B, M, STT, N, LP)                                                                                                   \
+    hipLaunchKernelGGL((compress_rows_multi_kernel<B, M, STT, N, LP>), grid, block, 0, st, (const uint16_t*)x, gm, n_rows, (int)len, group, k, \
                        (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval, (float*)omean)
 #define GOMN(B, M, STT)                                      \
     do {                                                     \
-        if (nch == 1) GOM(B, M, STT, 1);                     \
-        else if (nch == 2) GOM(B, M, STT, 2);                \
-        else if (nch == 3) GOM(B, M, STT, 3);                \
-        else GOM(B, M, STT, 4);                              \
+        if (l16) {                                           \
+            if (nch == 1) GOM(B, M, STT, 1, 16);             \
+            else if (nch == 2) GOM(B, M, STT, 2, 16);        \
+            else GOM(B, M, STT, 3, 16);                      \
+        } else if (nch == 1) GOM(B, M, STT, 1, 8);           \
+        else GOM(B, M, STT, 3, 8);                           \
     } while (0)
     if (mode == 0) {
         if (bits == 2) GOMN(2, 0, uint16_t); else if (bits == 4) GOMN(4, 0, uint16_t); else GOMN(8, 0, uint16_t);
