@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json", "r3_bench_line.json"])
+@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json", "r3_bench_line.json", "r4_bench_line.json"])
 def test_committed_bench_line_has_the_contract_fields(line):
     d = json.load(open(os.path.join(ROOT, "profiles", line)))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
@@ -29,8 +29,8 @@ def test_committed_bench_line_has_the_contract_fields(line):
     # value = fp16 KV bytes through compress + decompress per second, whole job
     n = 32 * 32 * 4096 * 128
     assert abs(d["value"] - 2 * (2 * n * 2) / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
-    if line.startswith("r3"):
-        # round 3: the headline roofline object is the compress CHAIN north_star names (the lower of K / V), with the PMC traffic of
+    if line.startswith(("r3", "r4")):
+        # round 3 on: the headline roofline object is the compress CHAIN north_star names (the lower of K / V), with the PMC traffic of
         # its launches; the dominant single kernel rides along; the decode-time block boundary is measured and reported
         assert r["kernel"].startswith(("k_compress chain", "v_compress chain")) and "dominant_kernel" in r
         lo = min(d["roofline_chain"][c]["frac"] for c in ("k_compress", "v_compress"))
@@ -43,6 +43,12 @@ def test_committed_bench_line_has_the_contract_fields(line):
         assert bb["traffic"] is None or bb["traffic"] >= 0.9 * bb["alg_bytes"]
         assert abs(d["decode"]["block_compress_ms"] - bb["block_kernel_us"] * 1e-3) < 1e-9
         assert "numpy_glue" in c and c["value"] > c["numpy_glue"]["value"]
+    if line.startswith("r4"):
+        # round 4: the V chain is rows -> wave-private Gram kernel -> per-head solve -> Q pass; the PMC traffic of the chain is tied to
+        # the library that produced the line; the hook module (the documented import swap) runs on its fast path
+        assert r["traffic"] is not None and r["traffic"] >= r["alg_bytes_per_launch"]
+        assert d["decode"]["hook_module_tokens_per_s"] >= 200.0
+        assert d["decode"]["tokens_per_s"] >= d["decode"]["hook_module_tokens_per_s"] * 0.9
     if line.startswith("r2"):
         # round 2: per-kernel and per-chain rooflines on SURVEY 8(d) bytes (no error term), traffic tied to the library build
         assert "no error term" in r["bytes_definition"] and "traffic_source" in r
@@ -57,7 +63,7 @@ def test_committed_bench_line_has_the_contract_fields(line):
         assert d["decode"]["outliers_per_side"]["v_row"] == 40 and "2% outliers" in d["decode"]["method"]
 
 
-@pytest.mark.parametrize("name", ["r2_traffic.json", "r3_traffic.json"])
+@pytest.mark.parametrize("name", ["r2_traffic.json", "r3_traffic.json", "r4_traffic.json"])
 def test_traffic_profile_names_the_library_it_was_measured_on(name):
     t = json.load(open(os.path.join(ROOT, "profiles", name)))
     assert len(t["lib_sha256"]) == 64 and t["config"] == "c3" and t["kernels"] and "FETCH_SIZE" in t["how"]
@@ -69,3 +75,33 @@ def test_bench_parses_and_defaults_to_one_gpu():
     src = open(os.path.join(ROOT, "bench.py")).read()
     ast.parse(src)
     assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
+
+
+def test_round4_config2_line_is_committed_with_its_roofline():
+    """BASELINE configs[1] (4-bit, rank 4, 1 % outliers, T = 2048): the 4-bit path has a measured line of its own."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_c2_line.json")))
+    assert "T=2048" in d["config"]["workload"] and "4-bit" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    n = 32 * 32 * 2048 * 128
+    assert abs(d["value"] - 2 * (2 * n * 2) / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    for name in ("k_compress", "v_compress", "k_decompress", "v_decompress"):
+        ch = d["roofline_chain"][name]
+        assert abs(ch["frac"] - ch["alg_bytes"] / (ch["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert d["cpu_baseline"]["value"] > 0 and d["decode"]["tokens_per_s"] > 0
+
+
+def test_sharded_line_reports_both_exchanges():
+    """world > 1: the decode leg runs once per exchange -- the peer-store kernel (the build's default) and the all-gather collective
+    north_star names -- and prints tokens/s for each (profiles/r4_bench_2rank_one_gpu.json: two ranks sharing ONE GPU over gloo, the
+    control flow of `bench.py --gpus 2 --exchange both`; not a multi-GPU measurement)."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_2rank_one_gpu.json")))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    modes = d["decode"]["exchange_modes"]
+    assert set(modes) == {"peer", "collective"} and d["decode"]["exchange_default"] == "peer"
+    for m in ("peer", "collective"):
+        assert modes[m]["tokens_per_s"] > 0 and modes[m]["eager_tokens_per_s"] > 0 and modes[m]["exchange"]
+    assert modes["peer"]["exchange_class"] == "PeerHeadGather" and modes["collective"]["exchange_class"] == "HeadGather"
+    assert abs(d["decode"]["tokens_per_s"] - modes["peer"]["tokens_per_s"]) < 1e-6 * modes["peer"]["tokens_per_s"] + 30.0   # (MAX over ranks)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--exchange", default="both"' in src
