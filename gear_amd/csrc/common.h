@@ -43,6 +43,7 @@ struct GearOptions {
     int gram_fused;        // low-rank step: 1 = Gram matrix and solve in ONE kernel per head (round 1-3); 2 = slab kernels with
                            // workgroup barriers + solve; 0 = wave-private slab kernel + solve
     int gram_nstg;         // wave-private Gram kernel: steps of loads in flight per wave (2, 3 = default, 4)
+    int decomp_general;    // row decompressor: the general row loop also for full blocks (never the straight-line 16-row path)
 };
 GearOptions& gear_options();
 

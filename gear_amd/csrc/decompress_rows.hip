@@ -15,11 +15,23 @@
 // from entries prefetched one fill ahead; a lane reads its 32 bytes of the table row and selects half-words branch-free.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+
+
+// a block-uniform 64-bit offset, moved to scalar registers (kept an integer: a pointer rebuilt from integers loses its address
+// space and its loads become FLAT ones, which also count on lgkmcnt)
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 
 template <int N>
 __device__ __forceinline__ void load_halfs(const uint16_t* p, float* f) {
@@ -47,6 +59,8 @@ struct DGeom {
     int trows;   // rows covered by one fill of the LDS outlier table (divides rpb; the block refills it rpb / trows times)
     int rpar;    // short rows (len / 16 < 64 lanes): rpar rows side by side in the block's one wave, lane = (row slot, 16 columns)
     int64_t n_rows;
+    int og, ig, sg;   // outer / inner / segment stride in groups
+    int general;      // never the straight-line path for full blocks (option decomp_general: test coverage of the general loop)
 };
 
 // RV: compile-time rank (4 / 8 / 16) or 0 for the generic runtime-rank path.
@@ -60,7 +74,10 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     constexpr int RVS = RV > 0 ? RV : 1;
-    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];   // [trows][len] fp16 outlier values (0xFFFF = none)
+    // straight-line path: rows whose inputs are in flight ahead of the row being computed (measured at config 3: two rows ahead
+    // 0.368 against 0.384 ms for K^T, 0.441 against 0.421 ms for V)
+    constexpr int PFD = (KIND == 1 && TB < 1024) ? 2 : 1;      // (1024 threads: 128 registers per lane, no room for a third row)
+    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];   // [trows][len] ~(fp16 outlier value) (0 = none)
     const int tid = threadIdx.x;
     // short rows: the wave holds rpar rows at a time, lane = (row slot sub, 16-column chunk lc); otherwise one row, lane = chunk
     const int lpr = g.len >> 4;
@@ -69,7 +86,8 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const bool active = j0 < g.len;
     const int64_t row0 = (int64_t)blockIdx.x * g.rpb;
     const int r = g.r;
-    // LDS outlier table: trows x len fp16, 0xFFFF (a NaN no payload value has) = "no outlier here"
+    // LDS outlier table: trows x len half-words holding the COMPLEMENT of the outlier's fp16 bits; 0 = "no outlier here" (the
+    // complement of 0xFFFF, a NaN no payload value has)
     uint16_t* lval = (uint16_t*)dsm;
     // the sparse part of `trows` rows of the block goes to LDS at a time: the dense pass then patches its own elements and
     // every global store stays a full 32-byte vector (scattered 2-byte stores cost a line read-modify-write each).  The
@@ -78,17 +96,17 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     // The entries of the next fill are loaded into registers one fill ahead (2 per thread cover 4 rows x 2k <= 512 entries
     // for 256 threads; more than that falls back to loading inside the fill), so a fill is LDS work only.
     constexpr int PF = 2;
-    uint16_t pf_idx[PF], pf_val[PF];
+    uint16_t pf_idx[PF], pf_val[PF];   // (kept exactly as loaded: any arithmetic on them here would wait for the loads on the spot)
     const int per_row_t = 2 * g.k, fill_n = g.trows * per_row_t;
     const bool pf_ok = fill_n <= PF * (int)blockDim.x;
-    // entry e = tid + q * blockDim of a fill is entry pf_c[q] of table row pf_r[q]: the same for every fill (one division here,
-    // none per fill)
-    int pf_r[PF], pf_c[PF];
+    // entry e = tid + q * blockDim of a fill is entry c of table row rr, the same for every fill (one division here, none per
+    // fill); kept as rr << 16 | c, rr = -1: nothing to do
+    int pf_rc[PF];
 #pragma unroll
     for (int q = 0; q < PF; q++) {
         const int e = tid + q * (int)blockDim.x;
-        pf_r[q] = (g.k > 0 && e < fill_n) ? e / per_row_t : -1;
-        pf_c[q] = (g.k > 0 && e < fill_n) ? e - pf_r[q] * per_row_t : 0;
+        const int rr = (g.k > 0 && e < fill_n) ? e / per_row_t : -1;
+        pf_rc[q] = (rr << 16) | (rr >= 0 ? e - rr * per_row_t : 0);
     }
     // Blocks walk their 16 rows in a rotated order (a multiple of the table period, by block index) so that blocks running in
     // near lockstep do not all write at the same offset of their 128 KB regions (HBM channel camping, tools/ubench/
@@ -98,36 +116,62 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     auto prefetch_entries = [&](int rbase) {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            const int64_t row = row0 + phys(rbase) + pf_r[q];
+            const int rr = pf_rc[q] >> 16, c = pf_rc[q] & 0xFFFF;
+            const int64_t row = row0 + phys(rbase) + rr;
             pf_idx[q] = 0; pf_val[q] = 0;
-            if (pf_r[q] >= 0 && row < g.n_rows && rbase < g.rpb) {
-                pf_idx[q] = oidx[row * per_row_t + pf_c[q]];
-                pf_val[q] = oval[row * per_row_t + pf_c[q]];
+            if (rr >= 0 && row < g.n_rows && rbase < g.rpb) {
+                pf_idx[q] = oidx[row * per_row_t + c];
+                pf_val[q] = oval[row * per_row_t + c];
             }
         }
     };
+    // (the same for a full block, every load issued by every lane -- a lane without an entry re-reads entry 0 of the fill's
+    // first row and drops it: loads under a per-lane condition make the compiler wait for ALL memory operations at the join)
+    auto prefetch_entries_all = [&](int rbase) {
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int rr = pf_rc[q] >> 16, c = pf_rc[q] & 0xFFFF;
+            const int64_t e = (row0 + phys(rbase) + (rr < 0 ? 0 : rr)) * per_row_t + c;
+            pf_idx[q] = oidx[e];
+            pf_val[q] = oval[e];
+        }
+    };
+    auto zero_table = [&]() {
+        for (int i = tid; i < g.trows * (g.len / 8); i += blockDim.x) ((uint4*)lval)[i] = make_uint4(0u, 0u, 0u, 0u);
+    };
     auto fill_table = [&](int rbase) {
-        for (int i = tid; i < g.trows * (g.len / 8); i += blockDim.x)
-            ((uint4*)lval)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        zero_table();
         __syncthreads();
         if (pf_ok) {
 #pragma unroll
-            for (int q = 0; q < PF; q++)
-                if (pf_r[q] >= 0 && row0 + phys(rbase) + pf_r[q] < g.n_rows) lval[(size_t)pf_r[q] * g.len + pf_idx[q]] = pf_val[q];
+            for (int q = 0; q < PF; q++) {
+                const int rr = pf_rc[q] >> 16;
+                if (rr >= 0 && row0 + phys(rbase) + rr < g.n_rows) lval[rr * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+            }
             prefetch_entries(rbase + g.trows);
         } else {
             for (int e = tid; e < fill_n; e += blockDim.x) {
                 const int ri = e / per_row_t;
                 const int64_t row = row0 + phys(rbase) + ri;
-                if (row < g.n_rows) lval[(size_t)ri * g.len + oidx[row * per_row_t + e % per_row_t]] = oval[row * per_row_t + e % per_row_t];
+                if (row < g.n_rows)
+                    lval[(size_t)ri * g.len + oidx[row * per_row_t + e % per_row_t]] = (uint16_t)~oval[row * per_row_t + e % per_row_t];
             }
         }
         __syncthreads();
     };
-    if (g.k > 0 && !g.patch && pf_ok) prefetch_entries(0);
     // all rows of the block share the outer index (rpb divides rows_inner)
     const int ro = (int)(row0 / g.rows_inner);
     const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
+    // (store exchange, see compute_row: this lane writes the 16-byte half `tid >> 5 & 1` of lane (tid & 31) of its wave in the
+    // first store and of lane 32 + (tid & 31) in the second; st_a / st_b = their offsets relative to this lane's own)
+    const bool wave_full = g.rpar == 1 && ((tid | 63) + 1) * 16 <= g.len;
+    int st_a = 0, st_b = 0;
+    if (wave_full) {
+        const int ja = ((tid & ~63) + (tid & 31)) * 16, jb = ja + 512, hf = 8 * ((tid >> 5) & 1);
+        const int own = seg * (int)g.seg_stride + pos;
+        st_a = (ja / g.seglen) * (int)g.seg_stride + ja % g.seglen + hf - own;
+        st_b = (jb / g.seglen) * (int)g.seg_stride + jb % g.seglen + hf - own;
+    }
 
     // ---- the 16 x r factor block of this lane's columns (row-independent)
     // kept as packed fp16 pairs: the row term is RV/2 v_dot2_f32_f16 per element (exact products, fp32 accumulate) and
@@ -158,24 +202,37 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     // Row ri of the block: all rows share the outer index and rpb divides rows_inner, so everything is the first row's
     // offset plus ri times a stride -- no integer division inside the row loop (a run-time 64-bit quotient is > 100 VALU
     // instructions, and the loop had three of them per row).
-    struct RowIn { uint32_t words[WPL]; float s, m; uint4 fv0, fv1; int64_t off; };
+    struct RowIn { uint32_t words[WPL]; float s, m; uint4 fv0, fv1; int off; };
+    // Addresses = a block-uniform 64-bit base (scalar registers: everything that depends on the block's first row only) + a
+    // 32-bit offset made of the lane's column part and ri times a stride (the host checks that a slab stays below 2^31
+    // elements): one multiply and a few adds per row and stream instead of 64-bit multiply-adds per lane.
     const int rin0 = (int)(row0 % g.rows_inner);
-    const int64_t off0 = (int64_t)ro * g.outer_stride + (int64_t)rin0 * g.inner_stride + (int64_t)seg * g.seg_stride + pos;
-    const int64_t gi0 = off0 / g.group;
-    const int gstep = (int)(g.inner_stride / g.group);          // (the host checks inner_stride % group == 0)
-    const uint16_t* fv0p = nullptr;
-    if (RV > 0 && r > 0)
-        fv0p = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin0) * r : P + ((int64_t)ro * g.D + rin0) * r;
+    const int64_t base_off = (int64_t)ro * g.outer_stride + (int64_t)rin0 * g.inner_stride;   // (a multiple of the group size)
+    uint16_t* outb = out + uni64(base_off);
+    const uint32_t* codeb = code + uni64(base_off / CPW);
+    const int64_t gbase = uni64((int64_t)ro * g.og + (int64_t)rin0 * g.ig);          // = base_off / group
+    const ST* scaleb = scale + gbase;
+    const ST* mnb = mn + gbase;
+    const int lane_off = seg * (int)g.seg_stride + pos;
+    const int lane_g = seg * g.sg + pos / g.group;
+    const int istride = (int)g.inner_stride;
+    const int gstep = g.ig;                                    // (the host checks inner_stride % group == 0)
+    const uint16_t* fvb = nullptr;
+    int fv_lane = 0;
+    if (RV > 0 && r > 0) {
+        fvb = (KIND == 0) ? Q + uni64(((int64_t)ro * g.nseg * g.T + rin0) * r) : P + uni64(((int64_t)ro * g.D + rin0) * r);
+        fv_lane = (KIND == 0) ? seg * g.T * r : 0;
+    }
     auto fetch = [&](int li, RowIn& in) {
         const int ri = phys(li);
-        in.off = off0 + (int64_t)ri * g.inner_stride;
-        const int64_t gi = gi0 + (int64_t)ri * gstep;
-        in.s = ld_st<ST>(scale + gi);
-        in.m = ld_st<ST>(mn + gi);
+        in.off = lane_off + ri * istride;
+        const int gi = lane_g + ri * gstep;
+        in.s = ld_st<ST>(scaleb + gi);
+        in.m = ld_st<ST>(mnb + gi);
 #pragma unroll
-        for (int w = 0; w < WPL; w++) in.words[w] = code[in.off / CPW + w];
+        for (int w = 0; w < WPL; w++) in.words[w] = codeb[in.off / CPW + w];
         if (RV > 0 && r > 0) {
-            const uint16_t* fvp = fv0p + (int64_t)ri * r;
+            const uint16_t* fvp = fvb + fv_lane + ri * r;
             if (RV == 4) { uint2 t = *(const uint2*)fvp; in.fv0 = make_uint4(t.x, t.y, 0, 0); }
             else in.fv0 = *(const uint4*)fvp;
             if (RV == 16) in.fv1 = ((const uint4*)fvp)[1];
@@ -190,38 +247,64 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             fill_table(ri);
         }
     };
-    auto compute_row = [&](int ri, const RowIn& cur) {
+    auto compute_row = [&](int ri, const RowIn& cur, const bool table) __attribute__((always_inline)) {
         float f[16];
+        uint4 d0, d1;
+        if constexpr (BITS == 2) {
+            // Two-bit codes: a group has four dequantized values.  Compute them once per row-lane (the lane's 16 columns lie
+            // in one group), keep them as two packed-fp16 registers and let v_perm_b32 pick the pair of every output word:
+            // 4 instructions per element pair (packed shift, mask, packed multiply-add to byte selectors, permute) where
+            // extract + convert + multiply + add + pack came to 11.
+            const uint32_t l01 = f2h2_bits(dequant_one<MODE>(0, cur.s, cur.m), dequant_one<MODE>(1, cur.s, cur.m));
+            const uint32_t l23 = f2h2_bits(dequant_one<MODE>(2, cur.s, cur.m), dequant_one<MODE>(3, cur.s, cur.m));
+            const uint32_t w = cur.words[0], w1 = w << 1, wh = w >> 31;
+            uint32_t dw[8];
 #pragma unroll
-        for (int w = 0; w < WPL; w++) {
+            for (int b = 0; b < 4; b++) {
+                // both halves = bits [8b - 1, 8b + 14] of the code word: byte b of it, doubled, with room for its top bit
+                const uint32_t y = __builtin_amdgcn_perm(wh, w1, (uint32_t)(b | ((b + 1) << 8) | (b << 16) | ((b + 1) << 24)));
 #pragma unroll
-            for (int j = 0; j < CPW; j++)
-                f[w * CPW + j] = dequant_one<MODE>((int)((cur.words[w] >> (BITS * j)) & MASK), cur.s, cur.m);
+                for (int h = 0; h < 2; h++) {
+                    const u16x2 sh = {(uint16_t)(4 * h), (uint16_t)(4 * h + 2)};
+                    u16x2 t = __builtin_bit_cast(u16x2, y) >> sh;            // {2 c_even, 2 c_odd} in bits 1..2 of the halves
+                    t = (t & (uint16_t)6) * (uint16_t)0x0101 + (uint16_t)0x0100;   // byte selectors {2c, 2c + 1} per half
+                    dw[2 * b + h] = __builtin_amdgcn_perm(l23, l01, __builtin_bit_cast(uint32_t, t));
+                }
+            }
+            d0 = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+            d1 = make_uint4(dw[4], dw[5], dw[6], dw[7]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < WPL; w++) {
+#pragma unroll
+                for (int j = 0; j < CPW; j++)
+                    f[w * CPW + j] = dequant_one<MODE>((int)((cur.words[w] >> (BITS * j)) & MASK), cur.s, cur.m);
+            }
+            // the dequantized values as packed fp16 (MODE 1: this is the reference's cast of the fp32 result; MODE 0: exact)
+            d0 = pack8(f);
+            d1 = pack8(f + 8);
         }
-        // the dequantized values as packed fp16 (MODE 1: this is the reference's cast of the fp32 result; MODE 0: exact)
-        uint4 d0 = pack8(f), d1 = pack8(f + 8);
         if (table) {
             // outlier elements: the stored value replaces the dequantized one (the low-rank term still adds).  Branch-free:
             // the lane's 32 bytes of the table row, half-words that are not the sentinel select the table value
-            // (per word: xor, min(x, 1), 0 - x, v_bfi -- the first version walked 16 branchy ds_read_u16 blocks)
+            // (per word: min(x, 1), 0 - x, one three-input bit operation -- the first version walked 16 branchy ds_read_u16 blocks)
             const int rt = ri & (g.trows - 1);
             const uint4 t0 = *(const uint4*)&lval[(size_t)rt * g.len + j0], t1 = *(const uint4*)&lval[(size_t)rt * g.len + j0 + 8];
-            auto sel = [](uint32_t tw, uint32_t dw) {
-                uint32_t x = ~tw, mk, rr;
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(mk) : "v"(x), "v"(0x00010001u));
+            auto sel = [](uint32_t tn, uint32_t dw) {
+                uint32_t mk;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(mk) : "v"(tn), "v"(0x00010001u));
                 asm("v_pk_sub_u16 %0, %1, %2" : "=v"(mk) : "v"(0u), "v"(mk));
-                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(rr) : "v"(mk), "v"(tw), "v"(dw));
+                uint32_t rr;                             // mk ? ~tn : dw  (truth table with S0 = 0xF0, S1 = 0xCC, S2 = 0xAA)
+                asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x3a" : "=v"(rr) : "v"(mk), "v"(tn), "v"(dw));
                 return rr;
             };
             d0 = make_uint4(sel(t0.x, d0.x), sel(t0.y, d0.y), sel(t0.z, d0.z), sel(t0.w, d0.w));
             d1 = make_uint4(sel(t1.x, d1.x), sel(t1.y, d1.y), sel(t1.z, d1.z), sel(t1.w, d1.w));
         }
         if (r > 0) {
-            unpack8(d0, f);
-            unpack8(d1, f + 8);
-        }
-        if (r > 0) {
             if (RV > 0) {
+                unpack8(d0, f);
+                unpack8(d1, f + 8);
                 const uint32_t fv[8] = {cur.fv0.x, cur.fv0.y, cur.fv0.z, cur.fv0.w, cur.fv1.x, cur.fv1.y, cur.fv1.z, cur.fv1.w};
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
@@ -231,7 +314,12 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                         acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, fv[c]), __builtin_bit_cast(half2_t, gb[j][c]), acc, false);
                     f[j] = acc;
                 }
+                // (v_cvt_pk_f16_f32: two results per conversion, round-to-nearest-even like the single one)
+                d0 = make_uint4(f2h2_bits(f[0], f[1]), f2h2_bits(f[2], f[3]), f2h2_bits(f[4], f[5]), f2h2_bits(f[6], f[7]));
+                d1 = make_uint4(f2h2_bits(f[8], f[9]), f2h2_bits(f[10], f[11]), f2h2_bits(f[12], f[13]), f2h2_bits(f[14], f[15]));
             } else {
+                unpack8(d0, f);
+                unpack8(d1, f + 8);
                 const int rin = rin0 + phys(ri);
                 const uint16_t* fvp = (KIND == 0) ? Q + ((((int64_t)ro * g.nseg + seg) * g.T) + rin) * r
                                                   : P + ((int64_t)ro * g.D + rin) * r;
@@ -243,35 +331,80 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                     for (int c = 0; c < r; c++) acc = fmaf(fv[c], h2f_bits(gbp[j * r + c]), acc);
                     f[j] += acc;
                 }
+                d0 = pack8(f);
+                d1 = pack8(f + 8);
             }
         }
-        uint4* op = (uint4*)(out + cur.off);
-        if (r > 0) {
-            op[0] = pack8(f);
-            op[1] = pack8(f + 8);
+        if (wave_full) {
+            // Full lines per store instruction: a lane's 32 bytes as two 16-byte stores cover every 128-byte line of the wave's
+            // 2 KB half per instruction, and with reads in flight the half-written lines cost a sixth of the write rate
+            // (tools/ubench/store_pattern3.hip: 3.9 -> 4.8 TB/s).  v_permlane32_swap puts both halves of the lower 32 lanes
+            // into the first instruction (lanes >= 32 carry the second halves) and those of the upper 32 lanes into the second.
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.x), "+v"(d1.x));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.y), "+v"(d1.y));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.z), "+v"(d1.z));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.w), "+v"(d1.w));
+            *(uint4*)(outb + cur.off + st_a) = d0;
+            *(uint4*)(outb + cur.off + st_b) = d1;
         } else {
+            uint4* op = (uint4*)(outb + cur.off);
             op[0] = d0;
             op[1] = d1;
         }
     };
-    // Two named row buffers in ping-pong (no register copies between them: a copy of a buffer whose loads are still in flight
-    // makes the compiler wait for them on the spot, which is what a rotating "cur = next" pipeline did): the loads of row
-    // i + 1 are issued before row i is computed and stored.
-    // (step li of the loop: block rows li * rpar .. li * rpar + rpar - 1, this lane's is li * rpar + sub)
-    RowIn bufA = {}, bufB = {};
-    const int R = g.rpar;
-    if (sub < nrows) fetch(sub, bufA);
-    for (int rb = 0; rb < nrows_blk; rb += 2 * R) {
-        before_row(rb);
-        if (active) {
-            if (rb + R + sub < nrows) fetch(rb + R + sub, bufB);
-            if (rb + sub < nrows) compute_row(rb + sub, bufA);
-        }
-        if (rb + R < nrows_blk) {
-            before_row(rb + R);
+    // ---- a full block of 16 rows, every lane of the wave inside the row: straight-line code.  Sixteen unrolled steps, every
+    // load issued by every lane, so the compiler's s_waitcnt for row i's inputs is exact -- "at most the loads of row i + 1 and
+    // the stores of row i - 1 still in flight".  The general loop below issues its loads under run-time conditions, and at every
+    // join the compiler can only wait for ALL outstanding memory operations: there the loads of row i + 1 were waited for
+    // right after they had been issued and every row waited for the previous row's stores to be acknowledged (the kernel ran
+    // at 2.2 - 2.5 TB/s where tools/ubench/store_pattern3.hip writes the same bytes at 4.5).
+    const bool fast = BITS <= 4 && !g.general && wave_full && (RV > 0 || r == 0) && g.rpb == 16 && g.trows == 4 && nrows_blk == 16 && (!table || pf_ok);
+    if (fast) {
+        auto rows16 = [&](auto tc) __attribute__((always_inline)) {
+            constexpr bool TBL = decltype(tc)::value;
+            RowIn buf[PFD + 1];
+            if (TBL) prefetch_entries_all(0);
+#pragma unroll
+            for (int i = 0; i < PFD; i++) fetch(i, buf[i]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (TBL && (i & 3) == 0) {
+                    if (i) __syncthreads();            // everyone is done reading the previous fill
+                    zero_table();
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < PF; q++)
+                        if (pf_rc[q] >= 0) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+                    if (i + 4 < 16) prefetch_entries_all(i + 4);
+                    __syncthreads();
+                }
+                if (i + PFD < 16) fetch(i + PFD, buf[(i + PFD) % (PFD + 1)]);
+                compute_row(i, buf[i % (PFD + 1)], TBL);
+            }
+        };
+        if (table) rows16(std::true_type{});
+        else rows16(std::false_type{});
+    } else {
+        // Two named row buffers in ping-pong (no register copies between them: a copy of a buffer whose loads are still in
+        // flight makes the compiler wait for them on the spot, which is what a rotating "cur = next" pipeline did): the loads
+        // of row i + 1 are issued before row i is computed and stored.
+        // (step li of the loop: block rows li * rpar .. li * rpar + rpar - 1, this lane's is li * rpar + sub)
+        if (table && pf_ok) prefetch_entries(0);
+        RowIn bufA = {}, bufB = {};
+        const int R = g.rpar;
+        if (sub < nrows) fetch(sub, bufA);
+        for (int rb = 0; rb < nrows_blk; rb += 2 * R) {
+            before_row(rb);
             if (active) {
-                if (rb + 2 * R + sub < nrows) fetch(rb + 2 * R + sub, bufA);
-                if (rb + R + sub < nrows) compute_row(rb + R + sub, bufB);
+                if (rb + R + sub < nrows) fetch(rb + R + sub, bufB);
+                if (rb + sub < nrows) compute_row(rb + sub, bufA, table);
+            }
+            if (rb + R < nrows_blk) {
+                before_row(rb + R);
+                if (active) {
+                    if (rb + 2 * R + sub < nrows) fetch(rb + 2 * R + sub, bufA);
+                    if (rb + R + sub < nrows) compute_row(rb + R + sub, bufB, table);
+                }
             }
         }
     }
@@ -372,6 +505,8 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
     GEAR_CHECK_ARG(inner_stride % group == 0 && outer_stride % group == 0 && (nseg == 1 || seg_stride % group == 0),
                    "gear_decompress_rows: strides must be multiples of the group size");
+    GEAR_CHECK_ARG(outer_stride / group < 0x7FFFFFFFLL && (int64_t)nseg * (nseg > 1 ? seg_stride : 0) + seglen + 16 * inner_stride < 0x7FFFFFFFLL,
+                   "gear_decompress_rows: a slab of 16 rows must span fewer than 2^31 elements");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
     const int patch = 0;   // (an in-kernel global patch pass measured 0.81 ms vs 0.72 ms for the LDS table: not used)
@@ -379,7 +514,7 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     // (fewer reloads of the lane's factor block).  The LDS outlier table covers 4 rows (35 KB) and is refilled inside the
     // block: outliers + factors 0.58 / 0.54 with 16 rows per block (0.64 / 0.62 when the block itself was 4 rows, 0.70 /
     // 0.75 with an 8-row table = 70 KB = half the resident blocks)
-    int rpb = patch ? 8 : (r > 0 ? 16 : 8);
+    int rpb = patch ? 8 : 16;
     while (rpb > 1 && rows_inner % rpb != 0) rpb >>= 1;
     int trows = rpb < 4 ? rpb : 4;            // rows per fill of the LDS outlier table (35 KB at 4096 columns)
     if (trows > rpb) trows = rpb;
@@ -392,7 +527,9 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     }
     const size_t shmem = (k > 0 && !patch) ? (size_t)trows * len * 2 : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
-    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, rpar, n_rows};
+    DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, rpar, n_rows,
+            (int)(outer_stride / group), (int)(inner_stride / group), (int)((nseg > 1 ? seg_stride : 0) / group),
+            gear_options().decomp_general};
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));
