@@ -105,8 +105,13 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     const int c2 = lane & 15, ts = lane >> 4, s = wave * 4 + ts;      // channel pair in the quarter, stream id (16 streams)
     const int T = a.T, k = a.k;
     const uint16_t* xq = a.x + bh * (int64_t)T * KD + 32 * q;         // this quarter's first channel of token 0
-    const uint32_t* xw = (const uint32_t*)xq + c2;                    // + t * 64 words
     const int per_stream = (T + 15) >> 4;                             // tokens of a stream: t = s + 16 i
+    // word (token t, this lane's channel pair): a block-uniform base (scalar registers) + a 32-bit byte offset, every load
+    // issued by every lane (an index past the end is clamped and the word dropped) -- loads under a condition make the
+    // compiler wait for ALL outstanding loads at the join, and a 64-bit multiply per load was 10 of this loop's instructions
+    const char* xbase = (const char*)xq;
+    const uint32_t lane_b = 4u * (uint32_t)c2 + 256u * (uint32_t)s;
+    auto ldw = [&](int i) { return *(const uint32_t*)(xbase + (lane_b + 4096u * (uint32_t)i)); };     // token s + 16 i
 
     // ---------------------------------------------------------------- phase A: sample statistics -> threshold guess
     {
@@ -116,13 +121,11 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         for (int i0 = 0; i0 < per_stream; i0 += KS_A * a.sstride) {
             uint32_t w[KS_A];
 #pragma unroll
-            for (int j = 0; j < KS_A; j++) {
-                const int i = i0 + j * a.sstride, t = s + 16 * i;
-                w[j] = (i < per_stream && t < T) ? xw[(int64_t)t * 64] : 0u;
-            }
+            for (int j = 0; j < KS_A; j++) w[j] = ldw(min(i0 + j * a.sstride, per_stream - 1));
 #pragma unroll
             for (int j = 0; j < KS_A; j++) {
-                const float f0 = h2f_bits((uint16_t)(w[j] & 0xFFFFu)), f1 = h2f_bits((uint16_t)(w[j] >> 16));
+                const uint32_t wj = (i0 + j * a.sstride < per_stream) ? w[j] : 0u;
+                const float f0 = h2f_bits((uint16_t)(wj & 0xFFFFu)), f1 = h2f_bits((uint16_t)(wj >> 16));
                 s1a += f0; s2a = fmaf(f0, f0, s2a);
                 s1b += f1; s2b = fmaf(f1, f1, s2b);
             }
@@ -172,25 +175,24 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         // LDS byte offsets (from cnt) of the lane's four lists: [half][side] -> counter, candidate region
         const uint32_t l0 = (uint32_t)(2 * c2) * 2u;
         const int nb = (per_stream + KS_B - 1) / KS_B;
-        auto load_batch = [&](int b, uint32_t (&dst)[KS_B]) {
+        auto load_batch = [&](int b, uint32_t (&dst)[KS_B]) {      // (a batch past the end re-reads the last one; never used)
+            const int i0 = min(b, nb - 1) * KS_B;
 #pragma unroll
-            for (int j = 0; j < KS_B; j++) {
-                const int t = s + 16 * (b * KS_B + j);
-                dst[j] = (t < T) ? xw[(int64_t)t * 64] : 0u;
-            }
+            for (int j = 0; j < KS_B; j++) dst[j] = ldw(min(i0 + j, per_stream - 1));
         };
         auto process_batch = [&](int b, const uint32_t (&cur)[KS_B]) {
+            const int nv = min(KS_B, per_stream - b * KS_B);                       // valid words of this batch (T % 16 == 0)
             uint32_t m = 0u;
 #pragma unroll
             for (int j = 0; j < KS_B; j++) {
-                const half2v xv = __builtin_bit_cast(half2v, cur[j]);
+                const uint32_t wj = (j < nv) ? cur[j] : 0u;
+                const half2v xv = __builtin_bit_cast(half2v, wj);
                 suma = __builtin_amdgcn_fdot2(xv, sel_a, suma, false);
                 sumb = __builtin_amdgcn_fdot2(xv, sel_b, sumb, false);
-                const uint32_t cl = pkmin16(pkmax16(cur[j], tlo_u), thi_u);
-                m = (m << 1) | pkminu16(cl ^ cur[j], 0x00010001u);
-                stash[j * 256] = cur[j];
+                const uint32_t cl = pkmin16(pkmax16(wj, tlo_u), thi_u);
+                m = (m << 1) | pkminu16(cl ^ wj, 0x00010001u);
+                stash[j * 256] = wj;
             }
-            const int nv = min(KS_B, per_stream - b * KS_B);                       // valid words of this batch (T % 16 == 0)
             m &= ((0xFFu << (KS_B - nv)) & 0xFFu) * 0x00010001u;
             const int tb0 = s + 16 * (b * KS_B + KS_B - 1);                         // token of word j: tb0 - 16 (p & 15)
             while (m) {
@@ -208,20 +210,18 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         // issued (a "cur = next" register copy made the compiler wait for the loads issued ONE batch time before, which is less
         // than an HBM round trip: ~1.2 us of stall per batch, 40 us per workgroup)
         uint32_t bufA[KS_B], bufB[KS_B], bufC[KS_B];
+        // (every load_batch is unconditional -- the conditions guard LDS work only -- so that the compiler can count: "the
+        // batch I need is followed by exactly two younger ones")
         load_batch(0, bufA);
-        if (nb > 1) load_batch(1, bufB);
+        load_batch(1, bufB);
 #pragma unroll 1
         for (int b = 0; b < nb; b += 3) {
-            if (b + 2 < nb) load_batch(b + 2, bufC);
+            load_batch(b + 2, bufC);
             process_batch(b, bufA);
-            if (b + 1 < nb) {
-                if (b + 3 < nb) load_batch(b + 3, bufA);
-                process_batch(b + 1, bufB);
-            }
-            if (b + 2 < nb) {
-                if (b + 4 < nb) load_batch(b + 4, bufB);
-                process_batch(b + 2, bufC);
-            }
+            load_batch(b + 3, bufA);
+            if (b + 1 < nb) process_batch(b + 1, bufB);
+            load_batch(b + 4, bufB);
+            if (b + 2 < nb) process_batch(b + 2, bufC);
         }
     }
     __syncthreads();                                   // the stash is dead: its space takes the 16 streams' partial sums
