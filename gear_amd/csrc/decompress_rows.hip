@@ -23,6 +23,7 @@ namespace {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 
 
@@ -340,10 +341,14 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             // 2 KB half per instruction, and with reads in flight the half-written lines cost a sixth of the write rate
             // (tools/ubench/store_pattern3.hip: 3.9 -> 4.8 TB/s).  v_permlane32_swap puts both halves of the lower 32 lanes
             // into the first instruction (lanes >= 32 carry the second halves) and those of the upper 32 lanes into the second.
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.x), "+v"(d1.x));
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.y), "+v"(d1.y));
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.z), "+v"(d1.z));
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d0.w), "+v"(d1.w));
+            // (the builtin, not inline asm: the instruction needs wait states after a vector write of its operands, which the
+            // compiler only inserts for instructions it knows -- with asm the first word of a block's first row came out wrong)
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(d0.x, d1.x, false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(d0.y, d1.y, false, false);
+            const u32x2 s2 = __builtin_amdgcn_permlane32_swap(d0.z, d1.z, false, false);
+            const u32x2 s3 = __builtin_amdgcn_permlane32_swap(d0.w, d1.w, false, false);
+            d0 = make_uint4(s0.x, s1.x, s2.x, s3.x);
+            d1 = make_uint4(s0.y, s1.y, s2.y, s3.y);
             *(uint4*)(outb + cur.off + st_a) = d0;
             *(uint4*)(outb + cur.off + st_b) = d1;
         } else {
