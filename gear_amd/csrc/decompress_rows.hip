@@ -164,14 +164,18 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const int ro = (int)(row0 / g.rows_inner);
     const int seg = active ? j0 / g.seglen : 0, pos = active ? j0 % g.seglen : 0;
     // (store exchange, see compute_row: this lane writes the 16-byte half `tid >> 5 & 1` of lane (tid & 31) of its wave in the
-    // first store and of lane 32 + (tid & 31) in the second; st_a / st_b = their offsets relative to this lane's own)
-    const bool wave_full = g.rpar == 1 && ((tid | 63) + 1) * 16 <= g.len;
+    // first store and of lane 32 + (tid & 31) in the second; st_a / st_b = their offsets relative to this lane's own.  With
+    // short rows side by side the lower 32 lanes hold whole rows, so the exchange puts whole rows into one instruction)
+    const bool wave_full = g.rpar > 1 || ((tid | 63) + 1) * 16 <= g.len;
     int st_a = 0, st_b = 0;
     if (wave_full) {
-        const int ja = ((tid & ~63) + (tid & 31)) * 16, jb = ja + 512, hf = 8 * ((tid >> 5) & 1);
-        const int own = seg * (int)g.seg_stride + pos;
-        st_a = (ja / g.seglen) * (int)g.seg_stride + ja % g.seglen + hf - own;
-        st_b = (jb / g.seglen) * (int)g.seg_stride + jb % g.seglen + hf - own;
+        auto off_of = [&](int ln) {          // element offset of lane ln's first column, its row slot included
+            const int lcs = g.rpar > 1 ? ln % lpr : ln, subs = g.rpar > 1 ? ln / lpr : 0, js = lcs * 16;
+            return (js / g.seglen) * (int)g.seg_stride + js % g.seglen + subs * (int)g.inner_stride;
+        };
+        const int la = (tid & ~63) + (tid & 31), hf = 8 * ((tid >> 5) & 1), own = off_of(tid);
+        st_a = off_of(la) + hf - own;
+        st_b = off_of(la + 32) + hf - own;
     }
 
     // ---- the 16 x r factor block of this lane's columns (row-independent)
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             fill_table(ri);
         }
     };
-    auto compute_row = [&](int ri, const RowIn& cur, const bool table) __attribute__((always_inline)) {
+    // (swp: exchange the store halves between lanes l and l + 32 -- every lane of the wave must be in this call)
+    auto compute_row = [&](int ri, const RowIn& cur, const bool table, const bool swp) __attribute__((always_inline)) {
         float f[16];
         uint4 d0, d1;
         if constexpr (BITS == 2) {
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                 d1 = pack8(f + 8);
             }
         }
-        if (wave_full) {
+        if (swp) {
             // Full lines per store instruction: a lane's 32 bytes as two 16-byte stores cover every 128-byte line of the wave's
             // 2 KB half per instruction, and with reads in flight the half-written lines cost a sixth of the write rate
             // (tools/ubench/store_pattern3.hip: 3.9 -> 4.8 TB/s).  v_permlane32_swap puts both halves of the lower 32 lanes
@@ -363,38 +368,50 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     // join the compiler can only wait for ALL outstanding memory operations: there the loads of row i + 1 were waited for
     // right after they had been issued and every row waited for the previous row's stores to be acknowledged (the kernel ran
     // at 2.2 - 2.5 TB/s where tools/ubench/store_pattern3.hip writes the same bytes at 4.5).
-    const bool fast = BITS <= 4 && !g.general && wave_full && (RV > 0 || r == 0) && g.rpb == 16 && g.trows == 4 && nrows_blk == 16 && (!table || pf_ok);
+    // Short rows (rpar of them side by side, TB == 256 only): the same sixteen steps with rpar rows each; the table period in
+    // steps is then a run-time number, so that flavour keeps a uniform branch around the fill.
+    const bool fast = BITS <= 4 && !g.general && wave_full && (RV > 0 || r == 0) && g.rpb == 16 * g.rpar && nrows_blk == g.rpb &&
+                      (g.rpar > 1 ? TB == 256 : g.trows == 4) && (!table || pf_ok);
     if (fast) {
-        auto rows16 = [&](auto tc) __attribute__((always_inline)) {
+        auto rows16 = [&](auto tc, auto rc) __attribute__((always_inline)) {
             constexpr bool TBL = decltype(tc)::value;
+            constexpr bool R1 = decltype(rc)::value;          // one row per step (the table period is four steps)
+            const int R = R1 ? 1 : g.rpar;
             RowIn buf[PFD + 1];
             if (TBL) prefetch_entries_all(0);
 #pragma unroll
-            for (int i = 0; i < PFD; i++) fetch(i, buf[i]);
+            for (int i = 0; i < PFD; i++) fetch(i * R + sub, buf[i]);
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                if (TBL && (i & 3) == 0) {
+                if (TBL && (R1 ? (i & 3) == 0 : ((i * R) & (g.trows - 1)) == 0)) {
                     if (i) __syncthreads();            // everyone is done reading the previous fill
                     zero_table();
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < PF; q++)
                         if (pf_rc[q] >= 0) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
-                    if (i + 4 < 16) prefetch_entries_all(i + 4);
+                    if (R1) { if (i + 4 < 16) prefetch_entries_all(i + 4); }
+                    else if (i * R + g.trows < g.rpb) prefetch_entries_all(i * R + g.trows);
                     __syncthreads();
                 }
-                if (i + PFD < 16) fetch(i + PFD, buf[(i + PFD) % (PFD + 1)]);
-                compute_row(i, buf[i % (PFD + 1)], TBL);
+                if (i + PFD < 16) fetch((i + PFD) * R + sub, buf[(i + PFD) % (PFD + 1)]);
+                compute_row(i * R + sub, buf[i % (PFD + 1)], TBL, true);
             }
         };
-        if (table) rows16(std::true_type{});
-        else rows16(std::false_type{});
+        if (TB == 256 && g.rpar > 1) {
+            if (table) rows16(std::true_type{}, std::false_type{});
+            else rows16(std::false_type{}, std::false_type{});
+        } else {
+            if (table) rows16(std::true_type{}, std::true_type{});
+            else rows16(std::false_type{}, std::true_type{});
+        }
     } else {
         // Two named row buffers in ping-pong (no register copies between them: a copy of a buffer whose loads are still in
         // flight makes the compiler wait for them on the spot, which is what a rotating "cur = next" pipeline did): the loads
         // of row i + 1 are issued before row i is computed and stored.
         // (step li of the loop: block rows li * rpar .. li * rpar + rpar - 1, this lane's is li * rpar + sub)
         if (table && pf_ok) prefetch_entries(0);
+        const bool swp_gen = wave_full && g.rpar == 1;      // (rows side by side: the last step of a block may be partly empty)
         RowIn bufA = {}, bufB = {};
         const int R = g.rpar;
         if (sub < nrows) fetch(sub, bufA);
@@ -402,13 +419,13 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             before_row(rb);
             if (active) {
                 if (rb + R + sub < nrows) fetch(rb + R + sub, bufB);
-                if (rb + sub < nrows) compute_row(rb + sub, bufA, table);
+                if (rb + sub < nrows) compute_row(rb + sub, bufA, table, swp_gen);
             }
             if (rb + R < nrows_blk) {
                 before_row(rb + R);
                 if (active) {
                     if (rb + 2 * R + sub < nrows) fetch(rb + 2 * R + sub, bufA);
-                    if (rb + R + sub < nrows) compute_row(rb + R + sub, bufB, table);
+                    if (rb + R + sub < nrows) compute_row(rb + R + sub, bufB, table, swp_gen);
                 }
             }
         }
@@ -510,8 +527,8 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     GEAR_CHECK_ARG(rows_inner > 0 && n_rows % rows_inner == 0, "gear_decompress_rows: n_rows must be a multiple of rows_inner");
     GEAR_CHECK_ARG(inner_stride % group == 0 && outer_stride % group == 0 && (nseg == 1 || seg_stride % group == 0),
                    "gear_decompress_rows: strides must be multiples of the group size");
-    GEAR_CHECK_ARG(outer_stride / group < 0x7FFFFFFFLL && (int64_t)nseg * (nseg > 1 ? seg_stride : 0) + seglen + 16 * inner_stride < 0x7FFFFFFFLL,
-                   "gear_decompress_rows: a slab of 16 rows must span fewer than 2^31 elements");
+    GEAR_CHECK_ARG(outer_stride / group < 0x7FFFFFFFLL && (int64_t)nseg * (nseg > 1 ? seg_stride : 0) + seglen + 128 * inner_stride < 0x7FFFFFFFLL,
+                   "gear_decompress_rows: the rows of a block (up to 128) must span fewer than 2^31 elements");
     if (kind == 0) GEAR_CHECK_ARG(rows_inner == T && seglen == D, "gear_decompress_rows: kind 0 needs rows_inner == T and seglen == D");
     if (kind == 1) GEAR_CHECK_ARG(rows_inner == D && nseg == 1 && seglen == T, "gear_decompress_rows: kind 1 needs rows_inner == D, one segment of T");
     const int patch = 0;   // (an in-kernel global patch pass measured 0.81 ms vs 0.72 ms for the LDS table: not used)
@@ -521,15 +538,20 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     // 0.75 with an 8-row table = 70 KB = half the resident blocks)
     int rpb = patch ? 8 : 16;
     while (rpb > 1 && rows_inner % rpb != 0) rpb >>= 1;
+    // short rows (head shards: 128 .. 512 elements): 8 / 4 / 2 rows side by side in the one wave of the block, and 16 such steps
+    // per block -- the lane's factor block (r / 2 registers per column, 32 KB per wave at rank 16) is loaded once per block, and
+    // with 16 ROWS per block a 128-element row cost eight times its own bytes in factor loads (config 5 on 8 GPUs: 0.216 ms)
+    int rpar = 1;
+    if (len / 16 < 64 && 64 % (len / 16) == 0) {
+        const int rp = (int)(64 / (len / 16));
+        int rb = 16 * rp;
+        while (rb > rp && rows_inner % rb != 0) rb >>= 1;
+        if (rows_inner % rb == 0) { rpar = rp; rpb = rb; }
+    }
     int trows = rpb < 4 ? rpb : 4;            // rows per fill of the LDS outlier table (35 KB at 4096 columns)
     if (trows > rpb) trows = rpb;
     while (trows > 1 && (rpb % trows != 0 || (size_t)trows * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024)) trows >>= 1;
-    // short rows (head shards: 128 .. 512 elements): 8 / 4 / 2 rows side by side in the one wave of the block
-    int rpar = 1;
-    if (len / 16 < 64 && 64 % (len / 16) == 0 && rpb % (64 / (len / 16)) == 0) {
-        rpar = (int)(64 / (len / 16));
-        if (trows < rpar) trows = rpar;            // one fill of the table covers at least the rows in flight
-    }
+    if (trows < rpar) trows = rpar;           // one fill of the table covers at least the rows in flight
     const size_t shmem = (k > 0 && !patch) ? (size_t)trows * len * 2 : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
     DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, rpar, n_rows,
