@@ -15,8 +15,11 @@
 // 8 GPUs with TWO chunks per lane instead of four (187 registers -> two waves per SIMD was this kernel's limit): 176 -> ~150 us.
 #include "common.h"
 #include "rowgeom.h"
+#include "dense16.h"
 
 namespace {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
 
 template <int LPR>
 __device__ __forceinline__ uint32_t grp_max_u32(uint32_t v) {
@@ -163,7 +166,33 @@ __global__ __launch_bounds__(256) void compress_rows_multi_kernel(const uint16_t
         }
     }
 
-    // ---------------- group quantization (the arithmetic of quant_pack.hip / compress_rows_kernel), one chunk at a time
+    // ---------------- group quantization, one chunk at a time
+    // fp32 arithmetic (the simulated path): the packed dense half of the long-row kernels (dense16.h: packed fp16 min / max,
+    // reciprocal multiply with a tie guard, Horner packing, packed error) -- the element-by-element loop below it came to 56
+    // vector instructions per element against 20, and this kernel is vector-bound (147 us for config 3's 8-GPU V shard)
+    if constexpr (MODE == 1) {
+        // (row bases are multiples of the group size -- the host checks the strides -- so the row-relative offsets split off)
+        uint32_t* code_row = code + orow_base / CPW;
+        float* scale_row = (float*)scale + (orow_base >> gm.group_shift);
+        float* mn_row = (float*)mn + (orow_base >> gm.group_shift);
+        uint16_t* err_row = err ? err + row_base : nullptr;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const uint32_t outl = fl_lo[c] | fl_hi[c];
+            uint32_t m[8];
+            const short2v o2 = __builtin_bit_cast(short2v, outl | (outl << 16));
+#pragma unroll
+            for (int w = 0; w < 8; w++) {          // half-word masks of elements 2w (low half) and 2w + 1 (high half)
+                short2v t = o2 << (short2v){(short)(15 - 2 * w), (short)(14 - 2 * w)};
+                t = t >> (short2v){15, 15};
+                m[w] = __builtin_bit_cast(uint32_t, t);
+            }
+            if (valid)
+                dense16<BITS>(raw[c], m, outl, fill, group, gm.group_shift, lane, code_row, scale_row, mn_row,
+                              (uint32_t)(ooff[c] - orow_base), err_row, (uint32_t)(off[c] - row_base));
+        }
+        return;
+    }
     const int lanes_per_group = group >> 4;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
