@@ -61,6 +61,7 @@ struct DGeom {
     int rpar;    // short rows (len / 16 < 64 lanes): rpar rows side by side in the block's one wave, lane = (row slot, 16 columns)
     int64_t n_rows;
     int og, ig, sg;   // outer / inner / segment stride in groups
+    int xcd;          // launch index -> block in XCD-contiguous order (grid a multiple of 8)
     int general;      // never the straight-line path for full blocks (option decomp_general: test coverage of the general loop)
 };
 
@@ -85,7 +86,12 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
     const int lc = g.rpar > 1 ? tid % lpr : tid, sub = g.rpar > 1 ? tid / lpr : 0;
     const int j0 = lc * 16;
     const bool active = j0 < g.len;
-    const int64_t row0 = (int64_t)blockIdx.x * g.rpb;
+    // XCD-aware order (g.xcd, K^T): workgroup i runs on XCD i % 8, so the launch index is turned around -- XCD x walks the
+    // consecutive blocks [x * n / 8, (x + 1) * n / 8).  The 8 blocks that share a head's 64 KB column factor (Q[bh]: 128 rows = 8
+    // blocks) then run on ONE XCD at about the same time and its L2 fetches the factor once instead of eight L2s fetching it once
+    // each: PMC FETCH_SIZE of the K^T call at config 3 0.78 -> 0.25 GB (the time moves by ~2 %: those reads were Infinity Cache hits)
+    const uint32_t bid = g.xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t row0 = (int64_t)bid * g.rpb;
     const int r = g.r;
     // LDS outlier table: trows x len half-words holding the COMPLEMENT of the outlier's fp16 bits; 0 = "no outlier here" (the
     // complement of 0xFFFF, a NaN no payload value has)
@@ -555,8 +561,9 @@ extern "C" int gear_decompress_rows(const void* code, const void* scale, const v
     const size_t shmem = (k > 0 && !patch) ? (size_t)trows * len * 2 : 0;
     GEAR_CHECK_ARG(shmem <= 72 * 1024, "gear_decompress_rows: row too long for the LDS outlier table");
     DGeom g{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride, (int)len, group, T, D, r, k, rpb, patch, trows, rpar, n_rows,
-            (int)(outer_stride / group), (int)(inner_stride / group), (int)((nseg > 1 ? seg_stride : 0) / group),
+            (int)(outer_stride / group), (int)(inner_stride / group), (int)((nseg > 1 ? seg_stride : 0) / group), 0,
             gear_options().decomp_general};
+    g.xcd = kind == 1 && r > 0 && ((n_rows + rpb - 1) / rpb) % 8 == 0;
     int threads = (int)((len / 16 + 63) / 64 * 64);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(threads), grid((unsigned)((n_rows + rpb - 1) / rpb));

@@ -28,7 +28,7 @@ out = {"lib_sha256": open(f"{src}/lib.sha256").read().split()[0], "config": conf
               f"1 GiB copy in the same run (read {kf:.1f}, write {kw:.1f} B / unit: KB units, FETCH_SIZE counts half the bytes)"}
 rows = []
 for n in fetch:
-    if not n.startswith(("compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "transpose_f16")):
+    if not n.startswith(("compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "transpose_f16", "decompress_rows")):
         continue
     f = sorted(fetch[n]["FETCH_SIZE"])[len(fetch[n]["FETCH_SIZE"]) // 2] * kf
     w = sorted(write[n]["WRITE_SIZE"])[len(write[n]["WRITE_SIZE"]) // 2] * kw

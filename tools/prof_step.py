@@ -1,4 +1,4 @@
-"""PMC / kernel-trace target (GPU box): the compress kernels of one bench step at BASELINE config 3 size, 3 launches each, after a
+"""PMC / kernel-trace target (GPU box): the compress and decompress kernels of one bench step at BASELINE config 3 size, 3 launches each, after a
 1 GiB copy as calibration (1 GiB read + 1 GiB written).  usage: python tools/prof_step.py [layers]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,10 +19,23 @@ del y
 P0 = torch.rand((L, H, D, rank), device="cuda")
 for _ in range(3):
     pv = C.compress_value(x, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0)
-    del pv
+    if _ < 2:
+        del pv
 torch.cuda.synchronize()
+for _ in range(3):                      # (round 4: the decompress kernels of the step too)
+    yv = C.decompress(pv, transposed_out=True)
+    del yv
+torch.cuda.synchronize()
+del pv
 for path in ("fused", "rows"):
     for _ in range(3):
         pk = C.compress_key(x, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0, path=path)
-        del pk
+        if not (path == "fused" and _ == 2):
+            del pk
     torch.cuda.synchronize()
+    if path == "fused":
+        for _ in range(3):
+            yk = C.decompress(pk, transposed_out=True)
+            del yk
+        torch.cuda.synchronize()
+        del pk
