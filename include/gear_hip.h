@@ -212,6 +212,8 @@ int gear_lowrank(const void* E, int e_dtype, int transposed, int64_t bh, int S, 
  * assembles the simulated result the same way).  Geometry as gear_compress_rows.
  *   kind 0: V rows (row = (b, t), rows_inner = T, nseg = H, seglen = D)   kind 1: K^T rows (row = (bh, d),
  *   rows_inner = D, one segment of T).  P fp16 [BH, D, r], Q fp16 [BH, T, r] (r == 0: none).
+ * Limits (GEAR_ERR_ARG otherwise): the rows of one outer index must span fewer than 2^31 elements (the kernel adds 32-bit lane
+ * offsets to a 64-bit base per workgroup), strides multiples of the group size.
  */
 int gear_decompress_rows(const void* code, const void* scale, const void* mn, int64_t n_rows, int rows_inner,
                          int64_t outer_stride, int64_t inner_stride, int nseg, int seglen, int64_t seg_stride, int group,
