@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prewarm-s", type=float, default=1.5,
+                    help="seconds of untimed steps before the warm-up steps (device clocks / power state); 0 = none")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the number)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -446,6 +448,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # untimed: bring the device to its sustained state first (a fresh box's first process measured the K chain 15 % slower than
+    # the next process on the same box -- clocks / power state, not the code), then the W warm-up steps of the contract
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < args.prewarm_s:
+        out = step()
+        torch.cuda.synchronize()
     for _ in range(max(1, args.warmup)):
         out = step()
     sync()
