@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--prewarm-s", type=float, default=1.5,
+    ap.add_argument("--prewarm-s", type=float, default=4.0,
                     help="seconds of untimed steps before the warm-up steps (device clocks / power state); 0 = none")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the number)")
@@ -448,8 +448,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # untimed: bring the device to its sustained state first (a fresh box's first process measured the K chain 15 % slower than
-    # the next process on the same box -- clocks / power state, not the code), then the W warm-up steps of the contract
+    # untimed: bring the device to its sustained state first, then the W warm-up steps of the contract.  The first process on a
+    # fresh box measured the serial K chain at 1.46-1.61 ms for its first ~3 s of GPU work and the next process on the same box at
+    # 1.30-1.34 ms (three boxes); with 5 s of steps in front the first process reads 1.30-1.32 ms too.
     tw = time.perf_counter()
     while time.perf_counter() - tw < args.prewarm_s:
         out = step()
@@ -488,6 +489,8 @@ def main():
     stages = {}
     for nme in names:
         ms = [a.elapsed_time(b) for a, b in zip(ev[prev], ev[nme])]
+        if os.environ.get("GEAR_BENCH_DEBUG"):
+            print(nme, [round(v, 3) for v in ms], file=sys.stderr)
         stages[nme] = sum(ms) / len(ms)
         prev = nme
 
