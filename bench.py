@@ -451,10 +451,18 @@ def main():
     # untimed: bring the device to its sustained state first, then the W warm-up steps of the contract.  The first process on a
     # fresh box measured the serial K chain at 1.46-1.61 ms for its first ~3 s of GPU work and the next process on the same box at
     # 1.30-1.34 ms (three boxes); with 5 s of steps in front the first process reads 1.30-1.32 ms too.
-    tw = time.perf_counter()
-    while time.perf_counter() - tw < args.prewarm_s:
+    if args.prewarm_s > 0:
         out = step()
-        torch.cuda.synchronize()
+        sync()
+        t1 = time.perf_counter()
+        out = step()
+        sync()
+        d1 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(d1, op=dist.ReduceOp.MAX)        # (the same number of steps on every rank)
+        for _ in range(int(min(5000.0, args.prewarm_s / max(float(d1.item()), 1e-4)))):
+            out = step()
+        sync()
     for _ in range(max(1, args.warmup)):
         out = step()
     sync()
