@@ -44,7 +44,7 @@ const char* gear_last_error(void);
 int gear_abi_version(void);
 /* Run-time options: switches that select an alternative, equally exact code path (used by the tests to reach the
  * paths ordinary inputs do not).  Names: "attn_generic", "lowrank_generic", "rows_hist_only", "rows_wg_only", "rows_v1",
- * "kfused_generic", "kselect_slow", "kfused_no_tr".  Each is also read once from the environment (GEAR_<NAME>) when the library is
+ * "kfused_generic", "kselect_slow", "kfused_no_tr", "gram_fused", "gram_nstg", "decomp_general".  Each is also read once from the environment (GEAR_<NAME>) when the library is
  * first used.  Returns 0, or -1 for an unknown name. */
 int gear_set_option(const char* name, int value);
 
