@@ -13,7 +13,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 python tools/kstats.py $(find $OUT/stats -name "*kernel_stats.csv" | head -1) 30 > $OUT/kernel_stats_bench.md
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dec -o st -- python tools/prof_decode.py > $OUT/stats_dec.log 2>&1
 python tools/kstats.py $(find $OUT/stats_dec -name "*kernel_stats.csv" | head -1) 30 > $OUT/kernel_stats_decode.md
-tail -3 $OUT/stats_dec.log >> $OUT/kernel_stats_decode.md
+# (the script's own result lines only: rocprofv3 writes its log to the same stream)
+grep -v -E "^[EWI][0-9]{8} " $OUT/stats_dec.log | grep -E "^(ms/token|enqueue)" | sed "s/^/\n/" | tail -4 >> $OUT/kernel_stats_decode.md
 # the compress kernels ONE AT A TIME on one stream (tools/prof_step.py): the durations the per-kernel roofline fractions stand on
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_iso -o st -- python tools/prof_step.py > $OUT/stats_iso.log 2>&1
 python tools/kstats.py $(find $OUT/stats_iso -name "*kernel_stats.csv" | head -1) 30 > $OUT/kernel_stats_isolated.md
