@@ -11,14 +11,23 @@ Workload (BASELINE.json): default = configs[2], the one the metric is quoted on
     "Llama-2-7B, seq=4096, 2-bit KIVI-style per-channel K / per-token V + rank-8 + 2% outlier, 1xMI355X"
     --config c2 = configs[1] (seq 2048, 4-bit, rank 4, 1 %), c4 = configs[3] (13B, 1 %), c5 = configs[4] (70B GQA, 8k, rank 16).
 Multi-GPU: KV heads are sharded across ranks (7B: 32/N heads per GPU, 13B: 40/4, 70B: 8/8 = one KV head with its 8 query
-heads); compress / decompress need no data-path collective (V outlier rows are selected per shard with k / N, see
-DESIGN.md); total work is fixed -> "scaling": "strong".  The decode leg shards the attention the same way and all-gathers
-the per-rank attention output (RCCL) in front of the replicated o_proj.
+heads); K compress and both decompressors need no data-path collective.  V outlier rows span ALL heads of a token
+(compress_function.py:297-333): with a process group the shards run the EXACT cross-shard selection (one small all-gather of
+candidates per call; the concatenated shard payloads are the unsharded payload bit for bit -- checked at start-up on a
+256-token tensor, `shard_parity` in the line) and the k / N per-shard selection of rounds 1-3 is reported beside it
+(`v_selection_per_shard`); `--emulate-world` has no process group and runs per-shard.  Total work is fixed -> "scaling":
+"strong".  The decode leg shards the attention the same way and all-gathers the per-rank attention output (RCCL by default)
+in front of the replicated o_proj.
 
-Accounting: `roofline` = the single longest kernel of the step, timed in isolation with HIP events on
-its launch stream, ALGORITHMIC bytes of SURVEY.md 8(d) (read 2n, write codes + scale/mn + outliers -- no error term);
-`roofline_chain` = the same byte definition per whole stage; `kernels` = the other large kernels one by one;
-`traffic` comes from profiles/r2_traffic.json and only when that file was measured on the library that is loaded now.
+Accounting: `roofline` = the compress CHAIN north_star names (all launches of one
+gear_compress_key_fused / gear_compress_value_fused call, the lower of K and V), HIP events on the launch stream, ALGORITHMIC
+bytes of SURVEY.md 8(d) verbatim (read 2n; write codes n b/8 + scale/mn 4n/g + factors + 6 bytes per outlier -- no error
+term; what the build actually stores -- fp32 scale/mn in the simulated arithmetic, uint16 indices -- is `stored_bytes`);
+`roofline.dominant_kernel` = the longest single kernel, timed alone AND (from the rocprofv3 trace of the bench step) inside the
+two-stream step; `roofline_chain` = the same byte definition per whole stage; `kernels` = the large kernels one by one;
+`traffic` comes from the newest profiles/r*_traffic.json that was measured on exactly the library that is loaded now.
+`value` is wall time over steps whose K and V chains OVERLAP on two HIP streams; `stage_ms` / `roofline_chain` are measured in
+a separate serial pass (one chain at a time), so their sum is larger than `ms_per_step`.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      (N > 1 via torch.distributed.run, one rank per GPU)
 """
@@ -451,6 +460,7 @@ def main():
     # untimed: bring the device to its sustained state first, then the W warm-up steps of the contract.  The first process on a
     # fresh box measured the serial K chain at 1.46-1.61 ms for its first ~3 s of GPU work and the next process on the same box at
     # 1.30-1.34 ms (three boxes); with 5 s of steps in front the first process reads 1.30-1.32 ms too.
+    prewarm_steps, prewarm_t0 = 0, time.perf_counter()
     if args.prewarm_s > 0:
         out = step()
         sync()
@@ -460,9 +470,12 @@ def main():
         d1 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(d1, op=dist.ReduceOp.MAX)        # (the same number of steps on every rank)
-        for _ in range(int(min(5000.0, args.prewarm_s / max(float(d1.item()), 1e-4)))):
+        n_pre = int(min(5000.0, args.prewarm_s / max(float(d1.item()), 1e-4)))
+        for _ in range(n_pre):
             out = step()
         sync()
+        prewarm_steps = n_pre + 2
+    prewarm_seconds = time.perf_counter() - prewarm_t0
     for _ in range(max(1, args.warmup)):
         out = step()
     sync()
@@ -503,16 +516,22 @@ def main():
         prev = nme
 
     # ---- algorithmic bytes (one K or V tensor of n elements on this rank): read 2n, write the payload
-    def payload_bytes(kind):
+    # SURVEY.md 8(d) VERBATIM: codes n b/8 + scale/mn 4n/g (fp16 each) + factors 2r(T+D) per head + 6 bytes per outlier (fp16
+    # value + uint32 index).  What the build stores differs by ~1 %: in the simulated (fp32) arithmetic scale / mn are float32
+    # (8n/g) and the indices uint16 (4 bytes per outlier) -- `stored_bytes`, not used for any fraction.
+    def payload_bytes(kind, stored=False):
         rows = BH * D if kind == "k" else layers * T
         kk = k_key if kind == "k" else k_val
-        return (n * bits / 8 + 8 * n / group                 # codes, scale + mn (float32 each in the simulated arithmetic)
+        return (n * bits / 8 + (8 if stored else 4) * n / group
                 + 2 * rnk * (T + D) * BH                     # P, Q fp16
-                + rows * 2 * kk * 4)                         # outliers: uint16 index + fp16 value
+                + rows * 2 * kk * (4 if stored else 6))
 
     alg = {"k_compress": 2 * n + payload_bytes("k"), "v_compress": 2 * n + payload_bytes("v"),
            "k_decompress": payload_bytes("k") + 2 * n, "v_decompress": payload_bytes("v") + 2 * n}
-    chain = {nme: {"alg_bytes": alg[nme], "ms": stages[nme], "achieved": alg[nme] / (stages[nme] * 1e-3) / 1e9,
+    stored = {"k_compress": 2 * n + payload_bytes("k", True), "v_compress": 2 * n + payload_bytes("v", True),
+              "k_decompress": payload_bytes("k", True) + 2 * n, "v_decompress": payload_bytes("v", True) + 2 * n}
+    chain = {nme: {"alg_bytes": alg[nme], "stored_bytes": stored[nme], "ms": stages[nme],
+                   "achieved": alg[nme] / (stages[nme] * 1e-3) / 1e9,
                    "frac": alg[nme] / (stages[nme] * 1e-3) / 1e9 / HBM_PEAK_GBS} for nme in names}
 
     # ---- the large kernels one by one (HIP events around back-to-back launches of ONE kernel on the launch stream)
@@ -533,7 +552,7 @@ def main():
     errb = torch.empty((layers, Hl, T, D), dtype=torch.float16, device=dev)
     rows_out = C._alloc_rows(tuple(V.shape), layers * T, group, bits, 1, k_val, dev)
     ms_rows = timed(lambda: C._compress_rows(V, geom_v, group, bits, 1, k_val, rows_out, errb))
-    b_rows = 2 * n + n * bits / 8 + 8 * n / group + layers * T * 2 * k_val * 4
+    b_rows = 2 * n + n * bits / 8 + 4 * n / group + layers * T * 2 * k_val * 6      # SURVEY 8(d) verbatim
     rows_len = Hl * D
     rows_name = (f"compress_rows_wave_kernel<{bits}, {rows_len // 1024}, fast + fallback pass>" if rows_len % 1024 == 0 and (rows_len <= 5120 or rows_len == 8192) and k_val <= 58
                  else f"compress_rows_fp32_kernel<{bits}, float>")
@@ -545,8 +564,8 @@ def main():
         ms_full = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k))
         ms_sel = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=32)) if k_key else 0.0
         ms_main = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=8 | 16))
-        b_sel = 2 * n + BH * D * 2 * k_key * 4 + n / 8
-        b_main = 2 * n + n / 8 * (1 if k_key else 0) + n * bits / 8 + 8 * n / group
+        b_sel = 2 * n + BH * D * 2 * k_key * 6 + n / 8
+        b_main = 2 * n + n / 8 * (1 if k_key else 0) + n * bits / 8 + 4 * n / group
         kernels.append({"kernel": "k_select_kernel + k_select_fix_kernel (K: per-channel outlier selection over T, token-major input)",
                         "ms": ms_sel, "alg_bytes": b_sel})
         kernels.append({"kernel": f"k_main_kernel<{bits}, 1, {group}, float, ...> (K: fused fill + quantize + pack + Gram on the matrix cores)",
@@ -557,25 +576,38 @@ def main():
         kx["achieved"] = kx["alg_bytes"] / (kx["ms"] * 1e-3) / 1e9 if kx["ms"] else None
         kx["frac"] = kx["achieved"] / HBM_PEAK_GBS if kx["ms"] else None
     dom = max(kernels[:3], key=lambda kx: kx["ms"])
-    # HBM bytes from PMC counters: only from a profile taken on exactly this library (profiles/r4_traffic.json)
-    traffic, tnote = None, "no profile for this library build"
-    tp = os.path.join(ROOT, "profiles", "r4_traffic.json")
-    if os.path.exists(tp) and world == 1 and not args.layers and not args.emulate_world:
-        prof = json.load(open(tp))
-        if prof.get("lib_sha256") == lib_sha256() and prof.get("config") == args.config:
+    # HBM bytes from PMC counters and in-step kernel durations: only from a profile taken on exactly this library (the newest
+    # profiles/r*_traffic.json whose lib_sha256 is the loaded library's; tools/make_traffic.py writes it)
+    import glob
+    traffic, tnote, prof, dom_step_us = None, "no profile for this library build", {}, None
+    if world == 1 and not args.layers and not args.emulate_world:
+        sha = lib_sha256()
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            cand = json.load(open(tp))
+            if cand.get("lib_sha256") == sha and cand.get("config") == args.config:
+                prof, tname = cand, os.path.relpath(tp, ROOT)
+                break
+        if prof:
             base = dom["kernel"].split(" ")[0].split("<")[0]       # compress_rows_wave_kernel / compress_rows_fp32_kernel / k_select_kernel / k_main_kernel
-            hit = [tb for kname, tb in prof.get("kernels", {}).items()
-                   if kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")]
+            same = lambda kname: kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")
+            hit = [tb for kname, tb in prof.get("kernels", {}).items() if same(kname)]
             # (both instantiations of the wave-per-row kernel -- fast and fallback pass -- share the base name and are added up)
             if hit:
-                traffic, tnote = float(sum(hit)), f"profiles/r4_traffic.json ({prof.get('how', '')})"
+                traffic, tnote = float(sum(hit)), f"{tname} ({prof.get('how', '')})"
+            st = [us for kname, us in prof.get("bench_step_avg_us", {}).items() if same(kname)]
+            dom_step_us = float(sum(st)) if st else None
         else:
-            tnote = "profiles/r4_traffic.json was measured on a different library build / config"
+            tnote = "no profiles/r*_traffic.json was measured on this library build / config"
     dominant = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac"], "traffic": traffic, "traffic_source": tnote, "alg_bytes_per_launch": dom["alg_bytes"],
                 "ms_per_launch": dom["ms"],
-                "note": "timed alone, back to back on one stream; inside the bench step the K and V chains share the chip on two "
-                        "streams and the same kernel takes longer (profiles/r4_kernel_stats_bench.md vs r4_kernel_stats_isolated.md)"}
+                # the same kernel inside the two-stream bench step (rocprofv3 trace of this command, average per launch, all of
+                # its instantiations): the K and V chains share the chip there
+                "ms_per_launch_in_step": dom_step_us / 1e3 if dom_step_us else None,
+                "frac_in_step": dom["alg_bytes"] / (dom_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS if dom_step_us else None,
+                "note": "ms_per_launch: timed alone, back to back on one stream (HIP events); ms_per_launch_in_step: from the "
+                        "rocprofv3 kernel trace of the bench step (profiles/*_kernel_stats_bench.md), null without a profile of "
+                        "exactly this library"}
     # the headline roofline object is what north_star names -- the fused K / V quant + low-rank + outlier COMPRESS, i.e. the chain
     # of launches per tensor kind -- not its fastest member: the chain with the lower fraction
     cname = min(("k_compress", "v_compress"), key=lambda c: chain[c]["frac"])
@@ -593,10 +625,10 @@ def main():
                 "v_compress": "compress_rows_wave_kernel (fast + fallback pass) + lr_gram_wave_kernel + k_solve_kernel + lr_qpass_tm_mfma_kernel"}
     roofline = {"bound": "hbm", "kernel": f"{cname} chain: {launches[cname]}", "achieved": chain[cname]["achieved"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chain[cname]["frac"], "traffic": chain_traffic,
-                "traffic_source": tnote + " (sum over the chain's kernels; per kernel: profiles/r4_pmc_traffic.md)",
+                "traffic_source": tnote + " (sum over the chain's kernels; per kernel: the *_pmc_traffic.md beside it)",
                 "alg_bytes_per_launch": chain[cname]["alg_bytes"],
                 "ms_per_launch": chain[cname]["ms"], "launch": "one chain = one call of gear_compress_%s_fused over all layers" % ("key" if cname == "k_compress" else "value"),
-                "bytes_definition": "SURVEY.md 8(d): read 2n + codes n*b/8 + scale/mn 8n/g + factors + outliers; no error term",
+                "bytes_definition": "SURVEY.md 8(d) verbatim: read 2n + codes n*b/8 + scale/mn 4n/g + factors 2r(T+D) per head + 6 bytes per outlier; no error term (stored_bytes in roofline_chain = what the build writes: fp32 scale/mn, uint16 indices)",
                 "dominant_kernel": dominant,
                 "spread": "the same binary measures within +-4 % from box to box (round-1 observation, DESIGN.md section 6)"}
 
@@ -635,6 +667,8 @@ def main():
         res = {
             "metric": "KV compress+decompress GB/s (fp16 KV bytes through compress + through decompress per second)",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # untimed steps IN FRONT of the `warmup` steps of the contract (device clocks / power state; --prewarm-s 0 = none)
+            "prewarm_steps": prewarm_steps, "prewarm_s": round(prewarm_seconds, 3),
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 arithmetic on fp16 data, int%d payload" % bits, "data": "synthetic",
             "config": {"workload": f"{cfg['model']} KV cache, {layers} layers x {H} KV heads x T={T} x D={D}, "
@@ -646,6 +680,9 @@ def main():
             "compress_GBps": fp16_bytes_job / ((stages["k_compress"] + stages["v_compress"]) * 1e-3) / 1e9,
             "decompress_GBps": fp16_bytes_job / ((stages["k_decompress"] + stages["v_decompress"]) * 1e-3) / 1e9,
             "stage_ms": stages,
+            "timing_note": "value / ms_per_step: wall time of steps whose K and V chains overlap on %d HIP streams; stage_ms, "
+                           "compress_GBps, decompress_GBps and roofline_chain: a separate serial pass, one chain at a time "
+                           "(their sum exceeds ms_per_step)" % n_str,
             "payload_ratio": payload_ratio,
             "attn_decode": {"ms_per_token_all_layers": attn_ms, "compressed_GBps": payload_bytes_job / (attn_ms * 1e-3) / 1e9,
                             "fp16_equiv_GBps": fp16_bytes_job / (attn_ms * 1e-3) / 1e9,

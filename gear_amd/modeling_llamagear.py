@@ -212,11 +212,27 @@ class GearHookCache:
     when somebody indexes it -- slices of the cache tensors with the lengths this step had, the factor lists re-shaped into the
     reference's [prefill, stacked [nbuf,B,H,.,r]] form.  The attention hook recognises the object and takes its fast decode path
     (window append in place, ONE fused attention call over the packed cache, compress of a full window in place): no torch.cat of
-    the payload, no per-token GEMV pair + eager softmax.  len() == 17, iteration and indexing behave like the tuple."""
+    the payload, no per-token GEMV pair + eager softmax.  len() == 17, iteration and indexing behave like the tuple.
+
+    SINGLE USE.  Unlike the reference's tuple (immutable: an earlier `past` can be fed again, rolled back to, or branched from, as
+    assisted / beam decoding do), the object is a view of ONE cache that every decode step mutates in place.  A decode step
+    consumes the object it was given and returns a new one; the consumed one (and every older one) is stale: using it again --
+    as `past_key_value`, through indexing or materialize() -- raises GearError instead of silently attending over an extra
+    token at a wrong position.  A caller that needs to branch calls materialize() BEFORE the step and continues on the tuple."""
 
     def __init__(self, cache, lowrank: bool, seq_len: int):
         self.cache, self.lowrank = cache, lowrank
         self.n_comp, self.n_win, self.seg0, self.seq_len = cache.n_comp, cache.n_win, cache.seg0, seq_len
+        # generation of the shared cache this view belongs to: every mutation (append / block compress) moves the cache on
+        self.gen = cache.hook_gen = getattr(cache, "hook_gen", 0) + 1
+
+    def check_live(self):
+        """Raise unless this is the newest view of its cache (see the class docstring)."""
+        c = self.cache
+        if getattr(c, "hook_gen", self.gen) != self.gen or (c.n_comp, c.n_win) != (self.n_comp, self.n_win):
+            raise L.GearError("GearHookCache: this past_key_value was already consumed by a decode step (the cache behind it is "
+                              "mutated in place); re-using, rolling back to or branching from an earlier past needs "
+                              "materialize() before the step that consumes it")
 
     def __len__(self):
         return 17
@@ -250,6 +266,7 @@ class GearHookCache:
         c, n, w = self.cache, self.n_comp, self.n_win
         if i == 8:
             return self.seq_len
+        self.check_live()                                  # (slot 8 is a plain int and stays readable)
         if i in (11, 12, 15, 16):
             return None
         if i in (1, 5):
@@ -385,7 +402,13 @@ class LlamaAttention_GEAR(nn.Module):
         cc = self.compress_config
         B, T = key_states.shape[0], key_states.shape[-2]
         R = self.residual_length
-        cap = max(int(getattr(self.config, "max_position_embeddings", 4096)), T + R)
+        # capacity: the prompt + the tokens the caller expects to generate (config.gear_max_new_tokens, default 1024), NOT the
+        # model's whole context window -- the buffers scale with batch x capacity (zero-filled: tile counts, factor segments), and
+        # a short prompt at a large batch would otherwise pay for 16k tokens per sequence and layer.  A cache that fills up hands
+        # over to the tuple path (materialize(), forward below), as before.
+        room = max(R, int(getattr(self.config, "gear_max_new_tokens", 1024)))
+        cap = min(T + room, max(int(getattr(self.config, "max_position_embeddings", 4096)), T + R))
+        cap = -(-cap // 128) * 128
         # (the hook stores no outliers -- slots 11, 12, 15, 16 are None in the reference's fused path -- so a sparsity in the config,
         # the simulated path's `left`, does not reach the cache)
         c = GearKVCache(B, self.num_key_value_heads, min(cap, 16384), dict(cc, left=0.0, sparsity=0.0), key_states.device,
@@ -421,6 +444,7 @@ class LlamaAttention_GEAR(nn.Module):
         the packed cache, compress of a full window in place.  Returns (res + delta, attention output [B, Hq * 128], new cache) or
         None when the cache is full (the caller takes the tuple path)."""
         c = hc.cache
+        hc.check_live()
         if c.n_comp + c.n_win + 1 > c.Tmax:
             return None
         B, K = res.shape
@@ -443,6 +467,7 @@ class LlamaAttention_GEAR(nn.Module):
         """One token over the pre-allocated cache: window append, fused attention (packed K / V + factors + fp16 window: one call of
         gear_attn_decode_cache where the tuple path runs two GEMV pairs, the eager softmax and ~40 small ops), compress of a full window."""
         c = hc.cache
+        hc.check_live()
         if c.n_comp + c.n_win + 1 > c.Tmax:
             return None                                  # capacity: the caller continues on the tuple path
         if qkv_flat is not None:

@@ -5,8 +5,10 @@ The reference has no distributed code at all; this is the 
 BASELINE.json's 1/2/4/8-GPU rows:
   * KV heads are split contiguously across ranks; every quantization group, low-rank factor pair and K outlier row
     lives inside one head, so compress / decompress need no communication.  The one exception is the simulated
-    path's V outlier selection, a top-k over the whole token row ACROSS heads (compress_function.py:304-311): a shard
-    selects k / world per side inside its own heads (documented divergence for world > 1; exact for world == 1).
+    path's V outlier selection, a top-k over the whole token row ACROSS heads (compress_function.py:304-311): the shards
+    run the EXACT selection (exact_v_selection below: one small all-gather of per-row candidates, after which the
+    concatenated shard payloads are the unsharded payload bit for bit); v_selection="per_shard" (k / world inside the
+    shard's own heads, rounds 1-3) remains as an option and as the only mode without a process group.
   * softmax is per head, so attention is local; the only exchange is an all-gather of the per-rank attention output
     [B, q, H_local*D] (a few KiB per layer per token: latency-bound single hop over xGMI), after which every rank
     applies the replicated o_proj.

@@ -35,8 +35,72 @@ class CompressionConfig(dict):
             setattr(self, name, self.create_attention_config(getattr(self, name)))
         self._broadcast = True
 
+    # ---- the reference's analytic ratio bookkeeping (compress_config.py:87-281; called by the GenerationBench drivers, e.g.
+    #      evaluation_gsm8k.py:407 `calculate_compress_ratio_list(4095, 4096)`).  It knows the LEGACY method names only; for the
+    #      methods of today's dispatcher (KIVI_V2, KCVT, GEAR*, GEARL*) the reference's if / elif chain matches nothing: the
+    #      function returns None and the list gets no entry -- kept as is (payload_ratio below is the build's own figure for them).
+    @staticmethod
+    def _ratio_terms(seqlen, model_dim, batch_num):
+        n_tok = seqlen * batch_num                       # token rows of the [n_tok, model_dim] matrix being approximated
+        return n_tok, n_tok * model_dim, model_dim + n_tok
+
+    def compress_ratio(self, compress_method, seqlen, model_dim, rank=0, rankv=0, quantize_bit=0, top_k=0, left=0.0, stage=1,
+                       batch_num=1):
+        """fp16 elements per stored element for one layer (None for a method name the table does not know, as in the
+        reference).  Same arguments, same arithmetic order of magnitude by magnitude as compress_config.py:87-186."""
+        if compress_method is None:
+            return 1.0
+        n_tok, dense, fac = self._ratio_terms(seqlen, model_dim, batch_num)
+        m = compress_method
+        if m == "Picache":               # K and V each as rank-r factors, quantized (:104-148)
+            if seqlen > rank and seqlen > rankv:
+                return 2 * dense / (fac * (rank + rankv) * quantize_bit / 16)
+            if seqlen <= rank:           # K kept dense
+                return 2 * dense / (fac * rankv + dense) * 16 / quantize_bit
+            if seqlen <= rankv:          # V kept dense
+                return 2 * dense / (fac * rank + dense) * 16 / quantize_bit
+            return None
+        if m == "poweriteration":
+            return dense / (fac * rank)
+        if m == "stagept":
+            return dense / (model_dim * rank + n_tok * (rank / stage))
+        if m in ("uniformquantization", "groupquantization", "sortquantization"):
+            return 16 / quantize_bit
+        if m == "pruning":
+            return 1 / top_k
+        if m in ("densesparseuniformquantization", "densesparsesortquantization"):
+            return 1 / (quantize_bit / 16 + left)
+        if m == "pt+outlier":
+            return dense * 16 / quantize_bit / (fac * rank)
+        return None
+
+    # which per-layer fields each legacy method hands to compress_ratio (compress_config.py:188-278)
+    _RATIO_ARGS = {
+        "Picache": ("rank", "rankv", "quantize_bit", "left"), "poweriteration": ("rank",), "stagept": ("rank", "stage"),
+        "uniformquantization": ("quantize_bit",), "groupquantization": ("quantize_bit",), "sortquantization": ("quantize_bit",),
+        "pruning": ("top_k",), "densesparseuniformquantization": ("quantize_bit", "left"),
+        "densesparsesortquantization": ("quantize_bit", "left"), "pt+outlier": ("rank", "quantize_bit", "left"),
+    }
+    _RATIO_BATCHED = ("Picache", "poweriteration", "stagept", "pt+outlier")      # (these also receive batch_num)
+
+    def calculate_compress_ratio_list(self, seqlen, model_dim):
+        """Per-layer ratios into self.compress_ratio_list (needs copy_for_all_attention() first, like the reference)."""
+        self.compress_ratio_list = []
+        for i, method in enumerate(self.compress_method):
+            if method is None:
+                self.compress_ratio_list.append(self.compress_ratio(method, seqlen, model_dim))
+            elif method in self._RATIO_ARGS:
+                kw = {f: getattr(self, f)[i] for f in self._RATIO_ARGS[method]}
+                if method in self._RATIO_BATCHED:
+                    kw["batch_num"] = self.batch_num
+                self.compress_ratio_list.append(self.compress_ratio(method, seqlen, model_dim, **kw))
+            # (any other name: no entry -- the reference's chain has no else)
+
+    def calculate_compress_ratio_total(self):
+        return sum(self.compress_ratio_list) / len(self.compress_ratio_list)
+
     # ---- bookkeeping: bytes of the REAL payload the build stores, per fp16 KV byte (the reference's
-    #      compress_ratio, compress_config.py:87-, covers only its legacy method names)
+    #      compress_ratio above covers only its legacy method names)
     def payload_ratio(self, layer_idx, B, H, T, D):
         g = lambda f: getattr(self, f)[layer_idx] if self._broadcast else getattr(self, f)  # noqa: E731
         method, bits, gs = g("compress_method"), g("quantize_bit"), g("group_size")

@@ -73,3 +73,25 @@ def test_pack_unpack_tensor_format(golden):
     assert np.array_equal(new_pack.unpack_tensor(torch.from_numpy(f["raw4_pack3"]), 4, 3).numpy(), f["raw4_unpack3"])
     assert np.array_equal(new_pack.pack_tensor(raw & 3, 2, 3).numpy(), f["raw2_pack3"])
     assert np.array_equal(new_pack.pack_tensor(raw & 3, 2, 2).numpy(), f["raw2_pack2"])
+
+
+def test_compression_config_ratio_bookkeeping_matches_the_reference():
+    """compress_ratio / calculate_compress_ratio_list / calculate_compress_ratio_total (compress_config.py:87-281; the GenerationBench
+    drivers call them right after building the config: evaluation_gsm8k.py:407) against fixture F11, made by executing the
+    reference's class: every legacy method name, the dense-K / dense-V corners of "Picache", and today's dispatcher names, for
+    which the reference appends nothing and the total divides by zero."""
+    import json
+    import os
+    from gear_amd.simulated import CompressionConfig
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "f11_compress_ratio.json")))
+    assert len(cases) == 75
+    for c in cases:
+        cfg = CompressionConfig(**c["kwargs"])
+        cfg.copy_for_all_attention()
+        cfg.calculate_compress_ratio_list(c["seqlen"], c["model_dim"])
+        assert cfg.compress_ratio_list == c["list"], c["kwargs"]
+        if c["total"] == "zde":
+            with pytest.raises(ZeroDivisionError):
+                cfg.calculate_compress_ratio_total()
+        else:
+            assert cfg.calculate_compress_ratio_total() == c["total"]

@@ -35,6 +35,16 @@ for n in fetch:
     rows.append((n, f, w))
     short = re.sub(r"<.*", "", n)
     out["kernels"][n[:60]] = f + w
+# average duration of the same kernels INSIDE the two-stream bench step (kernel_stats_bench.md of the same collection: the rocprofv3
+# trace of `python bench.py`, whose launches are overwhelmingly the step's) -- bench.py's roofline.dominant_kernel.ms_per_launch_in_step
+import os
+ksb = f"{src}/kernel_stats_bench.md"
+if os.path.exists(ksb):
+    out["bench_step_avg_us"] = {}
+    for ln in open(ksb):
+        m = re.match(r"\| `([^`]+)` \| (\d+) \| ([0-9.]+) \|", ln)
+        if m and m.group(1).startswith(("compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "decompress_rows")):
+            out["bench_step_avg_us"][m.group(1)[:60]] = float(m.group(3))
 json.dump(out, open(f"{dst}_traffic.json", "w"), indent=1)
 with open(f"{dst}_pmc_traffic.md", "w") as fmd:
     fmd.write(f"# HBM traffic per launch (PMC), config {config}, library {out['lib_sha256'][:12]}\n\n{out['how']}\n\n"
