@@ -45,6 +45,7 @@ SIGNATURES = {
     "gear_decompress_rows": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _i,
                                   _vp, _vp, _i, _vp, _vp]),
     "gear_attn_decode_workspace": (_sz, [_i, _i, _i, _i]),
+    "gear_attn_decode_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _vp, _vp, _vp, _sz, _vp]),
     "gear_attn_decode": (_i, [_vp] * 17 + [_i] * 18 + [C.c_float, _vp, _vp, _vp, _sz, _vp]),
     "gear_attn_decode_seg": (_i, [_vp] * 17 + [_i] * 21 + [C.c_float, _vp, _vp, _vp, _sz, _vp]),
     "gear_attn_decode_dyn": (_i, [_vp] * 17 + [_i] * 21 + [_vp, C.c_float, _vp, _vp, _vp, _sz, _vp]),

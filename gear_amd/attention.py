@@ -56,3 +56,24 @@ def decode_attention(q: torch.Tensor, pk: Optional[Payload], pv: Optional[Payloa
                                   1.0 / math.sqrt(D), p(out), p(lse), p(ws), wsb, L.stream_ptr())
     L.check(rc, "gear_attn_decode")
     return (out, lse) if return_lse else out
+
+
+def decode_attention_f16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, T: Optional[int] = None, return_lse: bool = False):
+    """The uncompressed baseline (the reference harness's model "None", cuda_supported_gear/test.py:41-62): q fp16 [B,Hq,1,128] over
+    an fp16 cache k, v [B,Hkv,tcap,128] whose first T tokens are valid (default: all).  Same split / merge kernels and the same
+    grouped-query mapping as decode_attention, so the two times are comparable."""
+    assert q.dim() == 4 and q.shape[2] == 1 and q.dtype == torch.float16 and k.dtype == torch.float16 and k.shape == v.shape
+    B, Hq, _, D = q.shape
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    L.require_gpu(q, k, v)
+    Hkv, tcap = k.shape[1], k.shape[2]
+    T = tcap if T is None else T
+    lib = L.load()
+    out = torch.empty((B, Hq, 1, D), dtype=torch.float16, device=q.device)
+    lse = torch.empty((B, Hq), dtype=torch.float32, device=q.device) if return_lse else None
+    wsb = lib.gear_attn_decode_workspace(B, Hq, T, 2)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
+    rc = lib.gear_attn_decode_f16(L.ptr(q), L.ptr(k), L.ptr(v), B, Hq, Hkv, D, T, tcap, 1.0 / math.sqrt(D), L.ptr(out), L.ptr(lse),
+                                  L.ptr(ws), wsb, L.stream_ptr(q))
+    L.check(rc, "gear_attn_decode_f16")
+    return (out, lse) if return_lse else out

@@ -62,6 +62,10 @@ struct AttnArgs {
     int64_t kP_seg_stride, vP_seg_stride;
     const int* dyn;          // optional device state {pos, slot, T, W}: T and W are read from it (hipGraph replay)
     int tc, splits;
+    int pslots;              // partial-result slots per query head: splits, + 1 when the fp16 window rides along as one more chunk
+    const uint16_t* kwin;    // fp16 window [B*Hkv, wcap, 128] (only read by the window chunk of attn_decode_partial_small)
+    const uint16_t* vwin;
+    int W, wcap;
     float qscale;
     float* part_o;           // [B*Hq, splits, 128]
     float* part_w;           // [B*Hq, splits, 16]
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
     const int Tc = a.dyn ? a.dyn[2] : a.T;
     const int tn = min(a.tc, Tc - t0);  // tokens in this chunk
     if (tn <= 0) {                      // grid planned for the cache capacity: chunks beyond the current length
-        const int64_t pe = bhq * a.splits + split;
+        const int64_t pe = bhq * a.pslots + split;
         if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
         if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
         return;
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
-    const int64_t po = bhq * a.splits + split;
+    const int64_t po = bhq * a.pslots + split;
 #define WSUM(sl, c) ((wacc[0][sl][c] + wacc[1][sl][c]) + (wacc[2][sl][c] + wacc[3][sl][c]))
     if (tid < AD) {
         float o = oacc[tid];
@@ -447,6 +451,105 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(AttnArgs a) {
 // (deterministic; float atomics only in the outlier terms).
 constexpr int SC = 128;
 
+// fp16 attention over tn <= 128 consecutive tokens of ONE KV head (rows of 128 fp16 at kb / vb) for the NREP query heads that share
+// it: partial output, chunk maximum and exponent sum into slot `slot` of every head's partial arrays.  All 256 threads; every load of
+// the chunk (64 KB at 128 tokens: sixteen 16-byte loads per thread) is issued before the first barrier.  Used for the fp16 window of a
+// compressed cache -- one more chunk of the flash-decoding split, so that the reduce kernel only merges -- and, chunk after chunk,
+// for the UNCOMPRESSED fp16 cache that the reference's harness times beside the compressed models (cuda_supported_gear/test.py:41-62).
+// K: 8 threads per token (16 channels each), 32 tokens per pass; V: 16 threads per token row (8 channels each), 16 token subsets.
+template <int NREP>
+__device__ __forceinline__ void f16_chunk(const AttnArgs& a, const uint16_t* __restrict__ kb, const uint16_t* __restrict__ vb, int tn,
+                                          int64_t bhq0, int slot, float* __restrict__ s, float (*__restrict__ op)[AD],
+                                          float* __restrict__ red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tn <= 0) {
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            const int64_t pe = (bhq0 + r) * a.pslots + slot;
+            if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
+            if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
+        }
+        return;
+    }
+    const int part = tid & 7, j0 = tid >> 3;           // K: channels 16 part .., tokens j0 + 32 i
+    const int c8 = tid & 15, ts = tid >> 4;            // V: channels 8 c8 .., tokens ts + 16 i
+    uint4 kr[4][2], vr[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                      // (tokens past the chunk: the last row again, dropped below)
+        const uint4* pk = (const uint4*)(kb + (uint32_t)min(j0 + 32 * i, tn - 1) * AD + part * 16);
+        kr[i][0] = pk[0];
+        kr[i][1] = pk[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) vr[i] = *(const uint4*)(vb + (uint32_t)min(ts + 16 * i, tn - 1) * AD + c8 * 8);
+    uint4 qh[NREP][2];
+#pragma unroll
+    for (int r = 0; r < NREP; r++) {
+        const uint4* pq = (const uint4*)(a.q + (bhq0 + r) * AD + part * 16);
+        qh[r][0] = pq[0];
+        qh[r][1] = pq[1];
+    }
+#pragma unroll 1
+    for (int r = 0; r < NREP; r++) {
+        uint4 q0 = qh[0][0], q1 = qh[0][1];
+#pragma unroll
+        for (int rr = 1; rr < NREP; rr++) { if (r == rr) { q0 = qh[rr][0]; q1 = qh[rr][1]; } }
+        float qf[16];
+        unpack8(q0, qf);
+        unpack8(q1, qf + 8);
+#pragma unroll
+        for (int c = 0; c < 16; c++) qf[c] *= a.qscale;
+        if (r > 0) __syncthreads();                    // (the previous head's reads of s / op are done)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float t[8], acc = 0.0f;
+            unpack8(kr[i][0], t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc = fmaf(qf[c], t[c], acc);
+            unpack8(kr[i][1], t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc = fmaf(qf[8 + c], t[c], acc);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 1, 64);
+            if (part == 0) s[j0 + 32 * i] = acc;
+        }
+        __syncthreads();
+        const float sv = tid < tn ? s[min(tid, SC - 1)] : -INFINITY;
+        const float m = block_reduce_max(sv, red);
+        const float p = tid < tn ? __expf(sv - m) : 0.0f;
+        if (tid < SC) s[tid] = p;
+        const float l = block_reduce_sum(p, red);      // (contains the barrier that publishes s[])
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[c] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float pt = s[ts + 16 * i];           // (0 beyond the chunk)
+            float t[8];
+            unpack8(vr[i], t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc[c] = fmaf(pt, t[c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {                  // the wave's four token subsets (lane bits 4, 5)
+            acc[c] += __shfl_xor(acc[c], 16, 64);
+            acc[c] += __shfl_xor(acc[c], 32, 64);
+        }
+        if (lane < 16) {
+            *(float4*)&op[wave][c8 * 8] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4*)&op[wave][c8 * 8 + 4] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        __syncthreads();
+        const int64_t po = (bhq0 + r) * a.pslots + slot;
+        if (tid < AD) a.part_o[po * AD + tid] = (op[0][tid] + op[1][tid]) + (op[2][tid] + op[3][tid]);
+        if (tid == 0) {
+            a.part_ml[po * 2] = m;
+            a.part_ml[po * 2 + 1] = l;
+        }
+    }
+}
+
 // Halving butterfly over the lane bits TOP, TOP/2, ... (STEPS of them): on entry every lane holds N partial values, on exit
 // v[0 .. (N >> STEPS) - 1] hold the sums over the lane group of the values with index base + i, where
 // base = sum over steps k of (lane & (TOP >> k)) ? N >> (k + 1) : 0.  Returns base.
@@ -481,9 +584,18 @@ __device__ __forceinline__ float reduce8_over_wave(float (&v)[8], int lane) {
     return r;
 }
 
-template <int BITS, typename ST, bool R16>
+//
+// NREP > 1 (grouped-query attention): ONE workgroup serves all NREP query heads of a KV head -- grid (splits, B * Hkv) -- so the
+// chunk's codes, scale / zero point, factor rows and sparse-tile entries are loaded ONCE into registers and used NREP times
+// (the reference's `mqa` mapping reads the shared KV head once per query head: gemv_cuda.cu:276-279; before round 5 so did this
+// kernel -- 70B's 8 query heads per KV head read the compressed cache 8 times per token).  NREP == 1: one query head per workgroup,
+// grid (splits, B * Hq), any Hq / Hkv.
+// RS: factor row length in the payload (a.rk / a.rv are 0 or RS) -- 4, 8 or 16.  Rank 4 (BASELINE configs[1]) computes at width
+// 8 with the upper half zero: its rows are 8-byte loads.
+template <int BITS, typename ST, int RS, int NREP>
 __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
-    constexpr int RW = R16 ? 16 : 8;   // factor row width (a.rk / a.rv are 0 or RW)
+    constexpr bool R16 = RS == 16;
+    constexpr int RW = R16 ? 16 : 8;   // factor row width the arithmetic runs at
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     constexpr int NWC = SC / CPW;    // K: packed words per channel in the chunk (8 | 16) = lanes along tokens
@@ -502,20 +614,38 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     __shared__ float oacc[AD];
     __shared__ float wsl[2][RW];      // Qv^T p of the two slabs
     __shared__ float red[4];
+    __shared__ float ksp[SC];        // K outliers through the sparse tile: sum of q[d] (value - dequant) per token
+    __shared__ float vsp[AD];        // V outliers through the sparse tiles: sum of p[t] (value - dequant) per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x;
-    const int64_t bhq = blockIdx.y;
-    const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
-    const int hkv = hq / (a.Hq / a.Hkv);
+    int b, hkv;
+    int64_t bhq0;                      // first (NREP == 1: the only) query head of this workgroup
+    if (NREP == 1) {
+        bhq0 = blockIdx.y;
+        b = (int)(bhq0 / a.Hq);
+        hkv = (int)(bhq0 % a.Hq) / (a.Hq / a.Hkv);
+    } else {
+        b = (int)blockIdx.y / a.Hkv;
+        hkv = (int)blockIdx.y % a.Hkv;
+        bhq0 = (int64_t)b * a.Hq + (int64_t)hkv * NREP;
+    }
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    if (split == a.splits) {           // the extra workgroup of the row: the fp16 window as one more chunk (a.pslots == a.splits + 1)
+        const int Wn = a.dyn ? a.dyn[3] : a.W;
+        f16_chunk<NREP>(a, a.kwin + bhk * a.wcap * (int64_t)AD, a.vwin + bhk * a.wcap * (int64_t)AD, Wn, bhq0, a.splits, s, op, red);
+        return;
+    }
     const int t0 = split * SC;
     const int Tc = a.dyn ? a.dyn[2] : a.T;
     const int tn = min(SC, Tc - t0);
-    const int64_t po = bhq * a.splits + split;
     if (tn <= 0) {
-        if (tid < AD) a.part_o[po * AD + tid] = 0.0f;
-        if (tid == 0) { a.part_ml[po * 2] = -INFINITY; a.part_ml[po * 2 + 1] = 0.0f; }
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            const int64_t pe = (bhq0 + r) * a.pslots + split;
+            if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
+            if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
+        }
         return;
     }
     const ST* kscale = (const ST*)a.kscale;
@@ -528,7 +658,9 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     // factor segment of each 64-token slab: block-uniform (scalar) arithmetic, then a select by slab
     auto seg_at = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
     const int seg_s0 = seg_at(t0), seg_s1 = seg_at(min(t0 + 64, t0 + tn - 1));
-    const float qv = h2f_bits(a.q[bhq * AD + dq]) * a.qscale;
+    float qvr[NREP];                   // this thread's channel of every query head of the group
+#pragma unroll
+    for (int r = 0; r < NREP; r++) qvr[r] = h2f_bits(a.q[(bhq0 + r) * AD + dq]) * a.qscale;
     const int lw = tid & (NWC - 1), dsub = tid / NWC;
     const bool kval = lw * CPW < tn;
     // Addresses = uniform 64-bit base (head / chunk, scalar registers) + a 32-bit lane offset; lanes past the end of a partial
@@ -574,16 +706,20 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     // such blocks that stood here were four serialized memory round trips before the first score was computed (per-phase
     // timestamps: 9.4 of the workgroup's 16.8 us with outliers in the cache; 7.5 of 14.0 now).  The values are only looked at
     // under the same conditions further down.
-    const uint4* dummy16 = (const uint4*)(a.q + bhq * AD);
+    const uint4* dummy16 = (const uint4*)(a.q + bhq0 * AD);
     const uint8_t* dummy1 = (const uint8_t*)dummy16;
     const uint32_t trow = (uint32_t)min(tid, tn - 1);                       // (threads past the chunk read its last row)
     const int64_t fseg = slab ? (int64_t)seg_s1 : (int64_t)seg_s0;
-    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RW + (uint32_t)dq * RW) : dummy16;
-    const uint4* kqp = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RW + trow * RW) : dummy16;
-    const uint4* vpp = a.rv ? (const uint4*)(a.vP + fseg * a.vP_seg_stride + bhk * AD * RW + (uint32_t)dq * RW) : dummy16;
-    const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RW + trow * RW) : dummy16;
-    const uint4 kp8 = kpp[0], kq8 = kqp[0], vp8 = vpp[0], vq8 = vqp[0];
-    const uint4 kp8b = kpp[R16 ? 1 : 0], kq8b = kqp[R16 ? 1 : 0], vp8b = vpp[R16 ? 1 : 0], vq8b = vqp[R16 ? 1 : 0];   // columns 8..15 (rank 16)
+    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    const uint4* kqp = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RS + trow * RS) : dummy16;
+    const uint4* vpp = a.rv ? (const uint4*)(a.vP + fseg * a.vP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RS + trow * RS) : dummy16;
+    auto ldrow = [](const uint4* p) {                  // one factor row: 16 bytes, or 8 (rank 4) with zeros above
+        if (RS == 4) { const uint2 t = *(const uint2*)p; return make_uint4(t.x, t.y, 0u, 0u); }
+        return p[0];
+    };
+    const uint4 kp8 = ldrow(kpp), kq8 = ldrow(kqp), vp8 = ldrow(vpp), vq8 = ldrow(vqp);
+    const uint4 kp8b = R16 ? kpp[1] : kp8, kq8b = R16 ? kqp[1] : kq8, vp8b = R16 ? vpp[1] : vp8, vq8b = R16 ? vqp[1] : vq8;   // columns 8..15 (rank 16)
 
     // outlier list ranges of this chunk (chunk index present): K list (channel dq, side tid >> 7), V list (token tid & 127,
     // side tid >> 7) -- two byte loads each, issued with everything else
@@ -602,6 +738,23 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     const int kc_raw = kcp[0], vc_raw0 = vcp[0], vc_raw1 = vcp[1];
     const uint32_t ke0 = ktp[0], ke1 = ktp[has_ktile ? 256 : 0], ve0 = vtp[0], ve1 = vtp[has_vtile ? a.vtile_cap : 0];
 
+    // everything below runs once per query head of the group on the registers loaded above (a rolled loop: the code stays at
+    // its one-head size, which is what a cold instruction cache charges for)
+#pragma unroll 1
+    for (int r = 0; r < NREP; r++) {
+    float qv = qvr[0];
+#pragma unroll
+    for (int rr = 1; rr < NREP; rr++) qv = (r == rr) ? qvr[rr] : qv;
+    const int64_t po = (bhq0 + r) * a.pslots + split;
+    if (NREP > 1 && r > 0) __syncthreads();          // (the previous head's reads of the LDS arrays are done)
+    // Outliers through the sparse tiles (the streaming cache's normal case) ride on the barriers the dense path has anyway: the
+    // K entries are added into ksp[] while the dense scores are being computed, the V entries into vsp[] while the dense V products
+    // are (round 4 parked the scores in LDS, added, and read them back: four barriers and two exposed rounds of LDS atomics;
+    // 21.1 -> see DESIGN.md section 6).  Tiles that overflowed (count -1) and payloads without tiles take the list paths below.
+    const bool ktile_ok = a.kk > 0 && has_ktile && kc_raw >= 0;
+    const bool vtile_ok = a.kv > 0 && has_vtile && vc_raw0 >= 0 && (tn <= 64 || vc_raw1 >= 0);
+    if (tid < SC) ksp[tid] = 0.0f;
+    if (tid < AD) vsp[tid] = 0.0f;
     // ------------------------------------------------------------------ 1. scores
     if (tid < AD) qs[tid] = qv;
     if (a.rk) {   // up[wave][:] = sum over this wave's 64 channels of q[d] Pk[seg(slab)][d][:]
@@ -620,6 +773,16 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         }
     }
     __syncthreads();
+    if (ktile_ok) {   // chunk-major tile: ksp[t] += q[d] * (value - dequant), entries prefetched with everything else
+        const int kc_n = kc_raw;
+        if (tid < kc_n) atomicAdd(&ksp[(ke0 >> 7) & 127u], qs[ke0 & 127u] * h2f_bits((uint16_t)(ke0 >> 16)));
+        if (tid + 256 < kc_n) atomicAdd(&ksp[(ke1 >> 7) & 127u], qs[ke1 & 127u] * h2f_bits((uint16_t)(ke1 >> 16)));
+        const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
+        for (int e = tid + 512; e < kc_n; e += 256) {
+            const uint32_t ke = kt[e];
+            atomicAdd(&ksp[(ke >> 7) & 127u], qs[ke & 127u] * h2f_bits((uint16_t)(ke >> 16)));
+        }
+    }
     {
         float acc[CPW];
 #pragma unroll
@@ -654,21 +817,13 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
             }
             v += acc;
         }
+        if (ktile_ok) v += ksp[tid];
         sv = v;
     }
-    if (a.kk > 0) {   // K outliers inside the chunk: s[t] += q[d] (val - dequant(t, d))
+    if (a.kk > 0 && !ktile_ok) {   // K outliers inside the chunk through the lists: s[t] += q[d] (val - dequant(t, d))
         if (tid < SC) s[tid] = sv;
         __syncthreads();
-        const int kc_n = has_ktile ? kc_raw : -1;
-        if (kc_n >= 0) {   // chunk-major tile: s[t] += q[d] * (value - dequant), entries prefetched above
-            if (tid < kc_n) atomicAdd(&s[(ke0 >> 7) & 127u], qs[ke0 & 127u] * h2f_bits((uint16_t)(ke0 >> 16)));
-            if (tid + 256 < kc_n) atomicAdd(&s[(ke1 >> 7) & 127u], qs[ke1 & 127u] * h2f_bits((uint16_t)(ke1 >> 16)));
-            const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
-            for (int e = tid + 512; e < kc_n; e += 256) {
-                const uint32_t ke = kt[e];
-                atomicAdd(&s[(ke >> 7) & 127u], qs[ke & 127u] * h2f_bits((uint16_t)(ke >> 16)));
-            }
-        } else {   // one sorted list per (channel, side) = per thread; its entries inside the chunk are [i0, i1)
+        {   // one sorted list per (channel, side) = per thread; its entries inside the chunk are [i0, i1)
             const int side = tid >> 7;
             const int64_t list = (bhk * AD + dq) * 2 + side;
             const uint16_t* oi = a.koidx + list * (int64_t)a.kk_stride;
@@ -722,6 +877,19 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     if (tid < SC) s[tid] = p;
     const float l = block_reduce_sum(p, red);   // (contains the barrier that publishes s[])
     // ------------------------------------------------------------------ 3. V side
+    if (vtile_ok) {   // block tiles: vsp[d] += p[t] * (value - dequant); read after the barriers of the dense part below
+        const int vc_n0 = vc_raw0, vc_n1 = (tn > 64) ? vc_raw1 : 0;
+        if (tid < vc_n0) atomicAdd(&vsp[(ve0 >> 6) & 127u], s[ve0 & 63u] * h2f_bits((uint16_t)(ve0 >> 16)));
+        if (tid < vc_n1) atomicAdd(&vsp[(ve1 >> 6) & 127u], s[64 + (ve1 & 63u)] * h2f_bits((uint16_t)(ve1 >> 16)));
+        for (int hb = 0; hb < 2; hb++) {   // tiles longer than one entry per thread (rare)
+            const int n = hb ? vc_n1 : vc_n0;
+            const uint32_t* vt = a.vtile + (bhk * a.nblk + 2 * split + hb) * (int64_t)a.vtile_cap;
+            for (int e = tid + 256; e < n; e += 256) {
+                const uint32_t ve = vt[e];
+                atomicAdd(&vsp[(ve >> 6) & 127u], s[64 * hb + (ve & 63u)] * h2f_bits((uint16_t)(ve >> 16)));
+            }
+        }
+    }
     {
         float acc[CPW];
 #pragma unroll
@@ -773,24 +941,13 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     if (tid < AD) {
         o = (op[0][tid] + op[1][tid]) + (op[2][tid] + op[3][tid]);
         if (a.rv) o += ot[0][tid] + ot[1][tid];
+        if (vtile_ok) o += vsp[tid];
     }
-    if (a.kv > 0) {   // V outliers of the chunk's tokens that fall into this head's 128 columns
+    if (a.kv > 0 && !vtile_ok) {   // V outliers of the chunk's tokens that fall into this head's 128 columns, through the lists
         if (tid < AD) oacc[tid] = o;
         __syncthreads();
         const int tok = tid & (SC - 1), side = tid >> 7;   // one sorted list per (token, side) = per thread
-        const int vc_n0 = has_vtile ? vc_raw0 : -1, vc_n1 = has_vtile ? ((tn > 64) ? vc_raw1 : 0) : -1;
-        if (vc_n0 >= 0 && vc_n1 >= 0) {   // block tiles: o[d] += p[t] * (value - dequant)
-            if (tid < vc_n0) atomicAdd(&oacc[(ve0 >> 6) & 127u], s[ve0 & 63u] * h2f_bits((uint16_t)(ve0 >> 16)));
-            if (tid < vc_n1) atomicAdd(&oacc[(ve1 >> 6) & 127u], s[64 + (ve1 & 63u)] * h2f_bits((uint16_t)(ve1 >> 16)));
-            for (int hb = 0; hb < 2; hb++) {   // tiles longer than one entry per thread (rare)
-                const int n = hb ? vc_n1 : vc_n0;
-                const uint32_t* vt = a.vtile + (bhk * a.nblk + 2 * split + hb) * (int64_t)a.vtile_cap;
-                for (int e = tid + 256; e < n; e += 256) {
-                    const uint32_t ve = vt[e];
-                    atomicAdd(&oacc[(ve >> 6) & 127u], s[64 * hb + (ve & 63u)] * h2f_bits((uint16_t)(ve >> 16)));
-                }
-            }
-        } else if (tok < tn) {
+        if (tok < tn) {
             const int c_lo = hkv * AD, c_hi = c_lo + AD;
             const int ngv = AD / a.group;
             const int64_t orow = (int64_t)b * a.tcap_v + t0 + tok;
@@ -839,28 +996,33 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         a.part_ml[po * 2] = m;
         a.part_ml[po * 2 + 1] = l;
     }
+    }   // query heads of the group
 }
 
-// merge the splits + the fp16 window, normalise.  grid (B*Hq), block 512 = 4 groups x 128 channels: the groups share the
-// splits / window rows between them so that every thread's loads are one batch (the whole kernel is a latency chain).
+// merge the splits (+ the fp16 window, unless it came as one more chunk: a.pslots == a.splits + 1, W_arg == 0), normalise.
+// grid (B*Hq), block 512 = 4 groups x 128 channels: the groups share the splits / window rows between them so that every
+// thread's loads are one batch (the whole kernel is a latency chain).  Up to 65 partial slots (64 chunks + the window chunk).
+constexpr int RS_MAX = 66;
 __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, const uint16_t* __restrict__ kwin,
                                                                  const uint16_t* __restrict__ vwin, int W_arg, int wcap,
                                                                  uint16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ float qs[AD];
     __shared__ float sw[128];
-    __shared__ float coef[64 + 128];  // per split, then per window token
+    __shared__ float sml[2][RS_MAX];          // per slot: chunk maximum, exponent sum
+    __shared__ float coef[RS_MAX + 128];      // per slot, then per window token
     __shared__ float og[4][AD];
     __shared__ float stat[2];
     const int tid = threadIdx.x, d = tid & (AD - 1), grp = tid >> 7;
-    int W = W_arg;
+    const bool win_here = a.pslots == a.splits;        // the window is this kernel's job (rounds 1-4; the generic partial kernel)
+    int W = win_here ? W_arg : 0;
     const int64_t bhq = blockIdx.x;
     const int b = (int)(bhq / a.Hq), hq = (int)(bhq % a.Hq);
     const int hkv = hq / (a.Hq / a.Hkv);
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
-    if (a.dyn) W = a.dyn[3];
-    const int ns = (a.dyn || a.T > 0) ? a.splits : 0;
-    // loads that depend on nothing: q, this thread's 16 channels of window tokens tid / 8 and 64 + tid / 8 (the window holds up
-    // to 128 tokens: the KIVI default residual_length), the split statistics
+    if (a.dyn && win_here) W = a.dyn[3];
+    const int ns = (a.dyn || a.T > 0) ? a.pslots : 0;
+    // loads that depend on nothing: the split statistics, the first partial outputs of this thread (the ones the final sum
+    // starts with), q and -- window here -- this thread's 16 channels of window tokens tid / 8 and 64 + tid / 8
     const int j = tid >> 3, part = tid & 7;
     uint4 k0 = {0, 0, 0, 0}, k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
     if (j < W) {
@@ -875,12 +1037,22 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
     }
     float mi = -INFINITY, li = 0.0f;
     if (tid < ns) {
-        mi = a.part_ml[(bhq * a.splits + tid) * 2];
-        li = a.part_ml[(bhq * a.splits + tid) * 2 + 1];
+        mi = a.part_ml[(bhq * a.pslots + tid) * 2];
+        li = a.part_ml[(bhq * a.pslots + tid) * 2 + 1];
     }
-    if (tid < AD) qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
-    __syncthreads();
-    {   // window scores: 8 threads per token, two tokens per thread group
+    // partial outputs of slots grp, grp + 4, ... (17 per thread at most): issued now, used after the statistics
+    constexpr int NPO = (RS_MAX + 3) / 4;
+    float po_r[NPO];
+#pragma unroll
+    for (int i = 0; i < NPO; i++) {
+        const int sl = grp + 4 * i;
+        po_r[i] = a.part_o[(bhq * a.pslots + min(sl, max(ns - 1, 0))) * AD + d];       // (clamped: every load unconditional)
+    }
+    if (tid < RS_MAX) { sml[0][tid] = mi; sml[1][tid] = li; }
+    if (W > 0) {                                            // (block-uniform)
+        if (tid < AD) qs[tid] = h2f_bits(a.q[bhq * AD + tid]) * a.qscale;
+        __syncthreads();
+        // window scores: 8 threads per token, two tokens per thread group
         float t[8], acc = 0.0f, acc2 = 0.0f;
         unpack8(k0, t);
 #pragma unroll
@@ -906,29 +1078,36 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
         }
     }
     __syncthreads();
-    if (tid < 64) {   // softmax statistics over <= 64 splits and <= 128 window tokens: one split and two tokens per lane
+    if (tid < 64) {   // softmax statistics over <= 65 slots and <= 128 window tokens: two slots and two tokens per lane
+        const float m1 = tid < ns ? sml[0][tid] : -INFINITY, l1 = tid < ns ? sml[1][tid] : 0.0f;
+        const float m2 = tid + 64 < ns ? sml[0][tid + 64] : -INFINITY, l2 = tid + 64 < ns ? sml[1][tid + 64] : 0.0f;
         const float sj = tid < W ? sw[tid] : -INFINITY;
         const float sj2 = tid + 64 < W ? sw[tid + 64] : -INFINITY;
-        float M = fmaxf(fmaxf(mi, sj), sj2);
+        float M = fmaxf(fmaxf(m1, m2), fmaxf(sj, sj2));
 #pragma unroll
         for (int x = 32; x >= 1; x >>= 1) M = fmaxf(M, __shfl_xor(M, x, 64));
-        const float ci = tid < ns ? __expf(mi - M) : 0.0f;
+        const float c1 = tid < ns ? __expf(m1 - M) : 0.0f;
+        const float c2 = tid + 64 < ns ? __expf(m2 - M) : 0.0f;
         const float cw = tid < W ? __expf(sj - M) : 0.0f;
         const float cw2 = tid + 64 < W ? __expf(sj2 - M) : 0.0f;
-        coef[tid] = ci;
-        coef[64 + tid] = cw;
-        coef[128 + tid] = cw2;
-        float L = fmaf(ci, li, cw) + cw2;
+        coef[tid] = c1;
+        if (tid + 64 < RS_MAX) coef[tid + 64] = c2;
+        coef[RS_MAX + tid] = cw;
+        coef[RS_MAX + 64 + tid] = cw2;
+        float L = fmaf(c1, l1, fmaf(c2, l2, cw)) + cw2;
 #pragma unroll
         for (int x = 32; x >= 1; x >>= 1) L += __shfl_xor(L, x, 64);
         if (tid == 0) { stat[0] = M; stat[1] = L; }
     }
     __syncthreads();
     float o = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPO; i++) {
+        const int sl = grp + 4 * i;
+        if (sl < ns) o = fmaf(coef[sl], po_r[i], o);
+    }
 #pragma unroll 8
-    for (int i = grp; i < ns; i += 4) o = fmaf(coef[i], a.part_o[(bhq * a.splits + i) * AD + d], o);
-#pragma unroll 8
-    for (int r = grp; r < W; r += 4) o = fmaf(coef[64 + r], h2f_bits(vwin[(bhk * wcap + r) * (int64_t)AD + d]), o);
+    for (int r = grp; r < W; r += 4) o = fmaf(coef[RS_MAX + r], h2f_bits(vwin[(bhk * wcap + r) * (int64_t)AD + d]), o);
     og[grp][d] = o;
     __syncthreads();
     if (tid < AD) {
@@ -958,7 +1137,7 @@ int plan_splits(int T, int bits, int64_t bhq, bool fast_ranks, int* tc_out, bool
 extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
     // sized for the largest plan (64 splits) so that a buffer obtained for the cache capacity serves every shorter length
     (void)T; (void)bits;
-    return (size_t)B * Hq * 64 * (AD + 16 + 2) * sizeof(float) + 256;
+    return (size_t)B * Hq * RS_MAX * (AD + 16 + 2) * sizeof(float) + 256;     // (64 chunks + the window chunk + 1)
 }
 
 namespace {
@@ -1085,23 +1264,46 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     bool small;
     const bool r8 = (a.rk == 0 || a.rk == 8) && (a.rv == 0 || a.rv == 8);
     const bool r16 = !r8 && (a.rk == 0 || a.rk == 16) && (a.rv == 0 || a.rv == 16);
-    a.splits = plan_splits(T, bits, (int64_t)B * Hq, r8 || r16, &a.tc, &small);
+    const bool r4 = !r8 && !r16 && (a.rk == 0 || a.rk == 4) && (a.rv == 0 || a.rv == 4);     // (BASELINE configs[1]: rank 4)
+    a.splits = plan_splits(T, bits, (int64_t)B * Hq, r8 || r16 || r4, &a.tc, &small);
+    // the fp16 window: the reduce kernel's job (default), or -- option attn_win_chunk, short-chunk kernel -- one more chunk of the
+    // split (its own workgroup per KV head / query head in the same launch; the reduce kernel then only merges: measured 22.3
+    // against 21.1 us per layer at batch 1, the window workgroup is the launch's longest)
+    const bool win_chunk = small && (T > 0 || dyn_state) && kwin && vwin && (W > 0 || dyn_state) && gear_options().attn_win_chunk;
+    a.pslots = a.splits + (win_chunk ? 1 : 0);
+    a.kwin = (const uint16_t*)kwin; a.vwin = (const uint16_t*)vwin; a.W = W; a.wcap = wcap;
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     a.part_o = ws;
-    a.part_w = a.part_o + (size_t)B * Hq * a.splits * AD;
-    a.part_ml = a.part_w + (size_t)B * Hq * a.splits * 16;
+    a.part_w = a.part_o + (size_t)B * Hq * a.pslots * AD;
+    a.part_ml = a.part_w + (size_t)B * Hq * a.pslots * 16;
     hipStream_t st = (hipStream_t)stream;
     if (T > 0 || a.dyn) {
-        dim3 grid(a.splits, (unsigned)(B * Hq));
+        dim3 grid(a.pslots, (unsigned)(B * Hq));
+        // grouped-query attention on the short-chunk kernel: option attn_gqa_group = 1: one workgroup per (chunk, KV head) serves the
+        // group's 2 / 4 / 8 query heads; default: one workgroup per query head (see common.h for the measurement)
+        const int n_rep = Hq / Hkv;
+        const int gq = gear_options().attn_gqa_group;
+        const bool group_on = gq > 0 || (gq < 0 && (int64_t)B * Hq * a.splits >= 32768);
+        const int nrep_t = (small && group_on && (n_rep == 2 || n_rep == 4 || n_rep == 8)) ? n_rep : 1;
+        const dim3 gridg(a.pslots, (unsigned)(B * Hkv));
+#define GOS(BI, STT, RSV)                                                                                                  \
+    do {                                                                                                                   \
+        if (nrep_t == 8) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 8>), gridg, dim3(256), 0, st, a);      \
+        else if (nrep_t == 4) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 4>), gridg, dim3(256), 0, st, a); \
+        else if (nrep_t == 2) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 2>), gridg, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 1>), grid, dim3(256), 0, st, a);                   \
+    } while (0)
 #define GO(BI, STT)                                                                                             \
     do {                                                                                                        \
-        if (small && r16) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, true>), grid, dim3(256), 0, st, a);  \
-        else if (small) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, false>), grid, dim3(256), 0, st, a);   \
+        if (small && r16) GOS(BI, STT, 16);                                                                     \
+        else if (small && r4) GOS(BI, STT, 4);                                                                  \
+        else if (small) GOS(BI, STT, 8);                                                                        \
         else hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a);              \
     } while (0)
         if (mode == 0) { if (bits == 2) GO(2, uint16_t); else GO(4, uint16_t); }
         else           { if (bits == 2) GO(2, float); else GO(4, float); }
 #undef GO
+#undef GOS
         GEAR_CHECK_LAUNCH("gear_attn_decode(partial)");
     }
     hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(512), 0, st, a, (const uint16_t*)kwin,
@@ -1111,6 +1313,72 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// The UNCOMPRESSED baseline: single-token attention over an fp16 K / V cache [B, Hkv, tcap, 128] (T valid tokens), the same
+// flash-decoding split (128-token chunks, f16_chunk above) and the same reduce kernel.  What the reference's harness runs as
+// model "None" beside gearl / KIVI (cuda_supported_gear/test.py:41-62); bench.py times it at the shapes of the compressed cache.
+namespace {
+template <int NREP>
+__global__ __launch_bounds__(256) void attn_f16_partial_kernel(AttnArgs a, const uint16_t* __restrict__ k,
+                                                               const uint16_t* __restrict__ v, int tcap) {
+    __shared__ float s[SC];
+    __shared__ float op[4][AD];
+    __shared__ float red[4];
+    const int split = blockIdx.x;
+    int b, hkv;
+    int64_t bhq0;
+    if (NREP == 1) {
+        bhq0 = blockIdx.y;
+        b = (int)(bhq0 / a.Hq);
+        hkv = (int)(bhq0 % a.Hq) / (a.Hq / a.Hkv);
+    } else {
+        b = (int)blockIdx.y / a.Hkv;
+        hkv = (int)blockIdx.y % a.Hkv;
+        bhq0 = (int64_t)b * a.Hq + (int64_t)hkv * NREP;
+    }
+    const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    const int t0 = split * SC;
+    const int64_t row0 = (bhk * tcap + t0) * (int64_t)AD;
+    f16_chunk<NREP>(a, k + row0, v + row0, min(SC, a.T - t0), bhq0, split, s, op, red);
+}
+}  // namespace
+
+extern "C" int gear_attn_decode_f16(const void* q, const void* k, const void* v, int B, int Hq, int Hkv, int D, int T, int tcap,
+                                    float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream) {
+    GEAR_CHECK_ARG(q && k && v && out && workspace, "gear_attn_decode_f16: null pointer");
+    GEAR_CHECK_ARG(D == AD, "gear_attn_decode_f16: head_dim must be 128 (got %d)", D);
+    GEAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "gear_attn_decode_f16: bad head counts %d / %d", Hq, Hkv);
+    GEAR_CHECK_ARG(T > 0 && T <= tcap && T <= (RS_MAX - 1) * SC, "gear_attn_decode_f16: need 0 < T <= min(tcap, %d) (got %d)",
+                   (RS_MAX - 1) * SC, T);
+    GEAR_CHECK_ARG((int64_t)B * Hq <= 65535, "gear_attn_decode_f16: too many (batch, head) pairs");
+    GEAR_CHECK_ARG(workspace_bytes >= gear_attn_decode_workspace(B, Hq, T, 2), "gear_attn_decode_f16: workspace too small");
+    AttnArgs a{};
+    a.q = (const uint16_t*)q;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.T = T;
+    a.qscale = qscale;
+    a.splits = a.pslots = (T + SC - 1) / SC;
+    float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    a.part_o = ws;
+    a.part_w = a.part_o + (size_t)B * Hq * a.pslots * AD;
+    a.part_ml = a.part_w + (size_t)B * Hq * a.pslots * 16;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_rep = Hq / Hkv;
+    const int gq = gear_options().attn_gqa_group;
+    const bool group_on = gq > 0 || (gq < 0 && (int64_t)B * Hq * a.splits >= 32768);
+    const int nrep_t = (group_on && (n_rep == 2 || n_rep == 4 || n_rep == 8)) ? n_rep : 1;
+    const dim3 grid(a.splits, (unsigned)(nrep_t > 1 ? B * Hkv : B * Hq));
+    const uint16_t *kp = (const uint16_t*)k, *vp = (const uint16_t*)v;
+    if (nrep_t == 8) hipLaunchKernelGGL(attn_f16_partial_kernel<8>, grid, dim3(256), 0, st, a, kp, vp, tcap);
+    else if (nrep_t == 4) hipLaunchKernelGGL(attn_f16_partial_kernel<4>, grid, dim3(256), 0, st, a, kp, vp, tcap);
+    else if (nrep_t == 2) hipLaunchKernelGGL(attn_f16_partial_kernel<2>, grid, dim3(256), 0, st, a, kp, vp, tcap);
+    else hipLaunchKernelGGL(attn_f16_partial_kernel<1>, grid, dim3(256), 0, st, a, kp, vp, tcap);
+    GEAR_CHECK_LAUNCH("gear_attn_decode_f16(partial)");
+    hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(512), 0, st, a, (const uint16_t*)nullptr,
+                       (const uint16_t*)nullptr, 0, 0, (uint16_t*)out, (float*)lse);
+    GEAR_CHECK_LAUNCH("gear_attn_decode_f16(reduce)");
+    return 0;
+}
 
 extern "C" int gear_attn_decode_dyn(const void* q, const void* kcode, const void* kscale, const void* kmn, const void* kP,
                                 const void* kQ, const void* koidx, const void* koval, const void* vcode,

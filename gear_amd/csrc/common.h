@@ -44,6 +44,11 @@ struct GearOptions {
                            // workgroup barriers + solve; 0 = wave-private slab kernel + solve
     int gram_nstg;         // wave-private Gram kernel: steps of loads in flight per wave (2, 3 = default, 4)
     int decomp_general;    // row decompressor: the general row loop also for full blocks (never the straight-line 16-row path)
+    int attn_gqa_group;    // decode attention, Hq > Hkv: 1 = ONE workgroup serves the 2 / 4 / 8 query heads of a KV head (the chunk's payload
+                           // loaded once); 0 = one workgroup per query head (default: measured 2 - 3 x faster up to batch 4, profiles/
+                           // r5_attn_experiments.md -- the repeated reads hit L2 and the chip wants the parallelism); -1 = by launch size
+    int attn_win_chunk;    // decode attention: the fp16 window as one more chunk of the split (measured 1 us slower at batch 1 than the
+                           // window inside the reduce kernel, the default)
 };
 GearOptions& gear_options();
 

@@ -216,9 +216,11 @@ class GearHookCache:
 
     SINGLE USE.  Unlike the reference's tuple (immutable: an earlier `past` can be fed again, rolled back to, or branched from, as
     assisted / beam decoding do), the object is a view of ONE cache that every decode step mutates in place.  A decode step
-    consumes the object it was given and returns a new one; the consumed one (and every older one) is stale: using it again --
-    as `past_key_value`, through indexing or materialize() -- raises GearError instead of silently attending over an extra
-    token at a wrong position.  A caller that needs to branch calls materialize() BEFORE the step and continues on the tuple."""
+    consumes the object it was given and returns a new one; feeding a consumed one (or any older one) to a decode step again
+    raises GearError instead of silently attending over an extra token at a wrong position.  Reading a stale object stays
+    possible where it is still TRUE: the packed slots are prefixes of buffers that only grow (compressed tokens never change), the
+    window slots 1 / 5 are readable until a block boundary has overwritten the window -- after that they raise too.  A caller
+    that needs to branch calls materialize() BEFORE the step that consumes the object and continues on the tuple."""
 
     def __init__(self, cache, lowrank: bool, seq_len: int):
         self.cache, self.lowrank = cache, lowrank
@@ -227,12 +229,20 @@ class GearHookCache:
         self.gen = cache.hook_gen = getattr(cache, "hook_gen", 0) + 1
 
     def check_live(self):
-        """Raise unless this is the newest view of its cache (see the class docstring)."""
+        """Raise unless this is the newest view of its cache (see the class docstring): what a decode step requires."""
         c = self.cache
         if getattr(c, "hook_gen", self.gen) != self.gen or (c.n_comp, c.n_win) != (self.n_comp, self.n_win):
             raise L.GearError("GearHookCache: this past_key_value was already consumed by a decode step (the cache behind it is "
                               "mutated in place); re-using, rolling back to or branching from an earlier past needs "
                               "materialize() before the step that consumes it")
+
+    def _window_intact(self):
+        """The fp16 window as this view saw it is still in the buffer: no block boundary since (same compressed length) and the
+        live window is at least as long."""
+        c = self.cache
+        if c.n_comp != self.n_comp or c.n_win < self.n_win:
+            raise L.GearError("GearHookCache: the fp16 window of this (stale) past_key_value has been overwritten by a block "
+                              "boundary; materialize() before the step that consumes the object keeps it")
 
     def __len__(self):
         return 17
@@ -266,11 +276,13 @@ class GearHookCache:
         c, n, w = self.cache, self.n_comp, self.n_win
         if i == 8:
             return self.seq_len
-        self.check_live()                                  # (slot 8 is a plain int and stays readable)
         if i in (11, 12, 15, 16):
             return None
         if i in (1, 5):
-            return None if w == 0 else (c.kwin if i == 1 else c.vwin)[:, :, :w]
+            if w == 0:
+                return None
+            self._window_intact()
+            return (c.kwin if i == 1 else c.vwin)[:, :, :w]
         if i in (0, 2, 3):
             if n == 0:
                 return None

@@ -249,6 +249,16 @@ int gear_attn_decode(const void* q, const void* kcode, const void* kscale, const
                      int tf_v, int group, int bits, int mode, int rk, int rv, int kk, int kv, float qscale, void* out,
                      void* lse, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the uncompressed baseline: single-token attention over an fp16 cache --------------------------------------
+ * What the reference's harness runs as model "None" beside gearl / KIVI (cuda_supported_gear/test.py:41-62: HF attention
+ * over the fp16 past_key_values) -- same flash-decoding split, same merge kernel and same grouped-query mapping as
+ * gear_attn_decode, so that bench.py can put a compressed and an uncompressed time per token side by side.
+ *   q fp16 [B, Hq, 128]; k, v fp16 [B, Hkv, tcap, 128], tokens [0, T) valid, 0 < T <= min(tcap, 8320); qscale = 1/sqrt(128)
+ *   out fp16 [B, Hq, 128]; lse optional float [B, Hq]; workspace: gear_attn_decode_workspace(B, Hq, T, any bits).
+ */
+int gear_attn_decode_f16(const void* q, const void* k, const void* v, int B, int Hq, int Hkv, int D, int T, int tcap,
+                         float qscale, void* out, void* lse, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- decode attention with per-segment low-rank factors (the streaming cache of the attention hook) ----------
  * As gear_attn_decode, but the channel-side factors kP / vP are [nseg, B*Hkv, 128, r]: tokens [0, seg0) use set 0 (the
  * prefill block, cuda_supported_gear/modeling_llamagear.py:402-434), every following `seglen` tokens their own set (the

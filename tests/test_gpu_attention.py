@@ -56,12 +56,15 @@ def _trace(attn, cfg, prefill_len, n_decode, seed):
         mask = torch.full((prefill_len, prefill_len), torch.finfo(torch.float16).min, dtype=torch.float16,
                           device="cuda").triu(1)[None, None]
         torch.manual_seed(seed)
+        # (a GearHookCache is a single-use view of a cache that is mutated in place: every step's state is kept as the plain
+        # tuple it materialises to -- the window slots of an old view are gone after the next block boundary)
+        snap = lambda c: c.materialize() if hasattr(c, "materialize") else c
         out, _, cache = attn(x, attention_mask=mask, use_cache=True)
-        caches = [cache]
+        caches = [snap(cache)]
         for i in range(n_decode):
             xt = (torch.randn(1, 1, cfg.hidden_size, generator=g) * 0.5).half().cuda()
             out, _, cache = attn(xt, past_key_value=cache, use_cache=True)
-            caches.append(cache)
+            caches.append(snap(cache))
     finally:
         M.apply_rotary_pos_emb = orig
         MK.apply_rotary_pos_emb = orig
@@ -516,3 +519,35 @@ def test_kivi_and_mistral_shaped_models_generate():
         assert out.shape == (2, 200) and torch.equal(out[:, :70], ids)
         with pytest.raises(NotImplementedError):
             model.generate(ids, 300)
+
+
+def test_hook_cache_is_single_use():
+    """GearHookCache wraps ONE GearKVCache that decode steps mutate in place.  Feeding a consumed past to a decode
+    step again (re-running a step, rolling back, branching) must fail loudly instead of attending over an extra token; what an old
+    view can still read truthfully -- the packed prefixes, the window until a block boundary overwrites it -- stays readable, and
+    materialize() BEFORE the consuming step gives a tuple that can be reused like the reference's."""
+    from gear_amd import _lib as L
+    from gear_amd.modeling_llamagear import GearHookCache
+    attn, cfg, cc = _make("gearlKIVI", 2, 2, 2)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(1, 200, cfg.hidden_size, generator=g) * 0.5).half().cuda()
+    mask = torch.full((200, 200), torch.finfo(torch.float16).min, dtype=torch.float16, device="cuda").triu(1)[None, None]
+    torch.manual_seed(9)
+    _, _, past0 = attn(x, attention_mask=mask, use_cache=True)
+    assert isinstance(past0, GearHookCache)
+    frozen = past0.materialize()                                   # the reusable form, taken before the step consumes past0
+    xt = (torch.randn(1, 1, cfg.hidden_size, generator=g) * 0.5).half().cuda()
+    out1, _, past1 = attn(xt, past_key_value=past0, use_cache=True)
+    with pytest.raises(L.GearError, match="already consumed"):
+        attn(xt, past_key_value=past0, use_cache=True)            # the same step again on the consumed view
+    assert past0[8] == 200 and past0[0].shape[-1] == 192 // 16 and past0[1].shape[2] == 8     # still-true reads of the old view
+    out1b, _, _ = attn(xt, past_key_value=frozen, use_cache=True)                             # the tuple path from the frozen state
+    assert float((out1.float() - out1b.float()).abs().max()) <= 4e-3 * float(out1.abs().max())
+    cur = past1
+    for _ in range(56):                                            # 200 + 1 + 56 = 257 tokens: the window was compressed at 256
+        xt = (torch.randn(1, 1, cfg.hidden_size, generator=g) * 0.5).half().cuda()
+        _, _, cur = attn(xt, past_key_value=cur, use_cache=True)
+    assert cur[8] == 257 and cur[1].shape[2] == 1
+    with pytest.raises(L.GearError, match="overwritten"):
+        past1[1]                                                   # its window rows are gone
+    assert past1[0].shape[-1] == 192 // 16                         # its packed prefix is not

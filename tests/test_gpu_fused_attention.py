@@ -70,6 +70,7 @@ CASES = [
     (1, 4, 4, 1024, 0, 4, "fp16", 0, 0),
     (1, 2, 2, 2112, 1, 2, "fp32", 16, 10),
     (1, 8, 1, 1024, 5, 2, "fp32", 4, 2),
+    (1, 4, 4, 2048, 33, 4, "fp32", 4, 20),      # BASELINE configs[1]: 4 bits, rank 4 (8-byte factor rows on the short-chunk kernel)
 ]
 
 
@@ -132,3 +133,82 @@ def test_outlier_chunk_index_matches_searchsorted():
         ref = np.stack([np.searchsorted(row, bounds, side="left") for row in idx])
         assert np.array_equal(tab, ref)
     assert p.chunk_index() is p.chunk_index()          # cached
+
+
+@pytest.mark.parametrize("Hq,Hkv,T,W,bits,rank,k_out", [(4, 2, 640, 9, 2, 8, 6), (8, 2, 1024, 0, 4, 8, 4), (8, 1, 2048, 33, 2, 16, 12),
+                                                    (16, 2, 512, 64, 2, 0, 0)])
+def test_gqa_group_in_one_workgroup_equals_one_workgroup_per_query_head(Hq, Hkv, T, W, bits, rank, k_out):
+    """Round 5 (option attn_gqa_group): the short-chunk kernel serves the 2 / 4 / 8 query heads of a KV head from ONE workgroup (the
+    chunk's payload loaded once).  Same registers, same order of operations per head as one workgroup per query head (the default:
+    measured faster): outputs equal up to the order of the float atomics of the outlier terms; without outliers bit for bit."""
+    from gear_amd import _lib as L
+    from gear_amd import compress as C
+    from gear_amd.attention import decode_attention
+    torch.manual_seed(64)
+    B, D = 2, 128
+    k = torch.randn(B, Hkv, T, D).half().cuda()
+    v = torch.randn(B, Hkv, T, D).half().cuda()
+    q = torch.randn(B, Hq, 1, D).half().cuda()
+    kw = torch.randn(B, Hkv, W, D).half().cuda() if W else None
+    vw = torch.randn(B, Hkv, W, D).half().cuda() if W else None
+    pk = C.compress_key(k, bits, 64, k_out=k_out, rank=rank, loop=3, mode="fp32")
+    pv = C.compress_value(v, bits, 64, k_out=k_out, rank=rank, loop=3, mode="fp32")
+    out_1, lse_1 = decode_attention(q, pk, pv, kw, vw, return_lse=True)
+    L.set_option("attn_gqa_group", 1)
+    try:
+        out_g, lse_g = decode_attention(q, pk, pv, kw, vw, return_lse=True)
+    finally:
+        L.set_option("attn_gqa_group", 0)
+    if k_out == 0:
+        assert torch.equal(out_g, out_1) and torch.equal(lse_g, lse_1)
+    else:
+        assert rel_fro(host(out_g).astype(np.float64), host(out_1).astype(np.float64)) < 1e-4
+    ref = ref_attention(host(q), reconstruct(pk), reconstruct(pv), host(kw), host(vw), Hq // Hkv)
+    assert rel_fro(host(out_g).astype(np.float64), ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,T,tcap", [(1, 4, 4, 4096, 4096), (2, 8, 2, 1000, 1152), (1, 8, 1, 8192, 8192), (3, 2, 2, 77, 128),
+                                             (1, 6, 2, 300, 300)])
+def test_fp16_cache_attention_baseline(B, Hq, Hkv, T, tcap):
+    """gear_attn_decode_f16: the UNCOMPRESSED baseline bench.py times beside the compressed cache (the reference harness's model
+    "None", test.py:41-62) == float64 attention over the first T tokens of the fp16 cache; ragged last chunk, capacity > T, grouped
+    (2 / 4 / 8) and ungrouped (3) query-head ratios."""
+    from gear_amd.attention import decode_attention_f16
+    torch.manual_seed(65)
+    k = torch.randn(B, Hkv, tcap, 128).half().cuda()
+    v = torch.randn(B, Hkv, tcap, 128).half().cuda()
+    q = torch.randn(B, Hq, 1, 128).half().cuda()
+    out, lse = decode_attention_f16(q, k, v, T, return_lse=True)
+    ref = ref_attention(host(q), host(k)[:, :, :T].astype(np.float64), host(v)[:, :, :T].astype(np.float64), None, None, Hq // Hkv)
+    assert rel_fro(host(out).astype(np.float64), ref) < 1e-3
+    s = np.einsum("bhd,bhtd->bht", host(q).astype(np.float64)[:, :, 0], np.repeat(host(k)[:, :, :T].astype(np.float64), Hq // Hkv, 1)) / math.sqrt(128)
+    ref_lse = np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)
+    assert np.allclose(host(lse), ref_lse, rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("Hq,Hkv,T,W,rank,k_out", [(4, 4, 512, 1, 8, 4), (4, 2, 1024, 64, 8, 0), (8, 1, 384, 100, 16, 6), (2, 2, 4096, 37, 0, 0)])
+def test_window_as_one_more_chunk_equals_window_in_the_reduce_kernel(Hq, Hkv, T, W, rank, k_out):
+    """Round 5 (option attn_win_chunk): the fp16 window as one more chunk of the short-chunk kernel's split (its own workgroup in the
+    same launch), the reduce kernel only merges; default = window scores and values inside the reduce kernel (measured faster).
+    Same softmax, merged in a different order: equal to fp32 rounding."""
+    from gear_amd import _lib as L
+    from gear_amd import compress as C
+    from gear_amd.attention import decode_attention
+    torch.manual_seed(66)
+    B, D = 2, 128
+    k = torch.randn(B, Hkv, T, D).half().cuda()
+    v = torch.randn(B, Hkv, T, D).half().cuda()
+    q = torch.randn(B, Hq, 1, D).half().cuda()
+    kw, vw = torch.randn(B, Hkv, W, D).half().cuda(), torch.randn(B, Hkv, W, D).half().cuda()
+    pk = C.compress_key(k, 2, 64, k_out=k_out, rank=rank, loop=3, mode="fp32")
+    pv = C.compress_value(v, 2, 64, k_out=k_out, rank=rank, loop=3, mode="fp32")
+    out_r, lse_r = decode_attention(q, pk, pv, kw, vw, return_lse=True)
+    L.set_option("attn_win_chunk", 1)
+    try:
+        out_c, lse_c = decode_attention(q, pk, pv, kw, vw, return_lse=True)
+    finally:
+        L.set_option("attn_win_chunk", 0)
+    assert rel_fro(host(out_c).astype(np.float64), host(out_r).astype(np.float64)) < 5e-4      # (one fp16 rounding of the output)
+    assert torch.allclose(lse_c, lse_r, rtol=0, atol=1e-4)
+    ref = ref_attention(host(q), reconstruct(pk), reconstruct(pv), host(kw), host(vw), Hq // Hkv)
+    assert rel_fro(host(out_c).astype(np.float64), ref) < 2e-3
