@@ -197,6 +197,7 @@ def attn_decode_by_batch(cfg, dev):
     window) at batch 1, 4, 16: time per call and compressed bytes per second.  The decode leg runs batch 1; this shows how far
     from the HBM rate the kernel is when a launch has more than one sequence's worth of chunks to spread over the chip."""
     from gear_amd.cache import GearKVCache
+    from gear_amd.attention import decode_attention_f16
     H, Hq, T, bits, group, rnk, loop, s = (cfg["kv_heads"], cfg["q_heads"], cfg["T"], cfg["bits"], cfg["group"], cfg["rank"],
                                            cfg["loop"], cfg["s"])
     cc = dict(compress_method="gearslKIVI" if s > 0 else "gearlKIVI", group_size=group, residual=64, quantize_bit=bits,
@@ -228,8 +229,29 @@ def attn_decode_by_batch(cfg, dev):
         nbytes += B * H * c.n_win * D * 2 * 2
         out[f"B{B}"] = {"us_per_call": us, "compressed_GBps": nbytes / (us * 1e-6) / 1e9,
                         "fp16_equiv_GBps": B * H * (nc + c.n_win) * D * 2 * 2 / (us * 1e-6) / 1e9}
-        del c, k, v, q
+        # the UNCOMPRESSED baseline at the same shapes (the reference's harness times model "None" beside gearl / KIVI,
+        # cuda_supported_gear/test.py:41-62): gear_attn_decode_f16 over an fp16 cache of the same length -- same split / merge
+        # kernels, fp16 rows instead of the packed payload.  > 1: compression makes this batch's attention FASTER.
+        Ttot = nc + c.n_win
+        del c, k, v
         torch.cuda.empty_cache()
+        kf = torch.randn((B, H, Ttot, D), device=dev, dtype=torch.float16)
+        vf = torch.randn((B, H, Ttot, D), device=dev, dtype=torch.float16)
+        for _ in range(10):
+            decode_attention_f16(q, kf, vf)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            decode_attention_f16(q, kf, vf)
+        e1.record()
+        torch.cuda.synchronize()
+        us16 = e0.elapsed_time(e1) / reps * 1e3
+        out[f"B{B}"].update({"fp16_cache_us_per_call": us16, "fp16_cache_GBps": B * H * Ttot * D * 2 * 2 / (us16 * 1e-6) / 1e9,
+                             "speedup_vs_fp16_cache": us16 / us})
+        del kf, vf, q
+        torch.cuda.empty_cache()
+    out["note"] = ("fp16_cache_*: gear_attn_decode_f16 over an UNCOMPRESSED fp16 cache of the same length (the reference harness's "
+                   "model None); speedup_vs_fp16_cache < 1 means the compressed cache costs attention time at that batch")
     return out
 
 

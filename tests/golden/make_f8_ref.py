@@ -62,8 +62,18 @@ def extract(path, name, klass=None):
 
 
 def cuda_bmm_fA_qB_outer(group_size, fA, qB, scales, zeros, bits, mqa=False):
-    w = new_pack.unpack_and_dequant_vcache(qB, scales.unsqueeze(-1), zeros.unsqueeze(-1), group_size, bits)
-    return torch.matmul(fA.float(), w.float()).to(fA.dtype)
+    """Stand-in for the CUDA extension with the ARITHMETIC of its kernels (quant/csrc/gemv_cuda.cu:331-345, bgemv{2,4}_kernel_outer_dim):
+    the weight is dequantized in fp32 -- float(scale) * float(code) + float(zero), never rounded to fp16 --, multiplied by float(input),
+    accumulated in fp32, and rounded to fp16 ONCE at the end.  (Rounds 3-4 used the reference's own host-side check of that kernel,
+    fA @ unpack_and_dequant_vcache(...), quant/gemv.py:70-74, which rounds the dequantized weight to fp16 first: the fixture was then
+    2e-3 away from the kernel it stood in for, and the parity tests had to carry that.)  Codes are unpacked by the reference's
+    unpack_tensor; the summation order over the input channels is torch.matmul's, the kernel's is a strided per-thread sum + warp
+    tree -- fp32 either way."""
+    code = new_pack.unpack_tensor(qB, bits, pack_dim=3).float()                      # [B, nh, K, N]
+    shape = code.shape
+    code = code.view(shape[:-1] + (shape[-1] // group_size, group_size))
+    w = scales.float().unsqueeze(-1) * code + zeros.float().unsqueeze(-1)            # fp32, as the kernel
+    return torch.matmul(fA.float(), w.view(shape)).to(fA.dtype)
 
 
 def apply_rotary_pos_emb(q, k, cos, sin, position_ids=None):
@@ -122,12 +132,16 @@ CASES = {  # name: (which forward, method, bits, stance, prompt length, decode s
     "gear_stance_gearl_b4_t30": ("gear", "gearlKIVI", 4, True, 30, 110),   # prompt shorter than the window
     "kivi_b2": ("kivi", "KIVI", 2, False, 200, 130),            # modeling_llama_kivi.py: sliding V window, per-token V quantization
     "kivi_b4_t64": ("kivi", "KIVI", 4, False, 64, 70),
+    # round 5: a wider trace -- 8 heads, rank 8, two block boundaries past a 512-token prompt (the shapes above are H = 2, rank 4)
+    "gear_stance_gearl_b2_h8r8": ("gear", "gearlKIVI", 2, True, 512, 130),
 }
 H, D, RANK = 2, 128, 4
+SHAPE = {"gear_stance_gearl_b2_h8r8": (8, 8)}      # per-case (heads, rank) where they differ from the defaults
 
 
 def run_case(name, out):
     which, method, bits, stance, TP, STEPS = CASES[name]
+    H, RANK = SHAPE.get(name, (globals()["H"], globals()["RANK"]))
     cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=RANK, rankv=RANK, loop=3)
     ns = namespace(stance)
     fwd = ns["forward_gear"] if which == "gear" else ns["forward_kivi"]

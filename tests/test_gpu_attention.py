@@ -146,14 +146,14 @@ class _NoRope(torch.nn.Module):
         return torch.ones(shape, dtype=x.dtype, device=x.device), torch.zeros(shape, dtype=x.dtype, device=x.device)
 
 
-def _fixture_module(kind, method, bits, H, D):
+def _fixture_module(kind, method, bits, H, D, rank=4):
     """The hook module with the model plumbing of tests/golden/make_f8_ref.py: input = (q | k | v) post-RoPE rows, projections =
     slices, o_proj and the rotary embedding = identity."""
     from gear_amd.modeling_llamagear import LlamaAttention_GEAR, LlamaConfigLite
     from gear_amd.modeling_llama_kivi import LlamaAttention_KIVI
     cfg = LlamaConfigLite(hidden_size=H * D, num_attention_heads=H, num_key_value_heads=H, num_hidden_layers=1, k_bits=bits,
                           v_bits=bits, group_size=64, residual_length=64)
-    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=3)
     attn = (LlamaAttention_GEAR if kind == "gear" else LlamaAttention_KIVI)(0, cfg, cc).half().cuda()
     HD = H * D
     attn.q_proj, attn.k_proj, attn.v_proj = _Slice(0, HD), _Slice(HD, 2 * HD), _Slice(2 * HD, 3 * HD)
@@ -197,7 +197,20 @@ def _same_bits(t, a):
     return np.array_equal(t.view(np.uint16), a.view(np.uint16)) if t.dtype == np.float16 else np.array_equal(t, a)
 
 
-@pytest.mark.parametrize("case", ["gear_kivi_b2", "gear_kivi_b4_t64", "gear_stance_gearl_b2", "gear_stance_gearl_b4_t30"])
+def _log_err(name, *vals):
+    """Measured errors of the reference-trace tests into gpurun_out/ (informational: how far inside its tolerance a test is)."""
+    import os
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "trace_errors.log"), "a") as fh:
+            fh.write(name + " " + " ".join("%.3e" % v for v in vals) + "\n")
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("case", ["gear_kivi_b2", "gear_kivi_b4_t64", "gear_stance_gearl_b2", "gear_stance_gearl_b4_t30",
+                                  "gear_stance_gearl_b2_h8r8"])       # (the last: 8 heads, rank 8, 512-token prompt + 2 blocks)
 def test_attention_hook_matches_reference_forward_trace(golden, case):
     """a8 / a5 / a7 against the reference itself: tests/golden/f8_ref_*.npz hold traces made by executing
     LlamaAttention_GEAR.forward, key_compression, value_compression and matmul_withlrap of
@@ -207,11 +220,15 @@ def test_attention_hook_matches_reference_forward_trace(golden, case):
     bits = 4 if "_b4" in case else 2
     method = "gearlKIVI" if "gearl" in case else "KIVI"
     qkv = f[case + "_qkv"]
-    attn = _fixture_module("gear", method, bits, qkv.shape[2], qkv.shape[4])
+    attn = _fixture_module("gear", method, bits, qkv.shape[2], qkv.shape[4], 8 if "r8" in case else 4)
     got, ref, cache, ndrawn = _run_fixture_trace(attn, f, case)
     assert got.shape == ref.shape
-    assert rel_fro(got, ref) < 2e-3, rel_fro(got, ref)
-    assert max(rel_fro(got[:, i], ref[:, i]) for i in range(ref.shape[1])) < 4e-3
+    # round 5: the fixtures' stand-in for the CUDA GEMV now has the kernel's arithmetic (fp32 dequantized weight, fp32 accumulate,
+    # one fp16 rounding: gemv_cuda.cu:331-345) -- 2e-3 / 4e-3 (the price of an fp16-rounded weight in the stand-in) became 1e-3 / 2e-3
+    worst = max(rel_fro(got[:, i], ref[:, i]) for i in range(ref.shape[1]))
+    _log_err("hook_gear " + case, rel_fro(got, ref), worst)
+    assert rel_fro(got, ref) < 1e-3, rel_fro(got, ref)
+    assert worst < 2e-3, worst
     assert len(cache) == 17 and cache[8] == int(f[case + "_seq"][0])
     for name, slot in (("kcode", 0), ("kfull", 1), ("kscale", 2), ("kmn", 3), ("vcode", 4), ("vfull", 5), ("vscale", 6), ("vmn", 7)):
         key = f"{case}_{name}"
@@ -240,8 +257,10 @@ def test_kivi_hook_matches_reference_forward_trace(golden, case):
     qkv = f[case + "_qkv"]
     attn = _fixture_module("kivi", "KIVI", bits, qkv.shape[2], qkv.shape[4])
     got, ref, cache, _ = _run_fixture_trace(attn, f, case)
-    assert rel_fro(got, ref) < 2e-3, rel_fro(got, ref)
-    assert max(rel_fro(got[:, i], ref[:, i]) for i in range(ref.shape[1])) < 4e-3
+    worst = max(rel_fro(got[:, i], ref[:, i]) for i in range(ref.shape[1]))
+    _log_err("hook_kivi " + case, rel_fro(got, ref), worst)
+    assert rel_fro(got, ref) < 1e-3, rel_fro(got, ref)
+    assert worst < 2e-3, worst
     assert len(cache) == 9 and cache[8] == int(f[case + "_seq"][0])
     for name, slot in (("kcode", 0), ("kfull", 1), ("kscale", 2), ("kmn", 3), ("vcode", 4), ("vfull", 5), ("vscale", 6), ("vmn", 7)):
         key = f"{case}_{name}"
@@ -269,7 +288,8 @@ def test_matmul_withlrap_matches_reference_fixture(golden, bits):
     for name, (a, code, scale, mn, pb, qb, typ) in cases.items():
         got = host(matmul_withlrap(64, a, code, scale, mn, bits, pb, qb, type=typ))
         ref = f[f"mm_b{bits}_{name}"].reshape(got.shape)
-        assert rel_fro(got, ref) < 2e-3, (name, rel_fro(got, ref))
+        _log_err(f"matmul_withlrap b{bits} {name}", rel_fro(got, ref))
+        assert rel_fro(got, ref) < 1e-3, (name, rel_fro(got, ref))
 
 
 def test_matmul_withlrap_gqa_matches_dense_reconstruction():

@@ -532,7 +532,7 @@ def test_streaming_cache_matches_reference_forward_trace(golden, case, bits, low
     """FastGearDecoder's data path -- GearKVCache: in-place window append, gear_attn_decode_cache, gear_compress_block at block
     boundaries -- held to the traces made by EXECUTING the reference's LlamaAttention_GEAR.forward (tests/golden/make_f8_ref.py,
     cuda_supported_gear/modeling_llamagear.py:177-484): fed the trace's post-projection q / k / v step by step, the attention output
-    of every decode step matches the reference's (2e-3 overall, 4e-3 worst step, the hook module's own tolerance) and the packed K / V
+    of every decode step matches the reference's (1e-3 overall, 2e-3 worst step, the hook module's own tolerance) and the packed K / V
     codes + scale + zero point + fp16 windows are the reference's bit for bit.  With low-rank factors the payload is still
     bit-identical; the factors start from the cache's own random basis (channel side, not the reference's token-side draw), and on
     this fixture's white-noise error matrices -- no dominant directions for three power iterations to find -- two random starts give
@@ -557,7 +557,7 @@ def test_streaming_cache_matches_reference_forward_trace(golden, case, bits, low
         c.maybe_compress()
     got = np.concatenate(outs, 1)
     want = ref[:, 1:]
-    tol_all, tol_step = (2e-3, 4e-3) if not lowrank else (0.25, 0.5)
+    tol_all, tol_step = (1e-3, 2e-3) if not lowrank else (0.25, 0.5)     # (1e-3 / 2e-3 since round 5's fp32-weight fixture stand-in)
     assert rel_fro(got, want) < tol_all, rel_fro(got, want)
     assert max(rel_fro(got[:, i], want[:, i]) for i in range(steps)) < tol_step
     n, fpi = c.n_comp, 32 // bits

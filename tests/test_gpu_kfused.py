@@ -76,10 +76,33 @@ def _check_payload(p, xn, k, g, b, mode=1):
         np.put_along_axis(mask, isml, False, 1)
         np.put_along_axis(mask, ilrg, False, 1)
     assert np.array_equal(cq[mask], ch[mask]), "codes"
-    # outlier slots carry quant(fill): the oracle's codes there come from the same rule
+    # Outlier slots carry quant(fill), fill = the row mean (compress_function.py:276-283: torch.mean of the fp32 row, an fp32
+    # reduction whose order torch does not specify).  The oracle takes the correctly rounded mean (fp64 sum), the select kernel an
+    # fp32 sum in its streaming order: the two can differ in the last place, and where the fill's quotient sits that close to a
+    # rounding boundary the code under the slot differs.  Those codes are never read back (the slot's value is restored from the
+    # sparse list).  Checked, not waved through: EVERY differing code must be the code of a mean one ulp away, and there must be
+    # few of them.
     if k > 0:
-        bad = np.count_nonzero(cq[~mask] != ch[~mask])
-        assert bad <= max(1, (~mask).sum() // 10000), f"fill codes: {bad} differ"
+        rr, cc_ = np.nonzero((cq != ch) & ~mask)
+        assert rr.size <= max(1, (~mask).sum() // 10000), f"fill codes: {rr.size} differ"
+        if rr.size:
+            mean = rows32.astype(np.float64).sum(1) / rows32.shape[1]
+            L = (1 << b) - 1
+            sc = np.asarray(q["scale"], np.float32).reshape(B * H * D, -1)[rr, cc_ // g]
+            mn_ = np.asarray(q["mn"], np.float32).reshape(B * H * D, -1)[rr, cc_ // g]
+            ok = np.zeros(rr.size, bool)
+            for step in (-1, 0, 1):
+                m32 = mean[rr].astype(np.float32)
+                if step:
+                    m32 = np.nextafter(m32, np.float32(np.inf * step), dtype=np.float32)
+                if mode == 0:
+                    f16 = m32.astype(np.float16)
+                    t1 = (f16 - mn_.astype(np.float16)).astype(np.float16)
+                    c = (t1.astype(np.float32) / sc).astype(np.float16).astype(np.float32)
+                else:
+                    c = (m32 - mn_) / sc
+                ok |= np.clip(np.rint(c), 0, L).astype(ch.dtype) == ch[rr, cc_]
+            assert ok.all(), "a fill code that no mean within one ulp of the exact one explains"
     return q, isml, ilrg, rows32
 
 

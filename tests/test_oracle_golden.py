@@ -241,7 +241,7 @@ def test_f7_gemv(golden, name, b):
 # matmul_withlrap source (tests/golden/make_f8_ref.py).  Tolerances: the reference-side GEMV of the fixture rounds the
 # dequantized weight to fp16 before the product (its own check of the kernel, quant/gemv.py:70-74) where the kernel -- and
 # orc.gemv_outer -- keep fp32 (2e-3, as fixture F7); low-rank factors agree up to the basis of the subspace (products only).
-F8_REF_GEAR = ["gear_kivi_b2", "gear_kivi_b4_t64", "gear_stance_gearl_b2", "gear_stance_gearl_b4_t30"]
+F8_REF_GEAR = ["gear_kivi_b2", "gear_kivi_b4_t64", "gear_stance_gearl_b2", "gear_stance_gearl_b4_t30", "gear_stance_gearl_b2_h8r8"]
 F8_REF_KIVI = ["kivi_b2", "kivi_b4_t64"]
 
 
@@ -271,7 +271,8 @@ def test_f8_ref_gear_state_machine_vs_reference_forward(golden, case):
     q, k, v, ref, H, D, TP, steps = _f8_ref_inputs(f, case)
     bits = 4 if "_b4" in case else 2
     method = "gearlKIVI" if "gearl" in case else "KIVI"
-    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=4, rankv=4, loop=3)
+    rank = 8 if "r8" in case else 4
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=3)
     drawn = []
 
     def draw(B, Hh, S, Dm, r):
@@ -282,9 +283,11 @@ def test_f8_ref_gear_state_machine_vs_reference_forward(golden, case):
     o = GearAttentionOracle(H, H, D, cc, draw)
     got = _run_trace(o, q, k, v, TP, steps)
     assert got.shape == ref.shape
-    assert rel_fro(got, ref) < 2e-3, rel_fro(got, ref)
+    # (round 5: the fixture's stand-in for the CUDA GEMV has the kernel's arithmetic -- fp32 dequantized weight, fp32 accumulate,
+    # one fp16 rounding -- instead of an fp16-rounded weight; the tolerances came down from 2e-3 / 4e-3 with it)
+    assert rel_fro(got, ref) < 5e-4, rel_fro(got, ref)
     worst = max(rel_fro(got[:, :, i], ref[:, :, i]) for i in range(steps + 1))
-    assert worst < 4e-3, worst
+    assert worst < 1e-3, worst
     c = o.c
     assert c["n"] == int(f[case + "_seq"][0]) == TP + steps
     # (a prompt of exactly `residual` tokens strands V in fp16 for good -- modeling_llamagear.py:416 / :335 -- in both)
@@ -320,8 +323,8 @@ def test_f8_ref_kivi_state_machine_vs_reference_forward(golden, case):
     bits = 4 if "_b4" in case else 2
     o = KiviAttentionOracle(H, H, D, 64, bits, 64)
     got = _run_trace(o, q, k, v, TP, steps)
-    assert rel_fro(got, ref) < 2e-3, rel_fro(got, ref)
-    assert max(rel_fro(got[:, :, i], ref[:, :, i]) for i in range(steps + 1)) < 4e-3
+    assert rel_fro(got, ref) < 5e-4, rel_fro(got, ref)
+    assert max(rel_fro(got[:, :, i], ref[:, :, i]) for i in range(steps + 1)) < 1e-3
     c = o.c
     assert c["n"] == int(f[case + "_seq"][0])
     assert np.array_equal(c["kc"], f[case + "_kcode"]) and np.array_equal(c["vc"], f[case + "_vcode"])
@@ -351,7 +354,7 @@ def test_f8_ref_matmul_withlrap(golden, bits):
     for name, (a, code, scale, mn, pb, qb, typ) in cases.items():
         got = matmul_withlrap(64, a, code, scale, mn, bits, pb, qb, type=typ)
         ref = g(name).reshape(got.shape)
-        assert rel_fro(got, ref) < 2e-3, (name, rel_fro(got, ref))
+        assert rel_fro(got, ref) < 2e-4, (name, rel_fro(got, ref))     # (fp32-weight stand-in since round 5: was 2e-3)
 
 
 @pytest.mark.parametrize("B,H,T,bits,g,s,r", [(1, 4, 256, 2, 64, 0.02, 4), (2, 2, 192, 4, 32, 0.05, 8), (1, 3, 200, 2, 64, 0.01, 2),
