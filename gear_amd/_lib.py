@@ -29,6 +29,10 @@ SIGNATURES = {
     "gear_compress_value_fused_workspace": (_sz, [_i64, _i, _i, _i]),
     "gear_compress_value_fused": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _i64,
                                        _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "gear_vsel_candidates": (_i, [_vp, _i64, _i, _i64, _i64, _i, _i, _i64, _i, _i, _vp, _vp]),
+    "gear_vsel_thresholds": (_i, [_vp, _i, _i64, _i, _i64, _i, _vp, _vp, _vp]),
+    "gear_compress_value_sharded": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _i64,
+                                         _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "gear_attn_decode_cache": (_i, [_vp, _vp, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp, _sz, _vp]),
     "gear_cache_tiles_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "gear_outlier_chunk_index_ex": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -78,7 +82,7 @@ SIGNATURES = {
     "gear_xchg_allgather": (_i, [_vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 4      # what this table was written against (gear_abi_version() of the library must match)
+ABI_VERSION = 5      # what this table was written against (gear_abi_version() of the library must match)
 
 
 def _source_hash() -> str:

@@ -68,6 +68,9 @@ def _cache_dims(batch, n_kv_heads, max_tokens, cc, head_dim=128, heads_total=Non
         # exact cross-shard V selection (parallel.exact_v_selection): the row's outliers are chosen over ALL heads, a shard keeps
         # the ones that fall into its heads -- anything between 0 and the full count, so its lists hold the full count per side
         kv = int(int(B * Ht * T * D * s) / B / T / 2) if s > 0 else 0
+        if kv > H * D:
+            raise L.GearError(f"GearKVCache: {kv} V outliers per side and row exceed the shard's row length {H * D} (sparsity > 1 / "
+                              "world): not a configuration the exact cross-shard selection supports; use v_selection='per_shard'")
     kk0_max = int(int(B * Ht * T * D * s) / B / T / 2) if s > 0 else 0
     # K outliers per side and channel row of a decode block: "nominal" = the sparsity applied to the row's own length; "reference" =
     # the reference's formula (B7: it depends on H*D, not on the row length), capped at half the row -- what gears_channelQ does to a
@@ -174,30 +177,46 @@ def _draw_p0(shape_local, gen, dev, tp):
 
 def _compress_value_exact(bufs, d, lead, B, H, D, v_src, T, t_off, seg, loop, P0v, tp, kk0, seg0):
     """V payload of a head shard with the outliers selected over the WHOLE token row (all ranks' heads), bit-identical to the matching
-    head slice of the unsharded payload (tests/test_gpu_parallel.py).  parallel.exact_v_selection gives the local share of every
-    row's outliers + the global fill value; in the cache's fp16-stepwise arithmetic the fill is an fp16 number, so the quantizer sees
-    the row with its outliers REPLACED by the fill (HIP: quantize + pack + error, new_pack.py:253-288), the error is zeroed at the
-    outliers (they are restored exactly: compress_function.py:216-219), then the usual low-rank step, lists, chunk index, tiles."""
-    from .parallel import exact_v_selection
-    from .quant.new_pack import triton_quantize_and_pack_along_last_dim_witherror
+    head slice of the unsharded payload (tests/test_gpu_parallel.py).  Round 5: in HIP -- gear_vsel_candidates, ONE all-gather of
+    8 (2 kv + 1) bytes per row and rank, gear_vsel_thresholds, then gear_compress_value_sharded (the row compressor with the selection
+    given + the usual low-rank step) writing straight behind token t_off of the cache: 3 launches + the chain's low-rank kernels where
+    round 4 ran ~25 torch launches (parallel.exact_v_selection: two topk, where, gather ...; kept as the tests' cross-check with
+    tp["exact"] == "torch")."""
+    from .parallel import exact_v_selection, exact_v_thresholds
     lib = L.load()
     p = L.ptr
     NB = lead * B
     Tmax, g, bits, kv = d["Tmax"], d["group"], d["bits"], d["kv"]
-    v4 = v_src.reshape(NB, H, -1, D)[:, :, :T]
-    filled, mask, oidx, oval = exact_v_selection(v4, kv, tp["rank"], tp["world"], tp.get("group"))
-    code, scale, mn, err = triton_quantize_and_pack_along_last_dim_witherror(filled, g, bits)
-    bufs["vcode"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = code
-    bufs["vscale"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = scale
-    bufs["vmn"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = mn
-    bufs["voidx"].view(NB, Tmax, 2 * kv)[:, t_off:t_off + T] = oidx
-    bufs["voval"].view(NB, Tmax, 2 * kv)[:, t_off:t_off + T] = oval
-    if d["lowrank"]:
-        err = err.view(NB, H, T, D).masked_fill_(mask, 0)
-        P, Q = C.lowrank(err, d["rv"], loop, P0v)
-        bufs["vPseg"].view(lead, d["nseg"], B, H, D, d["rv"])[:, seg] = P.view(lead, B, H, D, d["rv"])
-        bufs["vQtok"].view(NB, H, Tmax, d["rv"])[:, :, t_off:t_off + T] = Q
     st = L.stream_ptr(v_src)
+    if tp.get("exact", True) == "torch":
+        from .quant.new_pack import triton_quantize_and_pack_along_last_dim_witherror
+        v4 = v_src.reshape(NB, H, -1, D)[:, :, :T]
+        filled, mask, oidx, oval = exact_v_selection(v4, kv, tp["rank"], tp["world"], tp.get("group"))
+        code, scale, mn, err = triton_quantize_and_pack_along_last_dim_witherror(filled, g, bits)
+        bufs["vcode"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = code
+        bufs["vscale"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = scale
+        bufs["vmn"].view(NB, H, Tmax, -1)[:, :, t_off:t_off + T] = mn
+        bufs["voidx"].view(NB, Tmax, 2 * kv)[:, t_off:t_off + T] = oidx
+        bufs["voval"].view(NB, Tmax, 2 * kv)[:, t_off:t_off + T] = oval
+        if d["lowrank"]:
+            err = err.view(NB, H, T, D).masked_fill_(mask, 0)
+            P, Q = C.lowrank(err, d["rv"], loop, P0v)
+            bufs["vPseg"].view(lead, d["nseg"], B, H, D, d["rv"])[:, seg] = P.view(lead, B, H, D, d["rv"])
+            bufs["vQtok"].view(NB, H, Tmax, d["rv"])[:, :, t_off:t_off + T] = Q
+    else:
+        v4 = v_src.reshape(NB, H, -1, D)
+        if v4.shape[2] != T:
+            v4 = v4[:, :, :T].contiguous()
+        thr, fill = exact_v_thresholds(v4, kv, tp["rank"], tp["world"], tp.get("group"), mode=0)
+        seg_v = B * H * D * d["rv"]
+        vP = bufs["vPseg"].view(-1)[seg * seg_v:] if d["lowrank"] else None
+        wsb = lib.gear_compress_value_fused_workspace(NB, H, T, d["rv"])
+        ws = C._workspace(wsb, v_src.device)
+        rc = lib.gear_compress_value_sharded(
+            p(v4), NB, H, T, g, bits, 0, kv, p(bufs["vcode"]), p(bufs["vscale"]), p(bufs["vmn"]), Tmax, t_off, d["rv"], loop, p(P0v),
+            p(vP), B * H, d["nseg"] * seg_v, p(bufs.get("vQtok")), Tmax, t_off, p(bufs["voidx"]), p(bufs["voval"]),
+            tp["rank"] * H * D, p(thr), p(fill), p(ws), ws.numel(), st)
+        L.check(rc, "gear_compress_value_sharded")
     if "vochunk" in bufs:     # (the sentinel index 0xFFFF of an unused list slot lies beyond every head bound: the terminal entry is the count)
         rc = lib.gear_outlier_chunk_index_ex(p(bufs["voidx"]), NB, 2 * T, 2 * Tmax, 2 * t_off, kv, kv, 128, H + 1,
                                              p(bufs["vochunk"]), H + 1, st)

@@ -149,12 +149,47 @@ def compress_rows_once(x, geom, group, bits, mode, k, want_err, err=None):
     return out + (err,)
 
 
+def compress_value_sharded(v: torch.Tensor, bits: int, group: int, k_out: int, rank: int, loop: int, mode, P0, shard) -> Payload:
+    """One head shard of a V tensor whose token rows span the heads of `world` ranks: v [B,H_local,T,128], k_out = the FULL row's
+    count per side, shard = (tp_rank, tp_world, process group or None).  The selection is the unsharded one (csrc/vsel.hip through
+    parallel.exact_v_thresholds: two launches + one all-gather), the rest is compress_value's; oidx holds LOCAL columns
+    (h_local * 128 + d), unused slots 0xFFFF."""
+    from .parallel import exact_v_thresholds
+    tp_rank, tp_world, tp_group = shard
+    B, H, T, D = v.shape
+    m = _MODES[mode]
+    dev = v.device
+    code, scale, mn, oidx, oval = _alloc_rows(v.shape, B * T, group, bits, m, k_out, dev)
+    P = Q = None
+    if rank > 0:
+        if P0 is None:
+            P0 = draw_p0(B, H, T, D, rank, dev)
+        P0 = P0.to(device=dev, dtype=torch.float32).contiguous()
+        P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
+        Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
+    # (tp_group may also be a ready (thr, fill) pair: the single-process tests and bench.py's emulation pass the thresholds in)
+    thr, fill = tp_group if isinstance(tp_group, tuple) else exact_v_thresholds(v, k_out, tp_rank, tp_world, tp_group, mode=m)
+    lib = L.load()
+    wsb = lib.gear_compress_value_fused_workspace(B, H, T, rank)
+    ws = _workspace(wsb, dev)
+    rc = lib.gear_compress_value_sharded(L.ptr(v), B, H, T, group, bits, m, k_out, L.ptr(code), L.ptr(scale), L.ptr(mn), T, 0, rank,
+                                         loop, L.ptr(P0) if rank > 0 else None, L.ptr(P), B * H, 0, L.ptr(Q), T, 0, L.ptr(oidx),
+                                         L.ptr(oval), tp_rank * H * D, L.ptr(thr), L.ptr(fill), L.ptr(ws), ws.numel(),
+                                         L.stream_ptr(v))
+    L.check(rc, "gear_compress_value_sharded")
+    return Payload("v", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx.view(B, T, 2 * k_out), oval.view(B, T, 2 * k_out),
+                   k_out)
+
+
 def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
-                   mode="fp32", P0: Optional[torch.Tensor] = None) -> Payload:
-    """V [B,H,T,D] fp16 -> Payload (per-token groups along D; outliers per token row across heads)."""
+                   mode="fp32", P0: Optional[torch.Tensor] = None, shard=None) -> Payload:
+    """V [B,H,T,D] fp16 -> Payload (per-token groups along D; outliers per token row across heads).
+    shard = (tp_rank, tp_world, group): v holds this rank's heads of rows that span `tp_world` ranks -- see compress_value_sharded."""
     assert v.dim() == 4 and v.dtype == torch.float16
     v = v.contiguous()
     L.require_gpu(v)
+    if shard is not None and k_out > 0 and shard[1] > 1:
+        return compress_value_sharded(v, bits, group, k_out, rank, loop, mode, P0, shard)
     B, H, T, D = v.shape
     m = _MODES[mode]
     dev = v.device

@@ -15,7 +15,7 @@ void gear_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gear_last_error(void) { return g_err; }
-extern "C" int gear_abi_version(void) { return 4; }
+extern "C" int gear_abi_version(void) { return 5; }
 
 // ---- run-time options ------------------------------------------------------------------------------------------
 // A handful of switches select an alternative (always exact) code path; the tests use them to cover the paths a normal

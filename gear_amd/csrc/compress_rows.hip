@@ -113,11 +113,21 @@ __device__ __forceinline__ uint32_t wave_bitonic_sort(uint32_t v) {
     return v;  // lane i holds the i-th element of the sorted order
 }
 
-template <int BITS, int MODE, typename ST>
+// EXT: the selection is GIVEN (head-sharded V rows, vsel.hip): per row two 36-bit composite thresholds (large side, small side) and
+// the fill value; an element is an outlier of a side when its GLOBAL composite (order key of the side << 20 | 0xFFFFF - (col0 + j))
+// is at or beyond the threshold.  A rank then holds between 0 and k outliers of a row per side: unused list slots carry the index
+// 0xFFFF (beyond every head bound) and the value 0.
+struct ExtSel {
+    const unsigned long long* thr;   // [n_rows][2]
+    const float* fill;               // [n_rows]
+    int col0;                        // global column of this rank's first element
+};
+
+template <int BITS, int MODE, typename ST, bool EXT = false>
 __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm, int len, int group, int k, float zthr,
                                      uint32_t* __restrict__ code, ST* __restrict__ scale, ST* __restrict__ mn,
                                      uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
-                                     uint16_t* __restrict__ oval, float* __restrict__ omean) {
+                                     uint16_t* __restrict__ oval, float* __restrict__ omean, ExtSel ext = ExtSel{nullptr, nullptr, 0}) {
     constexpr int LEVELS = (1 << BITS) - 1;
     constexpr int WPL = BITS / 2;
     constexpr int CPW = 32 / BITS;
@@ -158,7 +168,42 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
     for (int j = 0; j < 16; j++) v[j] = h2f_bits((uint16_t)hb[j]);
 
     uint32_t flag_lo = 0, flag_hi = 0;  // bit j: element j of this lane is an outlier (small / large side)
-    if (k > 0) {
+    if (EXT && k > 0) {
+        const unsigned long long thr_l = ext.thr[r * 2], thr_s = ext.thr[r * 2 + 1];
+        uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k);
+        uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k);
+        for (int i = tid; i < 2 * k; i += blockDim.x) { oi[i] = 0xFFFFu; ov[i] = 0u; }      // (slots this rank does not fill)
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const unsigned long long kx = sort_key(hb[j]), inv = (unsigned long long)(0xFFFFF - (ext.col0 + j0 + j));
+                if (((kx << 20) | inv) >= thr_l) flag_hi |= 1u << j;
+                if ((((0xFFFFull - kx) << 20) | inv) >= thr_s) flag_lo |= 1u << j;
+            }
+        }
+        // sorted lists: exclusive scan of the per-lane counts (the barriers inside also order the padding stores above against
+        // the entries below)
+        unsigned long long cnt = (unsigned long long)__popc(flag_hi) | ((unsigned long long)__popc(flag_lo) << 32);
+        unsigned long long slot = block_excl_scan(cnt, wave_tot, nullptr);
+        int slot_hi = (int)(slot & 0xFFFFFFFFull), slot_lo = (int)(slot >> 32);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (flag_lo & (1u << j)) {
+                if (slot_lo < k) { oi[slot_lo] = (uint16_t)(j0 + j); ov[slot_lo] = (uint16_t)hb[j]; }
+                slot_lo++;
+            }
+            if (flag_hi & (1u << j)) {
+                if (slot_hi < k) { oi[k + slot_hi] = (uint16_t)(j0 + j); ov[k + slot_hi] = (uint16_t)hb[j]; }
+                slot_hi++;
+            }
+        }
+        const float mean = ext.fill[r];
+        const float fill = (MODE == 0) ? hround(mean) : mean;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((flag_lo | flag_hi) & (1u << j)) v[j] = fill;
+    }
+    if (!EXT && k > 0) {
         // ---------------- row mean (of the ORIGINAL row, compress_function.py:276 / :312)
         // summed in fp64: fp16 values add exactly there, so the mean is the correctly rounded one whatever the order -- the oracle's,
         // the block compressor's and the short-row kernel's, and the one a head-sharded job reconstructs from per-rank sums
@@ -1277,6 +1322,42 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
 #undef GO2
 #undef GO
     GEAR_CHECK_LAUNCH("gear_compress_rows");
+    return 0;
+}
+
+// The row compressor with the outlier selection given from outside (head-sharded V rows: vsel.hip finds the thresholds over all
+// ranks).  Same geometry arguments as gear_compress_rows_geom; one workgroup per row (the rows of a shard are short).
+int gear_compress_rows_ext(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride, int nseg,
+                           int seglen, int64_t seg_stride, int64_t o_outer_stride, int64_t o_inner_stride, int64_t o_seg_stride,
+                           int o_list_outer, int group, int bits, int mode, int k, int col0, const void* thr, const void* fill,
+                           void* code, void* scale, void* mn, void* err, void* oidx, void* oval, void* stream) {
+    GEAR_CHECK_ARG(bits == 2 || bits == 4 || bits == 8, "gear_compress_rows_ext: bits must be 2, 4 or 8 (got %d)", bits);
+    GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_compress_rows_ext: bad mode %d", mode);
+    GEAR_CHECK_ARG(n_rows > 0 && n_rows < 0x7FFFFFFFLL && nseg > 0 && seglen > 0, "gear_compress_rows_ext: empty input");
+    const int64_t len = (int64_t)nseg * seglen;
+    GEAR_CHECK_ARG(len <= 16384 && len % 16 == 0, "gear_compress_rows_ext: bad row length %lld", (long long)len);
+    GEAR_CHECK_ARG(group >= 16 && gear_is_pow2(group / 16) && group % 16 == 0 && group <= 1024 && seglen % group == 0,
+                   "gear_compress_rows_ext: group %d must be a power of two in [16,1024] dividing the segment length %d", group, seglen);
+    GEAR_CHECK_ARG(k > 0 && k <= 32767 && thr && fill && oidx && oval, "gear_compress_rows_ext: selection inputs / list outputs missing");
+    GEAR_CHECK_ARG(x && code && scale && mn, "gear_compress_rows_ext: null pointer");
+    GEAR_CHECK_ARG(outer_stride % group == 0 && inner_stride % group == 0 && (nseg == 1 || seg_stride % group == 0) &&
+                   o_outer_stride % group == 0 && o_inner_stride % group == 0 && (nseg == 1 || o_seg_stride % group == 0),
+                   "gear_compress_rows_ext: strides must be multiples of the group size");
+    GEAR_CHECK_ARG(o_list_outer >= rows_inner && col0 >= 0 && col0 + len <= 0xFFFFF, "gear_compress_rows_ext: bad list pitch / column base");
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+    RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride,
+               gear_is_pow2(seglen) ? ilog2(seglen) : -1, ilog2(group), o_outer_stride, o_inner_stride, o_seg_stride, o_list_outer};
+    const int threads = (int)((len / 16 + 63) / 64 * 64);
+    const ExtSel ext{(const unsigned long long*)thr, (const float*)fill, col0};
+    dim3 block(threads), grid((unsigned)n_rows);
+    hipStream_t st = (hipStream_t)stream;
+#define GOX(B, M, STT)                                                                                                 \
+    hipLaunchKernelGGL((compress_rows_kernel<B, M, STT, true>), grid, block, (size_t)threads * 32, st, (const uint16_t*)x, gm, (int)len, group, k, 0.0f, \
+                       (uint32_t*)code, (STT*)scale, (STT*)mn, (uint16_t*)err, (uint16_t*)oidx, (uint16_t*)oval, (float*)nullptr, ext)
+    if (mode == 0) { if (bits == 2) GOX(2, 0, uint16_t); else if (bits == 4) GOX(4, 0, uint16_t); else GOX(8, 0, uint16_t); }
+    else { if (bits == 2) GOX(2, 1, float); else if (bits == 4) GOX(4, 1, float); else GOX(8, 1, float); }
+#undef GOX
+    GEAR_CHECK_LAUNCH("gear_compress_rows_ext");
     return 0;
 }
 

@@ -38,6 +38,10 @@ int gear_lowrank_gram_ex(const void* E, int transposed, int64_t bh, int S, int r
                          int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, int out_dtype,
                          void* workspace, hipStream_t st);
 size_t gear_lowrank_gram_workspace(int64_t bh, int S, int RP);
+int gear_compress_rows_ext(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride, int nseg,
+                           int seglen, int64_t seg_stride, int64_t o_outer_stride, int64_t o_inner_stride, int64_t o_seg_stride,
+                           int o_list_outer, int group, int bits, int mode, int k, int col0, const void* thr, const void* fill,
+                           void* code, void* scale, void* mn, void* err, void* oidx, void* oval, void* stream);
 int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride,
                             int nseg, int seglen, int64_t seg_stride, int64_t o_outer_stride, int64_t o_inner_stride,
                             int64_t o_seg_stride, int o_list_outer, int group, int bits, int mode, int k, void* code,
@@ -1203,6 +1207,37 @@ extern "C" int gear_compress_value_fused(const void* x, int64_t B, int H, int T,
                                            (int64_t)tcap * KD, tcap, group, bits, mode, k, code_o, scale_o, mn_o, err,
                                            oi ? oi + (int64_t)t_off * (2 * k) : nullptr, ov ? ov + (int64_t)t_off * (2 * k) : nullptr,
                                            nullptr, stream);
+    if (rc != 0 || rank == 0) return rc;
+    return gear_lowrank_gram_ex(err, 0, B * H, T, rank, loop, P0, P_out, p_inner, p_outer_stride, Q_out, q_tcap, q_toff,
+                                GEAR_DTYPE_F16, lrws, (hipStream_t)stream);
+}
+
+// gear_compress_value_fused for ONE HEAD SHARD of a tensor whose token rows span the heads of several ranks: the outlier selection
+// of every row comes from outside (gear_vsel_candidates -> all-gather -> gear_vsel_thresholds: the k smallest / largest of the
+// FULL row, compress_function.py:297-333), everything else -- fill, quantize, pack, error, low-rank step, output geometry -- is
+// gear_compress_value_fused's.  col0 = global column of this rank's first element (rank * H_local * 128); thr uint64 [B*T][2],
+// fill float [B*T].  Unused list slots: index 0xFFFF, value 0.
+extern "C" int gear_compress_value_sharded(const void* x, int64_t B, int H, int T, int group, int bits, int mode, int k, void* code,
+                                           void* scale, void* mn, int tcap, int t_off, int rank, int loop, const void* P0, void* P_out,
+                                           int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, void* oidx,
+                                           void* oval, int col0, const void* thr, const void* fill, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    GEAR_CHECK_ARG(x && code && scale && mn && workspace && oidx && oval && thr && fill, "gear_compress_value_sharded: null pointer");
+    GEAR_CHECK_ARG(B > 0 && H > 0 && T > 0 && tcap >= t_off + T && t_off >= 0 && k > 0, "gear_compress_value_sharded: bad shape");
+    GEAR_CHECK_ARG(workspace_bytes >= gear_compress_value_fused_workspace(B, H, T, rank), "gear_compress_value_sharded: workspace too small");
+    GEAR_CHECK_ARG(rank == 0 || (P0 && P_out && Q_out && loop >= 1 && q_tcap >= q_toff + T && p_inner >= 1),
+                   "gear_compress_value_sharded: bad factor geometry");
+    const int cpw = 32 / (bits ? bits : 2);
+    const int sel = mode == GEAR_MODE_FP16_STEPWISE ? 2 : 4;
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    uint16_t* err = rank > 0 ? (uint16_t*)base : nullptr;
+    void* lrws = rank > 0 ? (void*)(base + (((size_t)B * H * T * KD * 2 + 255) & ~(size_t)255)) : nullptr;
+    char* code_o = (char*)code + (size_t)t_off * KD / cpw * 4;
+    char* scale_o = (char*)scale + (size_t)t_off * KD / group * sel;
+    char* mn_o = (char*)mn + (size_t)t_off * KD / group * sel;
+    const int rc = gear_compress_rows_ext(x, B * T, T, (int64_t)H * T * KD, KD, H, KD, (int64_t)T * KD, (int64_t)H * tcap * KD, KD,
+                                          (int64_t)tcap * KD, tcap, group, bits, mode, k, col0, thr, fill, code_o, scale_o, mn_o, err,
+                                          (uint16_t*)oidx + (int64_t)t_off * (2 * k), (uint16_t*)oval + (int64_t)t_off * (2 * k), stream);
     if (rc != 0 || rank == 0) return rc;
     return gear_lowrank_gram_ex(err, 0, B * H, T, rank, loop, P0, P_out, p_inner, p_outer_stride, Q_out, q_tcap, q_toff,
                                 GEAR_DTYPE_F16, lrws, (hipStream_t)stream);

@@ -168,6 +168,30 @@ int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group,
                               int64_t p_inner, int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, void* oidx,
                               void* oval, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- head-sharded V rows: the outlier selection of a row that spans the heads of several GPUs ------------------------------
+ * gears_tokenQ selects the k smallest and k largest values of a token's row over ALL heads (compress_function.py:297-333, two
+ * torch.topk over H * D columns) and fills them with the row mean.  With the heads spread over `world` ranks:
+ *   gear_vsel_candidates   this rank's part of every row (same row geometry as gear_compress_rows: n_rows rows of nseg segments of
+ *                          seglen contiguous fp16 elements) -> cand uint64 [n_rows][2k + 1]: per side its k best elements as global
+ *                          composites (16-bit order key << 20 | 0xFFFFF - global column: ties -> lower column), then the exact
+ *                          fp64 sum of the local part (bit pattern).  col0 = global column of the rank's first element.
+ *   (the ranks all-gather cand -> cand_all [world][n_rows][2k + 1]; 8 (2k + 1) bytes per row and rank)
+ *   gear_vsel_thresholds   -> thr uint64 [n_rows][2] (the k-th largest composite, large side then small side), fill float [n_rows]
+ *                          (mean of the full row of row_len_total elements; mode 0: rounded to fp16 like the row kernels' fill)
+ *   gear_compress_value_sharded = gear_compress_value_fused with that selection instead of its own: a rank stores the outliers
+ *                          that fall into its heads (0 .. k per side and row; unused list slots: index 0xFFFF, value 0).
+ * The concatenated shard payloads are the unsharded payload (mode 0: bit for bit; mode 1: the unsharded kernel's fill is an fp32
+ * tree sum, here it is the correctly rounded mean -- the last place of the fill can differ, the selection cannot).
+ * The reference has no multi-GPU path; this keeps its single-GPU semantics under head sharding. */
+int gear_vsel_candidates(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride, int nseg,
+                         int seglen, int64_t seg_stride, int k, int col0, void* cand, void* stream);
+int gear_vsel_thresholds(const void* cand_all, int world, int64_t n_rows, int k, int64_t row_len_total, int mode, void* thr,
+                         void* fill, void* stream);
+int gear_compress_value_sharded(const void* x, int64_t B, int H, int T, int group, int bits, int mode, int k, void* code, void* scale,
+                                void* mn, int tcap, int t_off, int rank, int loop, const void* P0, void* P_out, int64_t p_inner,
+                                int64_t p_outer_stride, void* Q_out, int q_tcap, int q_toff, void* oidx, void* oval, int col0,
+                                const void* thr, const void* fill, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a12 (KCVT variants): ONE quantization group per row -------------------------------------------------------------
  * Replaces fake_groupwise_channel_asymmetric_quantization_new(key, bits, seq_len) and
  * fake_groupwise_token_asymmetric_quantization(value, bits, num_head * sep_dim) of the KCVT / GEAR-KCVT / GEARL-KCVT branches

@@ -217,3 +217,88 @@ def test_head_sharded_graph_decode():
         assert captured
         assert same, r
         assert agree > 0.9, (r, agree)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 5: the exact cross-shard V outlier selection in HIP (csrc/vsel.hip), held to the unsharded payload in ONE process: the
+# "ranks" are head slices of one tensor, the all-gather is a torch.stack.
+def _shard_payloads(C, P, v, world, k, bits, rank_, mode, P0):
+    B, H, T, D = v.shape
+    Hl = H // world
+    m = 0 if mode == "fp16" else 1
+    shards = [v[:, r * Hl:(r + 1) * Hl].contiguous() for r in range(world)]
+    cand_all = torch.stack([P.v_candidates(s, k, r) for r, s in enumerate(shards)])
+    thr, fill = P.v_thresholds(cand_all, k, H * D, m)
+    return [C.compress_value(s, bits, 64, k_out=k, rank=rank_, loop=3, mode=mode,
+                             P0=None if P0 is None else P0[:, r * Hl:(r + 1) * Hl].contiguous(), shard=(r, world, (thr, fill)))
+            for r, s in enumerate(shards)], thr, fill
+
+
+@pytest.mark.parametrize("H,T,world,s,bits,rank_", [(32, 256, 8, 0.02, 2, 8), (32, 128, 2, 0.02, 2, 0), (8, 192, 4, 0.05, 4, 4),
+                                                   (40, 64, 4, 0.01, 2, 8), (4, 320, 4, 0.1, 2, 0)])
+def test_hip_exact_v_selection_shards_are_the_unsharded_payload(H, T, world, s, bits, rank_):
+    """gear_vsel_candidates -> (gather) -> gear_vsel_thresholds -> gear_compress_value_sharded on every head shard of a tensor, in the
+    cache's fp16-stepwise arithmetic: codes, scale, zero point, error-derived factors and the sparse lists of the shards, put side by
+    side, ARE the unsharded payload bit for bit (7B on 8 / 2 ranks, a GQA-sized row on 4, 13B's 40 heads on 4, one head per rank)."""
+    from gear_amd import compress as C
+    from gear_amd import parallel as P
+    torch.manual_seed(70)
+    B, D = 2, 128
+    v = torch.randn(B, H, T, D).half().cuda()
+    v[0, :, 5, :7] = 3.0                                          # ties across heads at the large side's boundary region
+    k = C.outlier_count(B, H, T, D, s)
+    P0 = torch.rand(B, H, D, rank_).cuda() if rank_ else None
+    full = C.compress_value(v, bits, 64, k_out=k, rank=rank_, loop=3, mode="fp16", P0=P0)
+    shards, thr, fill = _shard_payloads(C, P, v, world, k, bits, rank_, "fp16", P0)
+    Hl = H // world
+    cat = lambda name: torch.cat([getattr(p, name) for p in shards], 1)
+    assert torch.equal(cat("code"), full.code) and torch.equal(cat("scale"), full.scale) and torch.equal(cat("mn"), full.mn)
+    if rank_:
+        assert torch.equal(cat("P"), full.P) and torch.equal(cat("Q"), full.Q)
+    # lists: a shard's entries (local column + its column base), in rank order, are the full row's sorted list; pads are 0xFFFF / 0
+    fo, fv = full.oidx.cpu().numpy().astype("int64") & 0xFFFF, full.oval.cpu().numpy().view("uint16")
+    so = [p.oidx.cpu().numpy().astype("int64") & 0xFFFF for p in shards]
+    sv = [p.oval.cpu().numpy().view("uint16") for p in shards]
+    import numpy as np
+    for side in (0, 1):
+        sl = slice(side * k, (side + 1) * k)
+        got_i = np.concatenate([np.where(so[r][:, :, sl] == 0xFFFF, 1 << 30, so[r][:, :, sl] + r * Hl * D) for r in range(world)], 2)
+        got_v = np.concatenate([sv[r][:, :, sl] for r in range(world)], 2)
+        order = np.argsort(got_i, 2, kind="stable")
+        got_i, got_v = np.take_along_axis(got_i, order, 2), np.take_along_axis(got_v, order, 2)
+        assert np.array_equal(got_i[:, :, :k], fo[:, :, sl]) and np.array_equal(got_v[:, :, :k], fv[:, :, sl])
+        assert (got_i[:, :, k:] == 1 << 30).all() and (got_v[:, :, k:] == 0).all()      # every shard list sorted, padded at its end
+
+
+@pytest.mark.parametrize("H,T,world,s", [(32, 128, 8, 0.02), (8, 128, 2, 0.05)])
+def test_hip_exact_v_selection_fp32_mode_and_torch_cross_check(H, T, world, s):
+    """The simulated (fp32) arithmetic: the shards select exactly the unsharded outliers; codes / scale / zero point equal the unsharded
+    payload's except where the LAST place of the fill value matters (the unsharded kernel sums the row in an fp32 tree, the sharded
+    path has the correctly rounded mean): at most a handful of words.  And the thresholds / fill agree with the round-4 torch
+    implementation (parallel.exact_v_selection) on what each rank keeps."""
+    from gear_amd import compress as C
+    from gear_amd import parallel as P
+    import numpy as np
+    torch.manual_seed(71)
+    B, D = 1, 128
+    v = torch.randn(B, H, T, D).half().cuda()
+    k = C.outlier_count(B, H, T, D, s)
+    full = C.compress_value(v, 2, 64, k_out=k, mode="fp32")
+    shards, thr, fill = _shard_payloads(C, P, v, world, k, 2, 0, "fp32", None)
+    Hl = H // world
+    fo = full.oidx.cpu().numpy().astype("int64") & 0xFFFF
+    for side in (0, 1):
+        sl = slice(side * k, (side + 1) * k)
+        got = np.sort(np.concatenate([np.where((p.oidx.cpu().numpy().astype("int64") & 0xFFFF)[:, :, sl] == 0xFFFF, 1 << 30,
+                                               (p.oidx.cpu().numpy().astype("int64") & 0xFFFF)[:, :, sl] + r * Hl * D)
+                                      for r, p in enumerate(shards)], 2), 2)[:, :, :k]
+        assert np.array_equal(got, fo[:, :, sl])
+    code = torch.cat([p.code for p in shards], 1)
+    assert int((code != full.code).sum()) <= 4 and int((torch.cat([p.scale for p in shards], 1) != full.scale).sum()) <= 2
+    # torch cross-check (single process: world == 1 view of one shard against the HIP thresholds is not possible; compare on the
+    # whole row instead -- rank 0 of a world of 1 keeps everything)
+    filled, mask, oidx_t, oval_t = P.exact_v_selection(v, k, 0, 1)
+    assert np.array_equal(oidx_t.cpu().numpy().astype("int64") & 0xFFFF, fo)
+    m16 = fill.cpu().numpy()                                       # fp32 fill of the full row: (float)(exact sum / length)
+    want = (v.double().permute(0, 2, 1, 3).reshape(B * T, H * D).sum(1) / (H * D)).float().cpu().numpy()
+    assert np.array_equal(m16, want)
