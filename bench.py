@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the full-model decode tokens/s leg")
     ap.add_argument("--decode-tokens", type=int, default=64)
+    ap.add_argument("--v-selection", default="exact", choices=("exact", "per_shard"),
+                    help="sharded legs (--gpus N / --emulate-world N): V outliers selected over the FULL token row (one small "
+                         "all-gather of candidates per compress call; the shard payloads are the unsharded payload) or k / N "
+                         "inside the shard's own heads (rounds 1-3); the other one's V chain time is reported beside it")
     ap.add_argument("--exchange", default="both", choices=("peer", "collective", "both"),
                     help="world > 1, decode leg: the head-shard exchange -- 'peer' = stores into hipIpc-mapped peer memory "
                          "(gear_xchg_allgather), 'collective' = all_gather_into_tensor (RCCL), 'both' = one decode leg each")
@@ -281,7 +285,8 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64, exchange="both"):
     ids = torch.randint(0, mcfg.vocab_size, (1, prompt), device=dev)
     res = {"context": T, "batch": 1, "weights": f"random init, {cfg['model']} shapes",
            "method": "gearslKIVI %d-bit, rank %d per block, %.0f%% outliers (V rows: reference count%s; K prompt rows: reference "
-                     "count, K 64-token blocks: nominal count), residual 64" % (bits, rnk, s * 100, " / world per shard" if world > 1 else ""),
+                     "count, K 64-token blocks: nominal count), residual 64"
+                     % (bits, rnk, s * 100, ", selected over the full row across the ranks (FastGearDecoder v_selection='exact')" if world > 1 else ""),
            "parallelism": f"head-shard x{world}"}
     from gear_amd.fast_decode import FastGearDecoder
 
@@ -331,13 +336,13 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64, exchange="both"):
         torch.cuda.empty_cache()
         return out
 
-    modes = ["peer"] if world == 1 else (["peer", "collective"] if exchange == "both" else [exchange])
+    modes = ["peer"] if world == 1 else (["collective", "peer"] if exchange == "both" else [exchange])
     legs = {m: leg(m) for m in modes}
     head = legs[modes[0]]
     res.update({k: v for k, v in head.items() if k != "exchange_class"})
     if world > 1:
-        # both exchanges of the head-sharded token step, each measured: north_star names the RCCL all-gather, the peer-store
-        # kernel is the build's default
+        # both exchanges of the head-sharded token step, each measured: the RCCL all-gather north_star names is the default and
+        # the headline (round 5), the peer-store kernel the option
         res["exchange_modes"] = {m: {k: v for k, v in l.items() if k != "outliers_per_side"} for m, l in legs.items()}
         res["exchange_default"] = modes[0]
     best = head["tokens_per_s"]
@@ -406,10 +411,13 @@ def main():
     assert H % shards == 0, "KV heads must divide across ranks"
     Hl = H // shards
     # k per side: reference formula on the FULL row (compress_function.py:265-267 / :300-303); K rows live inside a head
-    # (count independent of the sharding), per-shard V rows take k / N
+    # (count independent of the sharding).  V rows span the heads: sharded legs run the EXACT cross-shard selection (the full row's
+    # k, a shard keeps what falls into its heads: csrc/vsel.hip); --v-selection per_shard = k / N inside the shard (rounds 1-3)
     k_full = C.outlier_count(1, H, T, D, sparsity)
     k_key = min(k_full, T // 2)
-    k_val = max(1, k_full // shards) if k_full else 0
+    v_exact = shards > 1 and k_full > 0 and args.v_selection == "exact"
+    k_val = k_full if (v_exact or shards == 1) else (max(1, k_full // shards) if k_full else 0)
+    k_val_per_shard = max(1, k_full // shards) if k_full else 0
     key_path = args.key_path
 
     torch.manual_seed(1234 + rank)
@@ -424,8 +432,35 @@ def main():
     def comp_k(x, p0):
         return C.compress_key(x, bits, group, k_out=k_key, rank=rnk, loop=loop, mode="fp32", P0=p0, path=key_path)
 
+    # exact selection: with a process group the candidates of the other ranks arrive by all-gather; the one-GPU emulation of a
+    # rank's shard holds the other ranks' candidates fixed (made once, outside the timed region, from random heads of the same
+    # shape) and does this rank's share per step: its own candidates, the thresholds over all of them, the sharded compress
+    emu_others = {}
+
+    def others_for(nl):
+        if nl not in emu_others:
+            from gear_amd import parallel as P_
+            g_ = torch.Generator(device=dev).manual_seed(99)
+            oth = []
+            for r in range(1, shards):
+                vv = torch.randn((nl, Hl, T, D), device=dev, dtype=torch.float16, generator=g_)
+                oth.append(P_.v_candidates(vv, k_val, r))
+                del vv
+            emu_others[nl] = torch.stack(oth)
+        return emu_others[nl]
+
     def comp_v(x, p0):
-        return C.compress_value(x, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=p0)
+        if not v_exact:
+            return C.compress_value(x, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=p0)
+        if world > 1:
+            return C.compress_value(x, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=p0, shard=(rank, world, None))
+        from gear_amd import parallel as P_
+        own = P_.v_candidates(x.contiguous(), k_val, 0)
+        thr_fill = P_.v_thresholds(torch.cat([own[None], others_for(x.shape[0])]), k_val, H * D, 1)
+        return C.compress_value(x, bits, group, k_out=k_val, rank=rnk, loop=loop, mode="fp32", P0=p0, shard=(0, shards, thr_fill))
+
+    def comp_v_per_shard(x, p0):
+        return C.compress_value(x, bits, group, k_out=k_val_per_shard, rank=rnk, loop=loop, mode="fp32", P0=p0)
 
     ev = {}
 
@@ -472,6 +507,7 @@ def main():
         return outs[0] if parts == 1 else outs
 
     step = step_streams if args.streams >= 2 else step_serial
+    comp_v_exact = comp_v
 
     def sync():
         torch.cuda.synchronize()
@@ -512,6 +548,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # sharded legs: the same timed loop once more with the OTHER V selection (k / N inside the shard's own heads, rounds 1-3) --
+    # `value` is the exact selection (the algorithm of N = 1), `value_per_shard_selection` stands beside it
+    dt_other = None
+    if v_exact:
+        comp_v = comp_v_per_shard
+        for _ in range(max(1, args.warmup)):
+            out = step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        sync()
+        dt_other = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_other], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_other = float(t.item())
+        comp_v = comp_v_exact
     del out
     n = K.numel()                                 # elements per tensor kind, this rank
     BH = layers * Hl
@@ -543,7 +597,8 @@ def main():
     # (8n/g) and the indices uint16 (4 bytes per outlier) -- `stored_bytes`, not used for any fraction.
     def payload_bytes(kind, stored=False):
         rows = BH * D if kind == "k" else layers * T
-        kk = k_key if kind == "k" else k_val
+        # (a head shard under the exact selection keeps on average k / N of a row's outliers per side: that, not its list capacity)
+        kk = k_key if kind == "k" else (k_val_per_shard if shards > 1 else k_val)
         return (n * bits / 8 + (8 if stored else 4) * n / group
                 + 2 * rnk * (T + D) * BH                     # P, Q fp16
                 + rows * 2 * kk * (4 if stored else 6))
@@ -555,6 +610,53 @@ def main():
     chain = {nme: {"alg_bytes": alg[nme], "stored_bytes": stored[nme], "ms": stages[nme],
                    "achieved": alg[nme] / (stages[nme] * 1e-3) / 1e9,
                    "frac": alg[nme] / (stages[nme] * 1e-3) / 1e9 / HBM_PEAK_GBS} for nme in names}
+
+    # ---- sharded legs: the other V selection's chain time, and the start-up self-check "concatenated shard payloads == unsharded
+    # payload" on a 256-token tensor (all ranks hold the same seeded full tensor; each compresses its head shard with the exact
+    # selection in the cache's fp16-stepwise arithmetic, rank 0 also the whole tensor; shards are gathered and compared bit for bit)
+    shard_info = None
+    if shards > 1 and k_full > 0:
+        def time_v(fn):
+            for _ in range(2):
+                fn(V, P0v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                fn(V, P0v)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 3
+        other = comp_v_per_shard if v_exact else None
+        shard_info = {"v_selection": args.v_selection, "v_outliers_per_side": k_val,
+                      "v_compress_ms": stages["v_compress"],
+                      "per_shard": {"v_outliers_per_side": k_val_per_shard,
+                                    "v_compress_ms": time_v(other) if other else stages["v_compress"]},
+                      "launches_of_the_selection": "gear_vsel_candidates + all-gather + gear_vsel_thresholds; the row compressor takes "
+                                                   "the selection (gear_compress_value_sharded)" if v_exact else "inside the row compressor"}
+        from gear_amd import parallel as P_
+        torch.manual_seed(4242)
+        Tt, kt = 256, max(1, C.outlier_count(1, H, 256, D, sparsity))
+        vt = torch.randn((2, H, Tt, D), device=dev, dtype=torch.float16)
+        p0t = torch.rand((2, H, D, rnk), device=dev, dtype=torch.float32)
+        full = C.compress_value(vt, bits, group, k_out=kt, rank=rnk, loop=loop, mode="fp16", P0=p0t)
+        my = rank if world > 1 else 0
+        if world > 1:
+            mine = C.compress_value(vt[:, my * Hl:(my + 1) * Hl].contiguous(), bits, group, k_out=kt, rank=rnk, loop=loop, mode="fp16",
+                                    P0=p0t[:, my * Hl:(my + 1) * Hl].contiguous(), shard=(my, world, None))
+            parts = {n: P_.all_gather_stack(getattr(mine, n), world) for n in ("code", "scale", "mn")}
+            cat = {n: torch.cat(list(t), 1) for n, t in parts.items()}
+        else:
+            sh_ = [vt[:, r * Hl:(r + 1) * Hl].contiguous() for r in range(shards)]
+            thr_fill = P_.v_thresholds(torch.stack([P_.v_candidates(x_, kt, r) for r, x_ in enumerate(sh_)]), kt, H * D, 0)
+            ps = [C.compress_value(x_, bits, group, k_out=kt, rank=rnk, loop=loop, mode="fp16",
+                                   P0=p0t[:, r * Hl:(r + 1) * Hl].contiguous(), shard=(r, shards, thr_fill)) for r, x_ in enumerate(sh_)]
+            cat = {n: torch.cat([getattr(p_, n) for p_ in ps], 1) for n in ("code", "scale", "mn")}
+        shard_info["shard_parity"] = bool(all(torch.equal(cat[n], getattr(full, n)) for n in ("code", "scale", "mn")))
+        shard_info["shard_parity_what"] = (f"{'ranks' if world > 1 else 'emulated head shards on one GPU'}: codes + scale + zero point of the "
+                                           f"{shards} shards of a [2, {H}, 256, 128] tensor, concatenated, == the unsharded payload "
+                                           "(fp16-stepwise arithmetic, exact selection)")
+        del vt, full, cat
 
     # ---- the large kernels one by one (HIP events around back-to-back launches of ONE kernel on the launch stream)
     def timed(fn, reps=5, warm=2):
@@ -572,11 +674,12 @@ def main():
     # (1) the V row compressor: outlier select + fill + quantize + pack + error, one launch over all layers
     geom_v = (layers * T, T, Hl * T * D, D, Hl, D, T * D)
     errb = torch.empty((layers, Hl, T, D), dtype=torch.float16, device=dev)
-    rows_out = C._alloc_rows(tuple(V.shape), layers * T, group, bits, 1, k_val, dev)
-    ms_rows = timed(lambda: C._compress_rows(V, geom_v, group, bits, 1, k_val, rows_out, errb))
-    b_rows = 2 * n + n * bits / 8 + 4 * n / group + layers * T * 2 * k_val * 6      # SURVEY 8(d) verbatim
+    k_rows = k_val_per_shard if v_exact else k_val       # (the standalone row compressor selects for itself: the shard's own count)
+    rows_out = C._alloc_rows(tuple(V.shape), layers * T, group, bits, 1, k_rows, dev)
+    ms_rows = timed(lambda: C._compress_rows(V, geom_v, group, bits, 1, k_rows, rows_out, errb))
+    b_rows = 2 * n + n * bits / 8 + 4 * n / group + layers * T * 2 * k_rows * 6      # SURVEY 8(d) verbatim
     rows_len = Hl * D
-    rows_name = (f"compress_rows_wave_kernel<{bits}, {rows_len // 1024}, fast + fallback pass>" if rows_len % 1024 == 0 and (rows_len <= 5120 or rows_len == 8192) and k_val <= 58
+    rows_name = (f"compress_rows_wave_kernel<{bits}, {rows_len // 1024}, fast + fallback pass>" if rows_len % 1024 == 0 and (rows_len <= 5120 or rows_len == 8192) and k_rows <= 58
                  else f"compress_rows_fp32_kernel<{bits}, float>")
     kernels.append({"kernel": rows_name + " (V rows: select + fill + quantize + pack + error)",
                     "ms": ms_rows, "alg_bytes": b_rows, "not_counted": "the fp16 error it also writes (2n bytes): an intermediate"})
@@ -713,6 +816,12 @@ def main():
             "roofline_chain": chain,
             "kernels": kernels,
         }
+        if shard_info is not None:
+            if dt_other is not None:
+                shard_info["per_shard"]["value_GBps"] = 2 * fp16_bytes_job * args.steps / dt_other / 1e9
+                shard_info["per_shard"]["ms_per_step"] = dt_other / args.steps * 1e3
+                res["value_per_shard_selection"] = shard_info["per_shard"]["value_GBps"]
+            res["sharding"] = shard_info
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
     del K, V, kr, vr, pk, pv, out, qv

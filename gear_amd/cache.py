@@ -178,7 +178,7 @@ def _draw_p0(shape_local, gen, dev, tp):
 def _compress_value_exact(bufs, d, lead, B, H, D, v_src, T, t_off, seg, loop, P0v, tp, kk0, seg0):
     """V payload of a head shard with the outliers selected over the WHOLE token row (all ranks' heads), bit-identical to the matching
     head slice of the unsharded payload (tests/test_gpu_parallel.py).  Round 5: in HIP -- gear_vsel_candidates, ONE all-gather of
-    8 (2 kv + 1) bytes per row and rank, gear_vsel_thresholds, then gear_compress_value_sharded (the row compressor with the selection
+    4 (2 kv + 2) bytes per row and rank, gear_vsel_thresholds, then gear_compress_value_sharded (the row compressor with the selection
     given + the usual low-rank step) writing straight behind token t_off of the cache: 3 launches + the chain's low-rank kernels where
     round 4 ran ~25 torch launches (parallel.exact_v_selection: two topk, where, gather ...; kept as the tests' cross-check with
     tp["exact"] == "torch")."""

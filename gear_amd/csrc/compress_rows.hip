@@ -113,12 +113,12 @@ __device__ __forceinline__ uint32_t wave_bitonic_sort(uint32_t v) {
     return v;  // lane i holds the i-th element of the sorted order
 }
 
-// EXT: the selection is GIVEN (head-sharded V rows, vsel.hip): per row two 36-bit composite thresholds (large side, small side) and
-// the fill value; an element is an outlier of a side when its GLOBAL composite (order key of the side << 20 | 0xFFFFF - (col0 + j))
+// EXT: the selection is GIVEN (head-sharded V rows, vsel.hip): per row two 32-bit composite thresholds (large side, small side) and
+// the fill value; an element is an outlier of a side when its GLOBAL composite (order key of the side << 16 | 0xFFFF - (col0 + j))
 // is at or beyond the threshold.  A rank then holds between 0 and k outliers of a row per side: unused list slots carry the index
 // 0xFFFF (beyond every head bound) and the value 0.
 struct ExtSel {
-    const unsigned long long* thr;   // [n_rows][2]
+    const uint32_t* thr;             // [n_rows][2]
     const float* fill;               // [n_rows]
     int col0;                        // global column of this rank's first element
 };
@@ -169,16 +169,16 @@ __global__ void compress_rows_kernel(const uint16_t* __restrict__ x, RowGeom gm,
 
     uint32_t flag_lo = 0, flag_hi = 0;  // bit j: element j of this lane is an outlier (small / large side)
     if (EXT && k > 0) {
-        const unsigned long long thr_l = ext.thr[r * 2], thr_s = ext.thr[r * 2 + 1];
+        const uint32_t thr_l = ext.thr[r * 2], thr_s = ext.thr[r * 2 + 1];
         uint16_t* oi = oidx + lrow_of(gm, r) * (int64_t)(2 * k);
         uint16_t* ov = oval + lrow_of(gm, r) * (int64_t)(2 * k);
         for (int i = tid; i < 2 * k; i += blockDim.x) { oi[i] = 0xFFFFu; ov[i] = 0u; }      // (slots this rank does not fill)
         if (active) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const unsigned long long kx = sort_key(hb[j]), inv = (unsigned long long)(0xFFFFF - (ext.col0 + j0 + j));
-                if (((kx << 20) | inv) >= thr_l) flag_hi |= 1u << j;
-                if ((((0xFFFFull - kx) << 20) | inv) >= thr_s) flag_lo |= 1u << j;
+                const uint32_t kx = sort_key(hb[j]), inv = (uint32_t)(0xFFFF - (ext.col0 + j0 + j));
+                if (((kx << 16) | inv) >= thr_l) flag_hi |= 1u << j;
+                if ((((0xFFFFu - kx) << 16) | inv) >= thr_s) flag_lo |= 1u << j;
             }
         }
         // sorted lists: exclusive scan of the per-lane counts (the barriers inside also order the padding stores above against
@@ -1343,12 +1343,12 @@ int gear_compress_rows_ext(const void* x, int64_t n_rows, int rows_inner, int64_
     GEAR_CHECK_ARG(outer_stride % group == 0 && inner_stride % group == 0 && (nseg == 1 || seg_stride % group == 0) &&
                    o_outer_stride % group == 0 && o_inner_stride % group == 0 && (nseg == 1 || o_seg_stride % group == 0),
                    "gear_compress_rows_ext: strides must be multiples of the group size");
-    GEAR_CHECK_ARG(o_list_outer >= rows_inner && col0 >= 0 && col0 + len <= 0xFFFFF, "gear_compress_rows_ext: bad list pitch / column base");
+    GEAR_CHECK_ARG(o_list_outer >= rows_inner && col0 >= 0 && col0 + len <= 0xFFFF, "gear_compress_rows_ext: bad list pitch / column base");
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
     RowGeom gm{rows_inner, outer_stride, inner_stride, nseg, seglen, seg_stride,
                gear_is_pow2(seglen) ? ilog2(seglen) : -1, ilog2(group), o_outer_stride, o_inner_stride, o_seg_stride, o_list_outer};
     const int threads = (int)((len / 16 + 63) / 64 * 64);
-    const ExtSel ext{(const unsigned long long*)thr, (const float*)fill, col0};
+    const ExtSel ext{(const uint32_t*)thr, (const float*)fill, col0};
     dim3 block(threads), grid((unsigned)n_rows);
     hipStream_t st = (hipStream_t)stream;
 #define GOX(B, M, STT)                                                                                                 \

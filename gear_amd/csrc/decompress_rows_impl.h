@@ -153,15 +153,18 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
 #pragma unroll
             for (int q = 0; q < PF; q++) {
                 const int rr = pf_rc[q] >> 16;
-                if (rr >= 0 && row0 + phys(rbase) + rr < g.n_rows) lval[rr * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+                // (an index beyond the row = an unused slot of a head shard's list, 0xFFFF: gear_compress_value_sharded)
+                if (rr >= 0 && row0 + phys(rbase) + rr < g.n_rows && (int)pf_idx[q] < g.len) lval[rr * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
             }
             prefetch_entries(rbase + g.trows);
         } else {
             for (int e = tid; e < fill_n; e += blockDim.x) {
                 const int ri = e / per_row_t;
                 const int64_t row = row0 + phys(rbase) + ri;
-                if (row < g.n_rows)
-                    lval[(size_t)ri * g.len + oidx[row * per_row_t + e % per_row_t]] = (uint16_t)~oval[row * per_row_t + e % per_row_t];
+                if (row < g.n_rows) {
+                    const int ix = oidx[row * per_row_t + e % per_row_t];
+                    if (ix < g.len) lval[(size_t)ri * g.len + ix] = (uint16_t)~oval[row * per_row_t + e % per_row_t];
+                }
             }
         }
         __syncthreads();
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < PF; q++)
-                        if (pf_rc[q] >= 0) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+                        if (pf_rc[q] >= 0 && (int)pf_idx[q] < g.len) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
                     if (R1) { if (i + 4 < 16) prefetch_entries_all(i + 4); }
                     else if (i * R + g.trows < g.rpb) prefetch_entries_all(i * R + g.trows);
                     __syncthreads();
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             const int64_t row = row0 + ri;
             const int rin = (int)(row % g.rows_inner);
             const uint32_t idx = oidx[row * per_row + e % per_row];
+            if ((int)idx >= g.len) continue;                       // (unused slot of a head shard's list)
             float v = h2f_bits(oval[row * per_row + e % per_row]);
             const int sg = (int)idx / g.seglen, ps = (int)idx % g.seglen;
             if (r > 0) {
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(256) void decompress_sparse_kernel(DGeom g, const u
     const int64_t row = e / per_row;
     const int ro = (int)(row / g.rows_inner), rin = (int)(row % g.rows_inner);
     const uint32_t idx = oidx[e];
+    if ((int)idx >= g.len) return;                                 // (unused slot of a head shard's list)
     float v = h2f_bits(oval[e]);
     const int sg = (int)idx / g.seglen, ps = (int)idx % g.seglen;
     const int r = g.r;

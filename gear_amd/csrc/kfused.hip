@@ -1215,7 +1215,7 @@ extern "C" int gear_compress_value_fused(const void* x, int64_t B, int H, int T,
 // gear_compress_value_fused for ONE HEAD SHARD of a tensor whose token rows span the heads of several ranks: the outlier selection
 // of every row comes from outside (gear_vsel_candidates -> all-gather -> gear_vsel_thresholds: the k smallest / largest of the
 // FULL row, compress_function.py:297-333), everything else -- fill, quantize, pack, error, low-rank step, output geometry -- is
-// gear_compress_value_fused's.  col0 = global column of this rank's first element (rank * H_local * 128); thr uint64 [B*T][2],
+// gear_compress_value_fused's.  col0 = global column of this rank's first element (rank * H_local * 128); thr uint32 [B*T][2],
 // fill float [B*T].  Unused list slots: index 0xFFFF, value 0.
 extern "C" int gear_compress_value_sharded(const void* x, int64_t B, int H, int T, int group, int bits, int mode, int k, void* code,
                                            void* scale, void* mn, int tcap, int t_off, int rank, int loop, const void* P0, void* P_out,

@@ -20,17 +20,19 @@ from .modeling_llamagear import apply_rotary_pos_emb
 
 class FastGearDecoder:
     def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0, tp_rank: int = 0, tp_world: int = 1,
-                 tp_group=None, tp_exchange: str = "peer", v_selection: str = "exact"):
+                 tp_group=None, tp_exchange: str = "collective", v_selection: str = "exact"):
         """tp_world > 1: the cache and the attention are sharded head-wise: this rank owns
         Hq / tp_world query heads with their KV heads -- local q/k/v projection rows, local compressed cache, local attention --
         and all-gathers the per-rank attention output (parallel.HeadGather, pre-allocated) in front of the replicated
         o_proj / MLP, which every rank computes in full.  The model passed in holds the full (replicated) weights.
-        tp_exchange: "peer" = parallel.PeerHeadGather (stores into the peers' memory from one launch per layer, capturable in
-        the token-step graph; falls back to the collective, on every rank alike, when the peer mappings cannot be set up),
-        "collective" = parallel.HeadGather (all_gather_into_tensor; captured too when the RCCL capture probe passes).
+        tp_exchange: "collective" (default since round 5: the RCCL all-gather north_star names) = parallel.HeadGather
+        (all_gather_into_tensor into a pre-allocated buffer; captured in the token-step graph when the RCCL capture probe passes),
+        "peer" = parallel.PeerHeadGather (stores into the peers' hipIpc-mapped memory from one launch per layer, always capturable;
+        falls back to the collective, on every rank alike, when the peer mappings cannot be set up).  Neither has run on more than
+        one GPU yet (no multi-GPU node was ever available to this build): the collective is the conservative default.
         v_selection: "exact" = the V outliers of a token row are selected over ALL ranks' heads (the reference's row spans the heads:
-        compress_function.py:304-311; parallel.exact_v_selection, one small all-gather per compress call), "per_shard" = k / world
-        inside the shard's own heads (rounds 1-3)."""
+        compress_function.py:304-311; csrc/vsel.hip through parallel.exact_v_thresholds: two launches + one small all-gather per
+        compress call), "per_shard" = k / world inside the shard's own heads (rounds 1-3)."""
         self.model = model
         cfg = model.config
         self.cfg = cfg

@@ -107,25 +107,25 @@ def exact_v_selection(v: torch.Tensor, k: int, rank: int, world: int, group=None
 
 def v_candidates(v: torch.Tensor, k: int, rank: int, T: int = None) -> torch.Tensor:
     """gear_vsel_candidates on this rank's heads: v fp16 [NB, H_local, Tp, 128] contiguous (rows = the first T <= Tp tokens) ->
-    int64 [NB*T, 2k + 1] (k best global composites per side + the fp64 bit pattern of the local row sum)."""
+    int32 [NB*T, 2k + 2] (k best global composites per side + the fp64 bit pattern of the local row sum in two words)."""
     from . import _lib as L
     NB, H, Tp, D = v.shape
     T = Tp if T is None else T
     L.require_gpu(v)
     assert v.is_contiguous() and v.dtype == torch.float16 and D == 128
     rows = NB * T
-    cand = torch.empty((rows, 2 * k + 1), dtype=torch.int64, device=v.device)
+    cand = torch.empty((rows, 2 * k + 2), dtype=torch.int32, device=v.device)
     L.check(L.load().gear_vsel_candidates(L.ptr(v), rows, T, H * Tp * D, D, H, D, Tp * D, k, rank * H * D, L.ptr(cand),
                                           L.stream_ptr(v)), "gear_vsel_candidates")
     return cand
 
 
 def v_thresholds(cand_all: torch.Tensor, k: int, row_len_total: int, mode: int = 0):
-    """gear_vsel_thresholds: cand_all int64 [world, rows, 2k + 1] -> (thr int64 [rows, 2], fill float32 [rows])."""
+    """gear_vsel_thresholds: cand_all int32 [world, rows, 2k + 2] -> (thr int32 [rows, 2], fill float32 [rows])."""
     from . import _lib as L
     world, rows = cand_all.shape[0], cand_all.shape[1]
     cand_all = cand_all.contiguous()
-    thr = torch.empty((rows, 2), dtype=torch.int64, device=cand_all.device)
+    thr = torch.empty((rows, 2), dtype=torch.int32, device=cand_all.device)
     fill = torch.empty((rows,), dtype=torch.float32, device=cand_all.device)
     L.check(L.load().gear_vsel_thresholds(L.ptr(cand_all), world, rows, k, row_len_total, mode, L.ptr(thr), L.ptr(fill),
                                           L.stream_ptr(cand_all)), "gear_vsel_thresholds")
@@ -135,9 +135,9 @@ def v_thresholds(cand_all: torch.Tensor, k: int, row_len_total: int, mode: int =
 def exact_v_thresholds(v: torch.Tensor, k: int, rank: int, world: int, group=None, mode: int = 0, T: int = None):
     """The exact cross-shard V outlier selection on the GPU (csrc/vsel.hip; round 5): two launches + ONE all-gather where
     exact_v_selection above runs ~25 torch launches incl. two topk.  v fp16 [NB, H_local, Tp, 128] contiguous (the first T <= Tp
-    tokens of every head are the rows); returns (thr uint64-as-int64 [NB*T, 2], fill float32 [NB*T]) for
+    tokens of every head are the rows); returns (thr uint32-as-int32 [NB*T, 2], fill float32 [NB*T]) for
     gear_compress_value_sharded: per row the k-th largest composite per side over ALL ranks' candidates and the full row's mean
-    (mode 0: rounded to fp16).  Exchange: 8 (2k + 1) bytes per row and rank."""
+    (mode 0: rounded to fp16).  Exchange: 4 (2k + 2) bytes per row and rank."""
     cand = v_candidates(v, k, rank, T)
     allc = all_gather_stack(cand, world, group) if world > 1 else cand[None]
     return v_thresholds(allc, k, world * v.shape[1] * v.shape[3], mode)

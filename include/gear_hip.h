@@ -172,11 +172,12 @@ int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group,
  * gears_tokenQ selects the k smallest and k largest values of a token's row over ALL heads (compress_function.py:297-333, two
  * torch.topk over H * D columns) and fills them with the row mean.  With the heads spread over `world` ranks:
  *   gear_vsel_candidates   this rank's part of every row (same row geometry as gear_compress_rows: n_rows rows of nseg segments of
- *                          seglen contiguous fp16 elements) -> cand uint64 [n_rows][2k + 1]: per side its k best elements as global
- *                          composites (16-bit order key << 20 | 0xFFFFF - global column: ties -> lower column), then the exact
- *                          fp64 sum of the local part (bit pattern).  col0 = global column of the rank's first element.
- *   (the ranks all-gather cand -> cand_all [world][n_rows][2k + 1]; 8 (2k + 1) bytes per row and rank)
- *   gear_vsel_thresholds   -> thr uint64 [n_rows][2] (the k-th largest composite, large side then small side), fill float [n_rows]
+ *                          seglen contiguous fp16 elements) -> cand uint32 [n_rows][2k + 2]: per side its k best elements as global
+ *                          composites (16-bit order key << 16 | 0xFFFF - global column: ties -> lower column), then the exact
+ *                          fp64 sum of the local part (bit pattern, two words).  col0 = global column of the rank's first element;
+ *                          a full row has at most 65535 elements.
+ *   (the ranks all-gather cand -> cand_all [world][n_rows][2k + 2]; 4 (2k + 2) bytes per row and rank)
+ *   gear_vsel_thresholds   -> thr uint32 [n_rows][2] (the k-th largest composite, large side then small side), fill float [n_rows]
  *                          (mean of the full row of row_len_total elements; mode 0: rounded to fp16 like the row kernels' fill)
  *   gear_compress_value_sharded = gear_compress_value_fused with that selection instead of its own: a rank stores the outliers
  *                          that fall into its heads (0 .. k per side and row; unused list slots: index 0xFFFF, value 0).

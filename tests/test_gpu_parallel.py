@@ -187,8 +187,10 @@ def _graph_worker(rank, world, port, ret):
         model = LlamaForCausalLM_GEARKIVI(cfg, cc).half().cuda().eval()
         torch.manual_seed(1)
         ids = torch.randint(0, 1000, (1, 150)).cuda()
-        eager = FastGearDecoder(model, 512, seed=5, tp_rank=rank, tp_world=world)
-        graph = FastGearDecoder(model, 512, seed=5, tp_rank=rank, tp_world=world)
+        # (the peer-store exchange: capturable on any backend; the default exchange -- the all-gather collective -- is captured only
+        # when RCCL passes its capture probe, which two ranks on one GPU over gloo cannot exercise)
+        eager = FastGearDecoder(model, 512, seed=5, tp_rank=rank, tp_world=world, tp_exchange="peer")
+        graph = FastGearDecoder(model, 512, seed=5, tp_rank=rank, tp_world=world, tp_exchange="peer")
         full = FastGearDecoder(model, 512, seed=5)
         assert eager.gather.capturable and graph.gather.capturable, (eager.exchange_error, graph.exchange_error)
         n_new = 90                                                # crosses a block boundary inside the replayed part
@@ -268,6 +270,10 @@ def test_hip_exact_v_selection_shards_are_the_unsharded_payload(H, T, world, s, 
         got_i, got_v = np.take_along_axis(got_i, order, 2), np.take_along_axis(got_v, order, 2)
         assert np.array_equal(got_i[:, :, :k], fo[:, :, sl]) and np.array_equal(got_v[:, :, :k], fv[:, :, sl])
         assert (got_i[:, :, k:] == 1 << 30).all() and (got_v[:, :, k:] == 0).all()      # every shard list sorted, padded at its end
+    # and back: a shard's payload decompresses (padded list slots skipped) to the matching heads of the unsharded reconstruction
+    rec = C.decompress(full)
+    for r, p in enumerate(shards):
+        assert torch.equal(C.decompress(p), rec[:, r * Hl:(r + 1) * Hl])
 
 
 @pytest.mark.parametrize("H,T,world,s", [(32, 128, 8, 0.02), (8, 128, 2, 0.05)])
