@@ -878,10 +878,32 @@ extern "C" int gear_compress_block(const gear_cache_view* c, int t_off, int o_of
     const size_t shmem = (size_t)64 * BT_PITCH * 2 + (rmax > 0 ? blk_lr_lds_bytes(RP) : 0);
     const dim3 grid((unsigned)(2 * NB * H));
     hipStream_t st = (hipStream_t)stream;
+    // Forward progress of the flag hand-off (file header): a V tile's rows belong to workgroups dispatched before it or at most 63
+    // after it, so the device must hold 64 of these workgroups AT ONCE (and dispatch them in order, as the hardware does).  Checked
+    // at launch time, per kernel instantiation and LDS size, against the device's own occupancy figure -- a configuration that
+    // cannot co-reside (a future larger tile, a partitioned GPU with a handful of CUs) is refused with an error instead of spinning
+    // into the 1 s poll bound (round 4: only the bound existed).
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || n_cu <= 0) n_cu = 1;
+    }
 #define BLK_GO3(B, GG, RR)                                                                                         \
     do {                                                                                                           \
         auto kfn = block_compress_kernel<B, GG, RR>;                                                               \
         if (shmem > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        if (a.rows_per_blk > 0) {                                                                                  \
+            static size_t occ_shmem = (size_t)-1;                                                                  \
+            static int occ = 0;                                                                                    \
+            if (occ_shmem != shmem) {                                                                              \
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64, shmem) != hipSuccess) occ = 0; \
+                occ_shmem = shmem;                                                                                 \
+            }                                                                                                      \
+            GEAR_CHECK_ARG((int64_t)occ * n_cu >= 64, "gear_compress_block: only %d workgroups of this kernel fit on the device " \
+                           "at once (%d per CU x %d CUs); the row-duty hand-off needs 64 resident -- use the kernel chain", \
+                           occ * n_cu, occ, n_cu);                                                                 \
+        }                                                                                                          \
         hipLaunchKernelGGL(kfn, grid, dim3(64), shmem, st, a);                                                     \
     } while (0)
 #define BLK_GO(B, GG)                                                                                              \
