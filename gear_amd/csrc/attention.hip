@@ -1258,6 +1258,14 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     if (ex && ex->vtile && ex->vcnt && a.kv && ex->vtile_cap >= 256) {
         a.vtile = (const uint32_t*)ex->vtile; a.vcnt = (const int*)ex->vcnt; a.vtile_cap = ex->vtile_cap; a.nblk = ex->nblk;
     }
+    // With sparse tiles in the view the chunk indices are dead weight for the short-chunk kernel: it still issued their loads with
+    // everything else (two bytes per thread, each from a different cache line of a [lists][bounds] table: ~16 KB of sectors per
+    // workgroup for a 14 KB chunk) although only a tile that overflowed (count -1: rare) would look at them -- that case searches
+    // the lists instead.  Option attn_keep_chunk_index restores the round-4 behaviour (A/B runs).
+    if (!gear_options().attn_keep_chunk_index) {
+        if (a.ktile) a.kochunk = nullptr;
+        if (a.vtile) a.vochunk = nullptr;
+    }
     a.nbv = Hkv + 1;
     a.kP_seg_stride = (int64_t)B * Hkv * AD * a.rk;
     a.vP_seg_stride = (int64_t)B * Hkv * AD * a.rv;
