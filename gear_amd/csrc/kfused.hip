@@ -1011,6 +1011,10 @@ KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
     // slabs: enough workgroups to fill the chip (>= ~2 per CU) without drowning the solve in partial Gram traffic
     int nslab = 1;
     while (nslab < 4 && BH * nslab < 2048 && ntiles / (nslab * 2) >= 8) nslab *= 2;       // (8 slabs for the 80 heads of 70B / 8: 0.406 -> 0.435 ms)
+    if (gear_options().kfused_nslab > 0) {                                               // (A/B runs)
+        nslab = gear_options().kfused_nslab;
+        while (nslab > 1 && ntiles / nslab < 4) nslab /= 2;
+    }
     w.nslab = nslab;
     w.tiles_per_slab = (ntiles + nslab - 1) / nslab;
     const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);

@@ -1,5 +1,6 @@
-"""PMC / kernel-trace target (GPU box): the compress and decompress kernels of one bench step at BASELINE config 3 size, 3 launches each, after a
-1 GiB copy as calibration (1 GiB read + 1 GiB written).  usage: python tools/prof_step.py [layers]"""
+"""PMC / kernel-trace target (GPU box): the compress and decompress kernels of one bench step at BASELINE config 3 size (config 2 with
+GEAR_PROF_CONFIG=c2), 3 launches each, after a copy of the same tensor as calibration (bytes read = bytes written = the tensor).
+usage: python tools/prof_step.py [layers]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +8,8 @@ from gear_amd import compress as C
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 H, T, D, g, bits, rank, k = 32, 4096, 128, 64, 2, 8, 40
+if os.environ.get("GEAR_PROF_CONFIG") == "c2":          # BASELINE configs[1]: T = 2048, 4 bits, rank 4, 1 % outliers
+    T, bits, rank, k = 2048, 4, 4, C.outlier_count(1, H, 2048, D, 0.01)
 torch.manual_seed(0)
 x = torch.empty((L, H, T, D), dtype=torch.float16, device="cuda")
 for l in range(L):
