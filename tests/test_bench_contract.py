@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json", "r3_bench_line.json", "r4_bench_line.json"])
+@pytest.mark.parametrize("line", ["r1_final_bench_line.json", "r2_bench_line.json", "r3_bench_line.json", "r4_bench_line.json",
+                                  "r5_bench_line.json"])
 def test_committed_bench_line_has_the_contract_fields(line):
     d = json.load(open(os.path.join(ROOT, "profiles", line)))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
@@ -29,7 +30,7 @@ def test_committed_bench_line_has_the_contract_fields(line):
     # value = fp16 KV bytes through compress + decompress per second, whole job
     n = 32 * 32 * 4096 * 128
     assert abs(d["value"] - 2 * (2 * n * 2) / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
-    if line.startswith(("r3", "r4")):
+    if line.startswith(("r3", "r4", "r5")):
         # round 3 on: the headline roofline object is the compress CHAIN north_star names (the lower of K / V), with the PMC traffic of
         # its launches; the dominant single kernel rides along; the decode-time block boundary is measured and reported
         assert r["kernel"].startswith(("k_compress chain", "v_compress chain")) and "dominant_kernel" in r
@@ -43,6 +44,22 @@ def test_committed_bench_line_has_the_contract_fields(line):
         assert bb["traffic"] is None or bb["traffic"] >= 0.9 * bb["alg_bytes"]
         assert abs(d["decode"]["block_compress_ms"] - bb["block_kernel_us"] * 1e-3) < 1e-9
         assert "numpy_glue" in c and c["value"] > c["numpy_glue"]["value"]
+    if line.startswith("r5"):
+        # round 5 (ADVICE): the untimed pre-warm is IN the line; bytes follow SURVEY 8(d) verbatim (4n/g for scale / mn,
+        # 6 bytes per outlier) with the stored format beside them; the dominant kernel carries its duration alone AND inside the
+        # two-stream step; the attention by batch stands beside an fp16-cache baseline; value vs stage timing is explained in the line
+        assert d["prewarm_steps"] >= 0 and d["prewarm_s"] >= 0 and (d["prewarm_steps"] == 0) == (d["prewarm_s"] < 0.5)
+        assert "timing_note" in d and "4n/g" in r["bytes_definition"] and "6 bytes per outlier" in r["bytes_definition"]
+        v = d["roofline_chain"]["v_compress"]
+        assert v["alg_bytes"] == 2 * n + n / 4 + 4 * n / 64 + 2 * 8 * (4096 + 128) * 1024 + 131072 * 80 * 6 and v["stored_bytes"] > v["alg_bytes"]
+        dk = r["dominant_kernel"]
+        assert dk["ms_per_launch_in_step"] is None or dk["ms_per_launch_in_step"] >= dk["ms_per_launch"]
+        assert r["traffic"] is not None and r["traffic"] >= r["alg_bytes_per_launch"] and "r5_traffic.json" in r["traffic_source"]
+        by_b = d["attn_decode"]["one_layer_streaming_cache_by_batch"]
+        for b in ("B1", "B4", "B16"):
+            assert by_b[b]["fp16_cache_us_per_call"] > 0
+            assert abs(by_b[b]["speedup_vs_fp16_cache"] - by_b[b]["fp16_cache_us_per_call"] / by_b[b]["us_per_call"]) < 1e-9
+        assert d["decode"]["hook_module_tokens_per_s"] >= 200.0
     if line.startswith("r4"):
         # round 4: the V chain is rows -> wave-private Gram kernel -> per-head solve -> Q pass; the PMC traffic of the chain is tied to
         # the library that produced the line; the hook module (the documented import swap) runs on its fast path
@@ -63,10 +80,12 @@ def test_committed_bench_line_has_the_contract_fields(line):
         assert d["decode"]["outliers_per_side"]["v_row"] == 40 and "2% outliers" in d["decode"]["method"]
 
 
-@pytest.mark.parametrize("name", ["r2_traffic.json", "r3_traffic.json", "r4_traffic.json"])
+@pytest.mark.parametrize("name", ["r2_traffic.json", "r3_traffic.json", "r4_traffic.json", "r5_traffic.json", "r5c2_traffic.json"])
 def test_traffic_profile_names_the_library_it_was_measured_on(name):
     t = json.load(open(os.path.join(ROOT, "profiles", name)))
-    assert len(t["lib_sha256"]) == 64 and t["config"] == "c3" and t["kernels"] and "FETCH_SIZE" in t["how"]
+    assert len(t["lib_sha256"]) == 64 and t["config"] == ("c2" if "c2" in name else "c3") and t["kernels"] and "FETCH_SIZE" in t["how"]
+    if name.startswith("r5"):
+        assert t["bench_step_avg_us"] and all(v > 0 for v in t["bench_step_avg_us"].values())
     assert all(v > 0 for v in t["kernels"].values())
 
 
@@ -105,3 +124,20 @@ def test_sharded_line_reports_both_exchanges():
     assert abs(d["decode"]["tokens_per_s"] - modes["peer"]["tokens_per_s"]) < 1e-6 * modes["peer"]["tokens_per_s"] + 30.0   # (MAX over ranks)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"--exchange", default="both"' in src
+
+
+def test_round5_sharded_lines_report_both_selections_and_shard_parity():
+    """Sharded legs: `value` is the EXACT cross-shard V selection -- the algorithm of N = 1 --, the k / N per-shard
+    selection stands beside it, and a start-up self-check compares the concatenated shard payloads with the unsharded payload.
+    profiles/r5_emulation.jsonl: one rank's shard emulated on one GPU; profiles/r5_bench_2rank_one_gpu.json: two real ranks (gloo, both on
+    one GPU: control flow, not a multi-GPU measurement), RCCL-style collective exchange first."""
+    lines = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r5_emulation.jsonl"))]
+    assert len(lines) == 6 and lines[0]["sharding"] is None
+    for d in lines[1:]:
+        sh = d["sharding"]
+        assert sh["v_selection"] == "exact" and sh["shard_parity"] is True
+        assert sh["per_shard"]["v_outliers_per_side"] <= sh["v_outliers_per_side"] and sh["per_shard"]["ms_per_step"] <= d["ms_per_step"] * 1.05
+        assert abs(d["value_per_shard_selection"] - sh["per_shard"]["value_GBps"]) < 1e-9
+    d = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_2rank_one_gpu.json")))
+    assert d["n_gpus"] == 2 and d["sharding"]["shard_parity"] is True and d["sharding"]["v_selection"] == "exact"
+    assert d["decode"]["exchange_default"] == "collective" and set(d["decode"]["exchange_modes"]) == {"peer", "collective"}
