@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "ktile.h"
 
 namespace {
 
@@ -999,6 +1000,435 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     }   // query heads of the group
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Matrix-core variant of the short-chunk kernel (round 5): dequantize ONCE per KV head, contract on the matrix cores.
+//
+// The kernel above is bound by vector instructions per QUERY head: extract + convert + multiply-add per cached element, then
+// ~250 instructions of cross-lane butterflies to sum over channels / tokens -- and for grouped-query attention all of it again for
+// every query head of the group.  Here the chunk's CODES go into an LDS tile once, as exact small integers in fp16 (no scale, no
+// zero point: 1.5 instructions per element, `(w >> s) & 0x00030003 | 0x6400 6400` then a packed subtract of 1024), and
+//     S[h, t] = sum_c (q[h, c] sc[c, g(t)]) code[c, t]  +  sum_c q[h, c] mn[c, g(t)]
+//     O[h, d] = sum_t (p[h, t] sc[t, g(d)]) code[t, d]  +  sum_t p[h, t] mn[t, g(d)]
+// are v_mfma_f32_32x32x16_f16 with the scaled q / p rows as the A operand (fp16 head + remainder: exact to 2^-22; up to 8 query
+// heads are rows of the SAME instruction) and the integer tile as the B operand through ds_read_b64_tr_b16 (ktile.h).  The
+// matrix cores do the multiply-adds AND the sums over the 128 channels / tokens; the constant terms are two short reductions.
+// Outliers: the stored corrections (value - dequant, fp16) are scattered into the zeroed tile -- one LDS store per entry, no
+// atomics, whatever the number of query heads -- and one more pass of MFMAs with the unscaled q / p adds them.
+// Token / channel ORDER inside the tile: a code word's pairs come out as (j, j + CPW/2); they are stored as they come, so tile
+// column 2k + b of a CPW-group is element k + (CPW/2) b; scores / outputs are written back through the same map.
+// Requirements (else the kernel above): group 64, sparse tiles in the view or no outliers, Hq / Hkv in {1, 2, 4, 8}.
+__device__ __forceinline__ int mt_logical(int p, int cpw) {      // tile column -> element index
+    const int h = cpw >> 1, r = p & (cpw - 1);
+    return (p & ~(cpw - 1)) | (r >> 1) | ((r & 1) ? h : 0);
+}
+__device__ __forceinline__ int mt_physical(int e, int cpw) {     // element index -> tile column
+    const int h = cpw >> 1, r = e & (cpw - 1);
+    return (e & ~(cpw - 1)) | ((r & (h - 1)) << 1) | (r >= h ? 1 : 0);
+}
+// the CPW codes of a word as fp16 integers, pairs (j, j + CPW/2), into CPW consecutive halfs of a tile row (16-byte aligned)
+template <int BITS>
+__device__ __forceinline__ void mt_store_codes(uint16_t* dst, uint32_t w) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t FM = ((1u << BITS) - 1u) * 0x00010001u;
+    uint32_t z[CPW / 2];
+#pragma unroll
+    for (int k = 0; k < CPW / 2; k++) {
+        const uint32_t y = ((w >> (BITS * k)) & FM) | 0x64006400u;          // (1024 + code k, 1024 + code k + CPW/2), exact
+        asm("v_pk_add_f16 %0, %1, %2" : "=v"(z[k]) : "v"(y), "v"(0xE400E400u));   // - 1024
+    }
+#pragma unroll
+    for (int v4 = 0; v4 < CPW / 8; v4++) ((uint4*)dst)[v4] = make_uint4(z[4 * v4], z[4 * v4 + 1], z[4 * v4 + 2], z[4 * v4 + 3]);
+}
+
+template <int BITS, typename ST, int RS, int NREP>
+__global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
+    constexpr bool R16 = RS == 16;
+    constexpr int RW = R16 ? 16 : 8;
+    constexpr int CPW = 32 / BITS;
+    constexpr int WPR = SC / CPW;            // words per 128-element row (8 | 16)
+    constexpr int RSUB = 256 / WPR;          // rows covered per pass (32 | 16)
+    constexpr int WPT = AD / RSUB;           // words per thread and side (4 | 8)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[SC * ET_PITCH];    // [row = contraction index][column]
+    __shared__ __attribute__((aligned(16))) uint16_t aop[2][2][NREP][AD];   // A operands: [group][head / remainder][query head][k]
+    __shared__ __attribute__((aligned(16))) uint16_t araw[2][NREP][AD];     // q exact (K deltas); p head / remainder (V deltas)
+    __shared__ __attribute__((aligned(16))) float s[NREP][SC];              // scores, then p, then the output rows
+    __shared__ float up[NREP][4][RW];
+    __shared__ float wsl[NREP][2][RW];
+    __shared__ float cst[NREP][4];
+    __shared__ float ot[NREP][AD];
+    __shared__ float mlh[NREP][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x;
+    int b, hkv;
+    int64_t bhq0;
+    if (NREP == 1) {
+        bhq0 = blockIdx.y;
+        b = (int)(bhq0 / a.Hq);
+        hkv = (int)(bhq0 % a.Hq) / (a.Hq / a.Hkv);
+    } else {
+        b = (int)blockIdx.y / a.Hkv;
+        hkv = (int)blockIdx.y % a.Hkv;
+        bhq0 = (int64_t)b * a.Hq + (int64_t)hkv * NREP;
+    }
+    const int64_t bhk = (int64_t)b * a.Hkv + hkv;
+    const int t0 = split * SC;
+    const int Tc = a.dyn ? a.dyn[2] : a.T;
+    const int tn = min(SC, Tc - t0);
+    if (tn <= 0) {
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            const int64_t pe = (bhq0 + r) * a.pslots + split;
+            if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
+            if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
+        }
+        return;
+    }
+    const ST* kscale = (const ST*)a.kscale;
+    const ST* kmn = (const ST*)a.kmn;
+    const ST* vscale = (const ST*)a.vscale;
+    const ST* vmn = (const ST*)a.vmn;
+
+    // ------------------------------------------------------------------ every load of the chunk (all unconditional)
+    const int dq = tid & (AD - 1), half_ = tid >> 7;   // (channel | token, group | slab | side)
+    auto seg_at = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
+    const int seg_s0 = seg_at(t0), seg_s1 = seg_at(min(t0 + 64, t0 + tn - 1));
+    float qf[NREP];                                    // q[h][dq] * qscale
+    uint16_t qb[NREP];
+#pragma unroll
+    for (int r = 0; r < NREP; r++) qb[r] = a.q[(bhq0 + r) * AD + dq];
+    const int wl = tid & (WPR - 1), rsub = tid / WPR;
+    uint32_t kw[WPT], vw[WPT];
+    {
+        const uint32_t* kc_b = a.kcode + bhk * AD * (int64_t)a.ldk + t0 / CPW;
+        const uint32_t wlc = (wl * CPW < tn) ? (uint32_t)wl : 0u;
+#pragma unroll
+        for (int i = 0; i < WPT; i++) kw[i] = kc_b[(uint32_t)(rsub + RSUB * i) * (uint32_t)a.ldk + wlc];
+        const uint32_t* vc_b = a.vcode + (bhk * a.tcap_v + t0) * (int64_t)WPR;
+#pragma unroll
+        for (int i = 0; i < WPT; i++) vw[i] = vc_b[(uint32_t)min(rsub + RSUB * i, tn - 1) * WPR + wl];
+    }
+    // scale / zero point: K of (channel dq, 64-token group half_), V of (token dq, 64-channel group half_)
+    const uint32_t gk = (uint32_t)(min(t0 + 64 * half_, t0 + tn - 1)) / 64u;
+    const float ksc1 = ld_st<ST>(kscale + (bhk * AD + dq) * (int64_t)a.lsk + gk), kmn1 = ld_st<ST>(kmn + (bhk * AD + dq) * (int64_t)a.lsk + gk);
+    const bool tok_ok = dq < tn;
+    const int64_t vrow = (bhk * a.tcap_v + t0 + min(dq, tn - 1)) * 2 + half_;
+    float vsc1 = ld_st<ST>(vscale + vrow), vmn1 = ld_st<ST>(vmn + vrow);
+    const uint4* dummy16 = (const uint4*)(a.q + bhq0 * AD);
+    const uint32_t trow = (uint32_t)min(dq, tn - 1);
+    const int64_t fseg = half_ ? (int64_t)seg_s1 : (int64_t)seg_s0;
+    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    const uint4* kqp = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RS + trow * RS) : dummy16;
+    const uint4* vpp = a.rv ? (const uint4*)(a.vP + fseg * a.vP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RS + trow * RS) : dummy16;
+    auto ldrow = [](const uint4* p) {
+        if (RS == 4) { const uint2 t = *(const uint2*)p; return make_uint4(t.x, t.y, 0u, 0u); }
+        return p[0];
+    };
+    const uint4 kp8 = ldrow(kpp), kq8 = ldrow(kqp), vp8 = ldrow(vpp), vq8 = ldrow(vqp);
+    const uint4 kp8b = R16 ? kpp[1] : kp8, kq8b = R16 ? kqp[1] : kq8, vp8b = R16 ? vpp[1] : vp8, vq8b = R16 ? vqp[1] : vq8;
+    const bool has_ktile = a.ktile && a.kk > 0, has_vtile = a.vtile && a.kv > 0;
+    const int64_t vb = bhk * a.nblk + 2 * split;
+    const int* kcp = has_ktile ? a.kcnt + bhk * a.nck + split : (const int*)dummy16;
+    const uint32_t* ktp = has_ktile ? a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap + tid : (const uint32_t*)dummy16;
+    const int* vcp = has_vtile ? a.vcnt + vb : (const int*)dummy16;
+    const uint32_t* vtp = has_vtile ? a.vtile + vb * a.vtile_cap + tid : (const uint32_t*)dummy16;
+    const int kc_n = has_ktile ? kcp[0] : 0, vc_n0 = has_vtile ? vcp[0] : 0, vc_n1 = (has_vtile && tn > 64) ? vcp[1] : 0;
+    const uint32_t ke0 = ktp[0], ke1 = ktp[has_ktile ? 256 : 0], ve0 = vtp[0], ve1 = vtp[has_vtile ? a.vtile_cap : 0];
+    if (!tok_ok) { vsc1 = 0.0f; vmn1 = 0.0f; }
+
+    typedef union { uint4 u; half8_t h; } U8;
+    const int x31 = lane & 31, kg = lane >> 5;
+    const int g_w = wave >> 1;                          // the 64-element group the wave's 32 tile columns lie in
+    // zero the tile / scatter corrections into it / one pass of MFMAs with the rows araw[part][m][:] (part 0, or 0 and 1)
+    auto zero_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < (SC * ET_PITCH * 2) / (256 * 16); i++) ((uint4*)tile)[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto mfma_pass = [&](const uint16_t* A0, const uint16_t* A1, float16_t acc) {     // A rows: [NREP][AD] halfs; A1 may be null
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            U8 ah, al;
+            ah.u = al.u = make_uint4(0u, 0u, 0u, 0u);
+            if (x31 < NREP) {
+                ah.u = *(const uint4*)(A0 + x31 * AD + 16 * ks + 8 * kg);
+                if (A1) al.u = *(const uint4*)(A1 + x31 * AD + 16 * ks + 8 * kg);
+            }
+            const half8_t bo = load_operand<true>(tile, 16 * ks, wave, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bo, acc, 0, 0, 0);
+            if (A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bo, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto split16 = [](float x, uint16_t& hi, uint16_t& lo) {
+        hi = f2h_bits(x);
+        lo = f2h_bits(x - h2f_bits(hi));
+    };
+
+    // ------------------------------------------------------------------ 1. K: code tile, scaled q rows, constant term, Pk^T q
+#pragma unroll
+    for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * ET_PITCH + CPW * wl, kw[i]);
+    {
+        float cp[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) cp[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NREP; r++) {
+            qf[r] = h2f_bits(qb[r]) * a.qscale;
+            uint16_t hi, lo;
+            split16(qf[r] * ksc1, hi, lo);
+            aop[half_][0][r][dq] = hi;
+            aop[half_][1][r][dq] = lo;
+            if (half_ == 0) araw[0][r][dq] = qb[r];
+            cp[r] = qf[r] * kmn1;
+        }
+        const float cr = reduce8_over_wave(cp, lane);       // over the wave's 64 channels; lanes 0, 8, .. hold head lane / 8
+        if ((lane & 7) == 0 && (lane >> 3) < NREP) cst[lane >> 3][wave] = cr;
+    }
+    if (a.rk) {
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            float qv = qf[0];
+#pragma unroll
+            for (int rr = 1; rr < NREP; rr++) qv = (r == rr) ? qf[rr] : qv;
+            float pr[8];
+            unpack8(kp8, pr);
+#pragma unroll
+            for (int c = 0; c < 8; c++) pr[c] *= qv;
+            const float r1 = reduce8_over_wave(pr, lane);
+            if ((lane & 7) == 0) up[r][wave][lane >> 3] = r1;
+            if (R16) {
+                unpack8(kp8b, pr);
+#pragma unroll
+                for (int c = 0; c < 8; c++) pr[c] *= qv;
+                const float r2 = reduce8_over_wave(pr, lane);
+                if ((lane & 7) == 0) up[r][wave][8 + (lane >> 3)] = r2;
+            }
+        }
+    }
+    __syncthreads();
+    float16_t acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], acc);
+    if (kc_n != 0) {                                       // K outliers: stored corrections through the zeroed tile
+        __syncthreads();
+        zero_tile();
+        __syncthreads();
+        if (kc_n > 0) {
+            const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
+            for (int e = tid; e < kc_n; e += 256) {
+                const uint32_t ke = e == tid ? ke0 : (e == tid + 256 ? ke1 : kt[e]);
+                tile[(ke & 127u) * ET_PITCH + mt_physical((int)((ke >> 7) & 127u), CPW)] = (uint16_t)(ke >> 16);
+            }
+        } else {   // the chunk's tile overflowed (count -1): the sorted lists, one per (channel dq, side half_)
+            const int64_t chn = bhk * AD + dq;
+            const uint16_t* oi = a.koidx + (chn * 2 + half_) * (int64_t)a.kk_stride;
+            const uint16_t* ov = a.koval + (chn * 2 + half_) * (int64_t)a.kk_stride;
+            int r0[2], r1[2];
+            k_list_ranges(a, oi, Tc, t0, tn, r0, r1);
+            for (int rg = 0; rg < 2; rg++)
+                for (int i = r0[rg]; i < r1[rg]; i++) {
+                    const int t = oi[i];
+                    if (t >= t0 + tn) break;
+                    if (t < t0) continue;
+                    const uint32_t word = a.kcode[chn * (int64_t)a.ldk + t / CPW];
+                    const float sc = ld_st<ST>(kscale + chn * (int64_t)a.lsk + t / a.group), mv = ld_st<ST>(kmn + chn * (int64_t)a.lsk + t / a.group);
+                    const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & ((1u << BITS) - 1u)), mv);
+                    tile[dq * ET_PITCH + mt_physical(t - t0, CPW)] = f2h_bits(h2f_bits(ov[i]) - deq);
+                }
+        }
+        __syncthreads();
+        float16_t ad;
+#pragma unroll
+        for (int q = 0; q < 16; q++) ad[q] = 0.0f;
+        ad = mfma_pass(&araw[0][0][0], nullptr, ad);
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = fmaf(a.qscale, ad[q], acc[q]);
+    }
+    {   // scores of (head q + 4 kg, tile column 32 wave + x31) + the constant term of the column's group
+        const int tok = mt_logical(32 * wave + x31, CPW);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int m = q + 4 * kg;
+            if (m < NREP) s[m][tok] = acc[q] + (cst[m][2 * g_w] + cst[m][2 * g_w + 1]);
+        }
+    }
+    __syncthreads();
+    if (a.rk && tid < SC) {                                // + Qk[t] . (Pk[seg(slab)]^T q) per head; token tid, slab = wave
+        float tq[8], tq2[8];
+        unpack8(kq8, tq);
+        if (R16) unpack8(kq8b, tq2);
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            float accl = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) accl = fmaf(tq[c], up[r][2 * wave][c] + up[r][2 * wave + 1][c], accl);
+            if (R16) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) accl = fmaf(tq2[c], up[r][2 * wave][8 + c] + up[r][2 * wave + 1][8 + c], accl);
+            }
+            s[r][tid] += accl;
+        }
+    }
+    if (a.rk) __syncthreads();
+    // ------------------------------------------------------------------ 2. softmax statistics: 32 lanes per query head
+    {
+        const int h = tid >> 5, j = tid & 31;
+        if (h < NREP) {
+            float v[4], mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = j + 32 * i;
+                v[i] = t < tn ? s[h][t] : -INFINITY;
+                mx = fmaxf(mx, v[i]);
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = j + 32 * i;
+                const float pv = t < tn ? __expf(v[i] - mx) : 0.0f;
+                sum += pv;
+                s[h][t] = pv;
+                uint16_t hi, lo;
+                split16(pv, hi, lo);
+                araw[0][h][t] = hi;
+                araw[1][h][t] = lo;
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            if (j == 0) { mlh[h][0] = mx; mlh[h][1] = sum; }
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ 3. V: code tile, scaled p rows, constant term, Qv^T p
+#pragma unroll
+    for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * ET_PITCH + CPW * wl, vw[i]);
+    {
+        float cp[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) cp[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NREP; r++) {
+            const float pv = s[r][dq];                      // (token dq; 0 beyond the chunk)
+            uint16_t hi, lo;
+            split16(pv * vsc1, hi, lo);
+            aop[half_][0][r][dq] = hi;
+            aop[half_][1][r][dq] = lo;
+            cp[r] = pv * vmn1;
+        }
+        const float cr = reduce8_over_wave(cp, lane);       // over the wave's 64 tokens
+        if ((lane & 7) == 0 && (lane >> 3) < NREP) cst[lane >> 3][wave] = cr;
+    }
+    if (a.rv && tid < SC) {                                // wsl[h][slab][:] = sum over the slab's tokens of p[h][t] Qv[t][:]; slab = wave
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            const float pv = s[r][tid];
+            float wv[8];
+            unpack8(vq8, wv);
+#pragma unroll
+            for (int c = 0; c < 8; c++) wv[c] *= pv;
+            const float r1 = reduce8_over_wave(wv, lane);
+            if ((lane & 7) == 0) wsl[r][wave][lane >> 3] = r1;
+            if (R16) {
+                unpack8(vq8b, wv);
+#pragma unroll
+                for (int c = 0; c < 8; c++) wv[c] *= pv;
+                const float r2 = reduce8_over_wave(wv, lane);
+                if ((lane & 7) == 0) wsl[r][wave][8 + (lane >> 3)] = r2;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], acc);
+    if (vc_n0 != 0 || vc_n1 != 0) {                        // V outliers of the chunk's two 64-token blocks
+        __syncthreads();
+        zero_tile();
+        __syncthreads();
+        for (int hb = 0; hb < 2; hb++) {
+            const int n = hb ? vc_n1 : vc_n0;
+            const uint32_t* vt = a.vtile + (vb + hb) * (int64_t)a.vtile_cap;
+            for (int e = tid; e < n; e += 256) {
+                const uint32_t ve = e == tid ? (hb ? ve1 : ve0) : vt[e];
+                tile[(64 * hb + (int)(ve & 63u)) * ET_PITCH + mt_physical((int)((ve >> 6) & 127u), CPW)] = (uint16_t)(ve >> 16);
+            }
+        }
+        if (((dq < 64) ? vc_n0 : vc_n1) < 0 && tok_ok) {   // this token's block overflowed its tile: the row's sorted list, side half_
+            const int c_lo = hkv * AD, c_hi = c_lo + AD;
+            const int64_t orow = (int64_t)b * a.tcap_v + t0 + dq, row = bhk * a.tcap_v + t0 + dq;
+            const uint16_t* oi = a.voidx + (orow * 2 + half_) * a.kv;
+            const uint16_t* ov = a.voval + (orow * 2 + half_) * a.kv;
+            for (int i = lower_bound_u16(oi, a.kv, c_lo); i < a.kv; i++) {
+                const int col = oi[i];
+                if (col >= c_hi) break;
+                const int d = col - c_lo;
+                const uint32_t word = a.vcode[row * WPR + d / CPW];
+                const float sc = ld_st<ST>(vscale + row * 2 + d / 64), mv = ld_st<ST>(vmn + row * 2 + d / 64);
+                const float deq = fmaf(sc, (float)((word >> (BITS * (d % CPW))) & ((1u << BITS) - 1u)), mv);
+                tile[dq * ET_PITCH + mt_physical(d, CPW)] = f2h_bits(h2f_bits(ov[i]) - deq);
+            }
+        }
+        __syncthreads();
+        acc = mfma_pass(&araw[0][0][0], &araw[1][0][0], acc);
+    }
+    // the last reads of s (p) are behind us after this barrier: it takes the output rows
+    __syncthreads();
+    {
+        const int ch = mt_logical(32 * wave + x31, CPW);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int m = q + 4 * kg;
+            if (m < NREP) s[m][ch] = acc[q] + (cst[m][2 * g_w] + cst[m][2 * g_w + 1]);
+        }
+    }
+    if (a.rv && half_ == 1) {                              // Pv[seg(slab 1)][dq][:] . wsl[h][1] -> ot (slab 0 adds its own below)
+        float t[8], t2[8];
+        unpack8(vp8, t);
+        if (R16) unpack8(vp8b, t2);
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            float accl = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) accl = fmaf(t[c], wsl[r][1][c], accl);
+            if (R16) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) accl = fmaf(t2[c], wsl[r][1][8 + c], accl);
+            }
+            ot[r][dq] = (64 < tn) ? accl : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (half_ == 0) {
+        float t[8], t2[8];
+        unpack8(vp8, t);
+        if (R16) unpack8(vp8b, t2);
+#pragma unroll 1
+        for (int r = 0; r < NREP; r++) {
+            float o = s[r][dq];
+            if (a.rv) {
+                float accl = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) accl = fmaf(t[c], wsl[r][0][c], accl);
+                if (R16) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) accl = fmaf(t2[c], wsl[r][0][8 + c], accl);
+                }
+                o += accl + ot[r][dq];
+            }
+            const int64_t po = (bhq0 + r) * a.pslots + split;
+            a.part_o[po * AD + dq] = o;
+            if (dq == 0) {
+                a.part_ml[po * 2] = mlh[r][0];
+                a.part_ml[po * 2 + 1] = mlh[r][1];
+            }
+        }
+    }
+}
+
 // merge the splits (+ the fp16 window, unless it came as one more chunk: a.pslots == a.splits + 1, W_arg == 0), normalise.
 // grid (B*Hq), block 512 = 4 groups x 128 channels: the groups share the splits / window rows between them so that every
 // thread's loads are one batch (the whole kernel is a latency chain).  Up to 65 partial slots (64 chunks + the window chunk).
@@ -1301,9 +1731,29 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         else if (nrep_t == 2) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 2>), gridg, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 1>), grid, dim3(256), 0, st, a);                   \
     } while (0)
+        // matrix-core variant (see attn_decode_partial_mfma): group 64, no outliers or outliers through sparse tiles
+        // Measured (profiles/r5_attn_experiments.md): 1.3 - 1.65 x faster than one workgroup per query head for grouped-query shapes
+        // once the launch has a workgroup per CU; slower for multi-head attention (one query head per KV head: the vector kernel's
+        // work is not repeated there) and for a single KV head at batch 1.  attn_mfma: 0 = by that rule, 1 = whenever it applies,
+        // -1 = never.
+        const int nrep_m = (n_rep == 2 || n_rep == 4 || n_rep == 8) ? n_rep : 1;
+        const int mfo = gear_options().attn_mfma;
+        const bool mf = small && group == 64 && mfo >= 0 && a.pslots == a.splits && (a.kk == 0 || a.ktile) && (a.kv == 0 || a.vtile) &&
+                        (mfo > 0 || (nrep_m > 1 && (int64_t)B * Hkv * a.splits >= 256));
+        const dim3 gridm(a.pslots, (unsigned)(nrep_m > 1 ? B * Hkv : B * Hq));
+#define GOM(BI, STT, RSV)                                                                                                  \
+    do {                                                                                                                   \
+        if (nrep_m == 8) hipLaunchKernelGGL((attn_decode_partial_mfma<BI, STT, RSV, 8>), gridm, dim3(256), 0, st, a);       \
+        else if (nrep_m == 4) hipLaunchKernelGGL((attn_decode_partial_mfma<BI, STT, RSV, 4>), gridm, dim3(256), 0, st, a);  \
+        else if (nrep_m == 2) hipLaunchKernelGGL((attn_decode_partial_mfma<BI, STT, RSV, 2>), gridm, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((attn_decode_partial_mfma<BI, STT, RSV, 1>), gridm, dim3(256), 0, st, a);                   \
+    } while (0)
 #define GO(BI, STT)                                                                                             \
     do {                                                                                                        \
-        if (small && r16) GOS(BI, STT, 16);                                                                     \
+        if (mf && r16) GOM(BI, STT, 16);                                                                        \
+        else if (mf && r4) GOM(BI, STT, 4);                                                                     \
+        else if (mf) GOM(BI, STT, 8);                                                                           \
+        else if (small && r16) GOS(BI, STT, 16);                                                                \
         else if (small && r4) GOS(BI, STT, 4);                                                                  \
         else if (small) GOS(BI, STT, 8);                                                                        \
         else hipLaunchKernelGGL((attn_decode_partial_kernel<BI, STT>), grid, dim3(256), 0, st, a);              \
@@ -1312,6 +1762,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         else           { if (bits == 2) GO(2, float); else GO(4, float); }
 #undef GO
 #undef GOS
+#undef GOM
         GEAR_CHECK_LAUNCH("gear_attn_decode(partial)");
     }
     hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(512), 0, st, a, (const uint16_t*)kwin,

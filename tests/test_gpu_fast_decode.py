@@ -567,3 +567,70 @@ def test_streaming_cache_matches_reference_forward_trace(golden, case, bits, low
     assert same(c.kscale[..., :n // 64], f[case + "_kscale"]) and same(c.kmn[..., :n // 64], f[case + "_kmn"])
     assert same(c.vscale[:, :, :n], f[case + "_vscale"]) and same(c.vmn[:, :, :n], f[case + "_vmn"])
     assert same(c.kwin[:, :, :c.n_win], f[case + "_kfull"]) and same(c.vwin[:, :, :c.n_win], f[case + "_vfull"])
+
+
+@pytest.mark.parametrize("method,bits,Hq,Hkv,T0,left,rank", [("gearslKIVI", 2, 8, 2, 520, 0.02, 8), ("gearslKIVI", 2, 8, 1, 300, 0.05, 16),
+                                                             ("gearlKIVI", 4, 4, 2, 200, 0.0, 4), ("KIVI", 2, 2, 2, 190, 0.02, 0),
+                                                             ("gearslKIVI", 2, 16, 2, 130, 0.02, 8), ("gearslKIVI", 4, 6, 2, 260, 0.03, 8)])
+def test_matrix_core_attention_kernel(method, bits, Hq, Hkv, T0, left, rank):
+    """Round 5: attn_decode_partial_mfma -- the chunk's codes once into an LDS tile as exact fp16 integers, scores and outputs as
+    v_mfma_f32_32x32x16_f16 with the scaled q / p rows of up to 8 query heads as ONE A operand, outlier corrections scattered into the
+    zeroed tile -- against the float64 reconstruction of the cache (2e-3, the vector kernel's tolerance) and against the vector kernel
+    (option attn_mfma = -1) on the same cache; 2 / 4 / 8 / 1 (ratio 3) query heads per KV head, ranks 0 / 4 / 8 / 16, 2 and 4 bits,
+    ragged last chunk, window, decode-time blocks."""
+    from gear_amd import _lib as L
+    from gear_amd.cache import GearKVCache
+    torch.manual_seed(73)
+    cc = dict(compress_method=method, group_size=64, residual=64, quantize_bit=bits, rank=rank, rankv=rank, loop=3, left=left)
+    B, D, steps = 2, 128, 140
+    c = GearKVCache(B, Hkv, T0 + steps + 10, cc, "cuda")
+    c.prefill(torch.randn(B, Hkv, T0, D).half().cuda(), torch.randn(B, Hkv, T0, D).half().cuda())
+    worst = worst_ab = 0.0
+    try:
+        for i in range(steps):
+            c.append(torch.randn(B, Hkv, 1, D).half().cuda(), torch.randn(B, Hkv, 1, D).half().cuda())
+            q = torch.randn(B, Hq, 1, D).half().cuda()
+            L.set_option("attn_mfma", 1)
+            out = c.attend(q)
+            if i % 11 == 0 or c.n_win in (1, 64):
+                L.set_option("attn_mfma", -1)
+                out_v = c.attend(q)
+                worst_ab = max(worst_ab, rel_fro(host(out).astype(np.float64), host(out_v).astype(np.float64)))
+                K, V = _reconstruct_cache(c)
+                ref = _ref_attn(host(q), K, V, host(c.kwin[:, :, :c.n_win]), host(c.vwin[:, :, :c.n_win]), Hq // Hkv)
+                worst = max(worst, rel_fro(host(out).astype(np.float64), ref))
+            c.maybe_compress()
+    finally:
+        L.set_option("attn_mfma", 0)
+    assert worst < 2e-3, worst
+    assert worst_ab < 1e-3, worst_ab
+
+
+def test_matrix_core_attention_with_overflowed_tiles():
+    """A chunk / block whose sparse tile overflowed (count -1) sends the matrix-core kernel to the sorted lists: K outliers of every
+    channel crowded into the first 128 tokens, V outliers of every row crowded into one head."""
+    from gear_amd import _lib as L
+    from gear_amd.cache import GearKVCache
+    torch.manual_seed(74)
+    cc = dict(compress_method="gearslKIVI", group_size=64, residual=64, quantize_bit=2, rank=8, rankv=8, loop=3, left=0.04)
+    B, Hq, Hkv, T0, D = 1, 8, 4, 512, 128
+    k = torch.randn(B, Hkv, T0, D)
+    v = torch.randn(B, Hkv, T0, D)
+    k[:, :, :100] *= 12.0                          # every channel's top / bottom-k tokens lie in chunk 0
+    v[:, 1] *= 12.0                                # every row's outliers lie in head 1
+    c = GearKVCache(B, Hkv, T0 + 128, cc, "cuda")
+    c.prefill(k.half().cuda(), v.half().cuda())
+    assert int((c.kcnt[:, :, :4] < 0).sum()) > 0 and int((c.vcnt[:, 1, :8] < 0).sum()) > 0      # the case under test
+    c.append(torch.randn(B, Hkv, 1, D).half().cuda(), torch.randn(B, Hkv, 1, D).half().cuda())
+    q = torch.randn(B, Hq, 1, D).half().cuda()
+    try:
+        L.set_option("attn_mfma", 1)
+        out = c.attend(q)
+        L.set_option("attn_mfma", -1)
+        out_v = c.attend(q)
+    finally:
+        L.set_option("attn_mfma", 0)
+    K, V = _reconstruct_cache(c)
+    ref = _ref_attn(host(q), K, V, host(c.kwin[:, :, :c.n_win]), host(c.vwin[:, :, :c.n_win]), Hq // Hkv)
+    assert rel_fro(host(out).astype(np.float64), ref) < 2e-3
+    assert rel_fro(host(out).astype(np.float64), host(out_v).astype(np.float64)) < 1e-3

@@ -34,9 +34,7 @@ def case(B, Hq, Hkv, T, rank, s, label, bits=2):
     c.prefill(k, v)
     q = torch.randn((B, Hq, 1, 128), device=dev, dtype=torch.float16)
     res = {}
-    for name, opts in (("default", {}), ("keep_chunk_index", {"attn_keep_chunk_index": 1}), ("gqa_group", {"attn_gqa_group": 1})):
-        if name == "gqa_group" and Hq == Hkv:
-            continue
+    for name, opts in (("default", {}), ("mfma", {"attn_mfma": 1}), ("vector", {"attn_mfma": -1})):
         for o, val in opts.items():
             L.set_option(o, val)
         res[name] = timed(lambda: c.attend(q))
