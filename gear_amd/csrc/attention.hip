@@ -1040,6 +1040,31 @@ __device__ __forceinline__ void mt_store_codes(uint16_t* dst, uint32_t w) {
     for (int v4 = 0; v4 < CPW / 8; v4++) ((uint4*)dst)[v4] = make_uint4(z[4 * v4], z[4 * v4 + 1], z[4 * v4 + 2], z[4 * v4 + 3]);
 }
 
+// MFMA operand of lane (x31, kg) from a tile of row pitch PITCH halfs: rows t0 + 8 kg .. + 7 of column 32 I + x31, through the
+// transposing LDS read (ktile.h's load_operand with the pitch as a parameter)
+template <int PITCH>
+__device__ __forceinline__ half8_t mt_operand(const uint16_t* tile, int t0, int I, int lane) {
+    const int kg = lane >> 5, i = lane & 15, c0 = 32 * I + 16 * ((lane >> 4) & 1);
+    const uint16_t* p = tile + (t0 + 8 * kg + (i >> 2)) * PITCH + c0 + 4 * (i & 3);
+    const uint32_t addr = (uint32_t)(uintptr_t)p;
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    short4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * PITCH * 2) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    union { half8_t h; short4v s[2]; } cv;
+    cv.s[0] = lo;
+    cv.s[1] = hi;
+    return cv.h;
+}
+
+// Layout of a workgroup's life (3 workgroup barriers; +3 per side when the chunk has outliers):
+//   loads (all up front) | K tile: codes [channel][token] + pad columns = Pk of the chunk's two factor segments; A rows q sc (head +
+//   remainder) per token group; constant term  ||  every wave, for ITS 32 token columns: scores = MFMA(q sc, codes) + const, u =
+//   MFMA(q, pad) -> Qk[t] . u added in registers, outlier pass  ||  32 lanes per query head: softmax statistics, p and the A rows
+//   p sc for the V side, its constant term -- while all threads put the V codes [token][channel] + pad = Qv into the tile  ||  every
+//   wave, for ITS 32 channel columns: out = MFMA(p sc, codes) + const, w = MFMA(p, pad) per 64-token slab -> Pv[c] . w added in
+//   registers, outlier pass, partial output stored by the lane that owns it.
 template <int BITS, typename ST, int RS, int NREP>
 __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     constexpr bool R16 = RS == 16;
@@ -1048,14 +1073,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     constexpr int WPR = SC / CPW;            // words per 128-element row (8 | 16)
     constexpr int RSUB = 256 / WPR;          // rows covered per pass (32 | 16)
     constexpr int WPT = AD / RSUB;           // words per thread and side (4 | 8)
-    __shared__ __attribute__((aligned(16))) uint16_t tile[SC * ET_PITCH];    // [row = contraction index][column]
+    constexpr int MP = AD + 2 * RW;          // tile row pitch in halfs (144 | 160): 128 code columns + 2 RW factor columns
+    __shared__ __attribute__((aligned(16))) uint16_t tile[SC * MP + 32];     // [row = contraction index][column]
     __shared__ __attribute__((aligned(16))) uint16_t aop[2][2][NREP][AD];   // A operands: [group][head / remainder][query head][k]
-    __shared__ __attribute__((aligned(16))) uint16_t araw[2][NREP][AD];     // q exact (K deltas); p head / remainder (V deltas)
-    __shared__ __attribute__((aligned(16))) float s[NREP][SC];              // scores, then p, then the output rows
-    __shared__ float up[NREP][4][RW];
-    __shared__ float wsl[NREP][2][RW];
+    __shared__ __attribute__((aligned(16))) uint16_t araw[2][NREP][AD];     // q exact; then p head / remainder
+    __shared__ __attribute__((aligned(16))) float s[NREP][SC];              // scores
+    __shared__ float vsm[2][2][SC];                                         // V [scale, zero point][channel group][token]
+    __shared__ __attribute__((aligned(16))) float ubuf[4][NREP][2 * RW];    // per wave: Pk^T q of the two segments, then Qv^T p of the two slabs
     __shared__ float cst[NREP][4];
-    __shared__ float ot[NREP][AD];
     __shared__ float mlh[NREP][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1091,9 +1116,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
 
     // ------------------------------------------------------------------ every load of the chunk (all unconditional)
     const int dq = tid & (AD - 1), half_ = tid >> 7;   // (channel | token, group | slab | side)
+    const int x31 = lane & 31, kg = lane >> 5;
+    const int g_w = wave >> 1;                          // the 64-element group the wave's 32 tile columns lie in
+    const int el_l = mt_logical(32 * wave + x31, CPW);  // the token (K side) / channel (V side) of this lane's tile column
     auto seg_at = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
     const int seg_s0 = seg_at(t0), seg_s1 = seg_at(min(t0 + 64, t0 + tn - 1));
-    float qf[NREP];                                    // q[h][dq] * qscale
     uint16_t qb[NREP];
 #pragma unroll
     for (int r = 0; r < NREP; r++) qb[r] = a.q[(bhq0 + r) * AD + dq];
@@ -1115,18 +1142,21 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     const int64_t vrow = (bhk * a.tcap_v + t0 + min(dq, tn - 1)) * 2 + half_;
     float vsc1 = ld_st<ST>(vscale + vrow), vmn1 = ld_st<ST>(vmn + vrow);
     const uint4* dummy16 = (const uint4*)(a.q + bhq0 * AD);
-    const uint32_t trow = (uint32_t)min(dq, tn - 1);
     const int64_t fseg = half_ ? (int64_t)seg_s1 : (int64_t)seg_s0;
-    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
-    const uint4* kqp = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RS + trow * RS) : dummy16;
-    const uint4* vpp = a.rv ? (const uint4*)(a.vP + fseg * a.vP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
-    const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RS + trow * RS) : dummy16;
     auto ldrow = [](const uint4* p) {
         if (RS == 4) { const uint2 t = *(const uint2*)p; return make_uint4(t.x, t.y, 0u, 0u); }
         return p[0];
     };
-    const uint4 kp8 = ldrow(kpp), kq8 = ldrow(kqp), vp8 = ldrow(vpp), vq8 = ldrow(vqp);
-    const uint4 kp8b = R16 ? kpp[1] : kp8, kq8b = R16 ? kqp[1] : kq8, vp8b = R16 ? vpp[1] : vp8, vq8b = R16 ? vqp[1] : vq8;
+    // factor rows for the tile's pad columns: Pk[segment of slab half_][channel dq] and Qv[token dq]; and the rows this LANE
+    // multiplies in registers: Qk[its token], Pv[both segments][its channel]
+    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RS + (uint32_t)min(dq, tn - 1) * RS) : dummy16;
+    const uint4* kql = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RS + (uint32_t)min(el_l, tn - 1) * RS) : dummy16;
+    const uint4* vpl0 = a.rv ? (const uint4*)(a.vP + (int64_t)seg_s0 * a.vP_seg_stride + bhk * AD * RS + (uint32_t)el_l * RS) : dummy16;
+    const uint4* vpl1 = a.rv ? (const uint4*)(a.vP + (int64_t)seg_s1 * a.vP_seg_stride + bhk * AD * RS + (uint32_t)el_l * RS) : dummy16;
+    const uint4 kp8 = ldrow(kpp), vq8 = ldrow(vqp), kq8 = ldrow(kql), vp08 = ldrow(vpl0), vp18 = ldrow(vpl1);
+    const uint4 kp8b = R16 ? kpp[1] : kp8, vq8b = R16 ? vqp[1] : vq8, kq8b = R16 ? kql[1] : kq8, vp08b = R16 ? vpl0[1] : vp08,
+                vp18b = R16 ? vpl1[1] : vp18;
     const bool has_ktile = a.ktile && a.kk > 0, has_vtile = a.vtile && a.kv > 0;
     const int64_t vb = bhk * a.nblk + 2 * split;
     const int* kcp = has_ktile ? a.kcnt + bhk * a.nck + split : (const int*)dummy16;
@@ -1138,23 +1168,21 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     if (!tok_ok) { vsc1 = 0.0f; vmn1 = 0.0f; }
 
     typedef union { uint4 u; half8_t h; } U8;
-    const int x31 = lane & 31, kg = lane >> 5;
-    const int g_w = wave >> 1;                          // the 64-element group the wave's 32 tile columns lie in
-    // zero the tile / scatter corrections into it / one pass of MFMAs with the rows araw[part][m][:] (part 0, or 0 and 1)
     auto zero_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < (SC * ET_PITCH * 2) / (256 * 16); i++) ((uint4*)tile)[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < (SC * MP * 2) / 16; i += 256) ((uint4*)tile)[i] = make_uint4(0u, 0u, 0u, 0u);
     };
-    auto mfma_pass = [&](const uint16_t* A0, const uint16_t* A1, float16_t acc) {     // A rows: [NREP][AD] halfs; A1 may be null
+    // one MFMA pass over the contraction steps [ks0, ks1) of tile column block I with the rows A0 (+ A1) [NREP][AD]
+    auto mfma_pass = [&](const uint16_t* A0, const uint16_t* A1, int I, int ks0, int ks1, float16_t acc) {
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
+            if (ks < ks0 || ks >= ks1) continue;
             U8 ah, al;
             ah.u = al.u = make_uint4(0u, 0u, 0u, 0u);
             if (x31 < NREP) {
                 ah.u = *(const uint4*)(A0 + x31 * AD + 16 * ks + 8 * kg);
                 if (A1) al.u = *(const uint4*)(A1 + x31 * AD + 16 * ks + 8 * kg);
             }
-            const half8_t bo = load_operand<true>(tile, 16 * ks, wave, lane);
+            const half8_t bo = mt_operand<MP>(tile, 16 * ks, I, lane);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bo, acc, 0, 0, 0);
             if (A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bo, acc, 0, 0, 0);
         }
@@ -1164,53 +1192,53 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         hi = f2h_bits(x);
         lo = f2h_bits(x - h2f_bits(hi));
     };
-
-    // ------------------------------------------------------------------ 1. K: code tile, scaled q rows, constant term, Pk^T q
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    float16_t zero16;
 #pragma unroll
-    for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * ET_PITCH + CPW * wl, kw[i]);
+    for (int q = 0; q < 16; q++) zero16[q] = 0.0f;
+
+    // ------------------------------------------------------------------ 1. K tile, A rows, constant term
+#pragma unroll
+    for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * MP + CPW * wl, kw[i]);
+    if (a.rk) {
+        *(uint4*)(tile + dq * MP + AD + RW * half_) = kp8;
+        if (R16) *(uint4*)(tile + dq * MP + AD + RW * half_ + 8) = kp8b;
+    }
     {
         float cp[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) cp[r] = 0.0f;
 #pragma unroll
         for (int r = 0; r < NREP; r++) {
-            qf[r] = h2f_bits(qb[r]) * a.qscale;
+            const float qf = h2f_bits(qb[r]) * a.qscale;
             uint16_t hi, lo;
-            split16(qf[r] * ksc1, hi, lo);
+            split16(qf * ksc1, hi, lo);
             aop[half_][0][r][dq] = hi;
             aop[half_][1][r][dq] = lo;
             if (half_ == 0) araw[0][r][dq] = qb[r];
-            cp[r] = qf[r] * kmn1;
+            cp[r] = qf * kmn1;
         }
         const float cr = reduce8_over_wave(cp, lane);       // over the wave's 64 channels; lanes 0, 8, .. hold head lane / 8
         if ((lane & 7) == 0 && (lane >> 3) < NREP) cst[lane >> 3][wave] = cr;
     }
-    if (a.rk) {
-#pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            float qv = qf[0];
-#pragma unroll
-            for (int rr = 1; rr < NREP; rr++) qv = (r == rr) ? qf[rr] : qv;
-            float pr[8];
-            unpack8(kp8, pr);
-#pragma unroll
-            for (int c = 0; c < 8; c++) pr[c] *= qv;
-            const float r1 = reduce8_over_wave(pr, lane);
-            if ((lane & 7) == 0) up[r][wave][lane >> 3] = r1;
-            if (R16) {
-                unpack8(kp8b, pr);
-#pragma unroll
-                for (int c = 0; c < 8; c++) pr[c] *= qv;
-                const float r2 = reduce8_over_wave(pr, lane);
-                if ((lane & 7) == 0) up[r][wave][8 + (lane >> 3)] = r2;
-            }
-        }
-    }
+    vsm[0][half_][dq] = vsc1;
+    vsm[1][half_][dq] = vmn1;
     __syncthreads();
-    float16_t acc;
+    // ------------------------------------------------------------------ 2. scores of this wave's 32 token columns
+    float16_t acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], wave, 0, 8, zero16);
+    if (a.rk) {   // u[m][r] of both segments: q (exact) against the pad columns; through the wave's LDS slot to the lanes that need it
+        const float16_t au = mfma_pass(&araw[0][0][0], nullptr, 4, 0, 8, zero16);
+        if (x31 < 2 * RW) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.0f;
-    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], acc);
+            for (int q = 0; q < 4; q++)
+                if (q + 4 * kg < NREP) ubuf[wave][q + 4 * kg][x31] = au[q] * a.qscale;
+        }
+        wave_sync();
+    }
     if (kc_n != 0) {                                       // K outliers: stored corrections through the zeroed tile
         __syncthreads();
         zero_tile();
@@ -1219,7 +1247,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
             const uint32_t* kt = a.ktile + (bhk * a.nck + split) * (int64_t)a.ktile_cap;
             for (int e = tid; e < kc_n; e += 256) {
                 const uint32_t ke = e == tid ? ke0 : (e == tid + 256 ? ke1 : kt[e]);
-                tile[(ke & 127u) * ET_PITCH + mt_physical((int)((ke >> 7) & 127u), CPW)] = (uint16_t)(ke >> 16);
+                tile[(ke & 127u) * MP + mt_physical((int)((ke >> 7) & 127u), CPW)] = (uint16_t)(ke >> 16);
             }
         } else {   // the chunk's tile overflowed (count -1): the sorted lists, one per (channel dq, side half_)
             const int64_t chn = bhk * AD + dq;
@@ -1235,44 +1263,38 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
                     const uint32_t word = a.kcode[chn * (int64_t)a.ldk + t / CPW];
                     const float sc = ld_st<ST>(kscale + chn * (int64_t)a.lsk + t / a.group), mv = ld_st<ST>(kmn + chn * (int64_t)a.lsk + t / a.group);
                     const float deq = fmaf(sc, (float)((word >> (BITS * (t % CPW))) & ((1u << BITS) - 1u)), mv);
-                    tile[dq * ET_PITCH + mt_physical(t - t0, CPW)] = f2h_bits(h2f_bits(ov[i]) - deq);
+                    tile[dq * MP + mt_physical(t - t0, CPW)] = f2h_bits(h2f_bits(ov[i]) - deq);
                 }
         }
         __syncthreads();
-        float16_t ad;
-#pragma unroll
-        for (int q = 0; q < 16; q++) ad[q] = 0.0f;
-        ad = mfma_pass(&araw[0][0][0], nullptr, ad);
+        const float16_t ad = mfma_pass(&araw[0][0][0], nullptr, wave, 0, 8, zero16);
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[q] = fmaf(a.qscale, ad[q], acc[q]);
     }
-    {   // scores of (head q + 4 kg, tile column 32 wave + x31) + the constant term of the column's group
-        const int tok = mt_logical(32 * wave + x31, CPW);
+    {   // finish the scores of (head q + 4 kg, token el_l) in registers: + constant term + Qk[token] . u[head][segment of the token]
+        float tq[RW];
+        if (a.rk) {
+            unpack8(kq8, tq);
+            if (R16) unpack8(kq8b, tq + 8);
+        }
+        const int uo = (el_l >> 6) * RW;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int m = q + 4 * kg;
-            if (m < NREP) s[m][tok] = acc[q] + (cst[m][2 * g_w] + cst[m][2 * g_w + 1]);
+            if (m < NREP) {
+                float v = acc[q] + (cst[m][2 * g_w] + cst[m][2 * g_w + 1]);
+                if (a.rk) {
+                    float accl = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < RW; c++) accl = fmaf(tq[c], ubuf[wave][m][uo + c], accl);
+                    v += accl;
+                }
+                s[m][el_l] = v;
+            }
         }
     }
     __syncthreads();
-    if (a.rk && tid < SC) {                                // + Qk[t] . (Pk[seg(slab)]^T q) per head; token tid, slab = wave
-        float tq[8], tq2[8];
-        unpack8(kq8, tq);
-        if (R16) unpack8(kq8b, tq2);
-#pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            float accl = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; c++) accl = fmaf(tq[c], up[r][2 * wave][c] + up[r][2 * wave + 1][c], accl);
-            if (R16) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) accl = fmaf(tq2[c], up[r][2 * wave][8 + c] + up[r][2 * wave + 1][8 + c], accl);
-            }
-            s[r][tid] += accl;
-        }
-    }
-    if (a.rk) __syncthreads();
-    // ------------------------------------------------------------------ 2. softmax statistics: 32 lanes per query head
+    // ------------------------------------------------------------------ 3. softmax statistics (32 lanes per query head) and V tile
     {
         const int h = tid >> 5, j = tid & 31;
         if (h < NREP) {
@@ -1285,66 +1307,53 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
             }
 #pragma unroll
             for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-            float sum = 0.0f;
+            float sum = 0.0f, c0 = 0.0f, c1 = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int t = j + 32 * i;
                 const float pv = t < tn ? __expf(v[i] - mx) : 0.0f;
                 sum += pv;
-                s[h][t] = pv;
                 uint16_t hi, lo;
                 split16(pv, hi, lo);
                 araw[0][h][t] = hi;
                 araw[1][h][t] = lo;
+                split16(pv * vsm[0][0][t], hi, lo);
+                aop[0][0][h][t] = hi;
+                aop[0][1][h][t] = lo;
+                split16(pv * vsm[0][1][t], hi, lo);
+                aop[1][0][h][t] = hi;
+                aop[1][1][h][t] = lo;
+                c0 = fmaf(pv, vsm[1][0][t], c0);
+                c1 = fmaf(pv, vsm[1][1][t], c1);
             }
 #pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-            if (j == 0) { mlh[h][0] = mx; mlh[h][1] = sum; }
-        }
-    }
-    __syncthreads();
-    // ------------------------------------------------------------------ 3. V: code tile, scaled p rows, constant term, Qv^T p
-#pragma unroll
-    for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * ET_PITCH + CPW * wl, vw[i]);
-    {
-        float cp[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) cp[r] = 0.0f;
-#pragma unroll
-        for (int r = 0; r < NREP; r++) {
-            const float pv = s[r][dq];                      // (token dq; 0 beyond the chunk)
-            uint16_t hi, lo;
-            split16(pv * vsc1, hi, lo);
-            aop[half_][0][r][dq] = hi;
-            aop[half_][1][r][dq] = lo;
-            cp[r] = pv * vmn1;
-        }
-        const float cr = reduce8_over_wave(cp, lane);       // over the wave's 64 tokens
-        if ((lane & 7) == 0 && (lane >> 3) < NREP) cst[lane >> 3][wave] = cr;
-    }
-    if (a.rv && tid < SC) {                                // wsl[h][slab][:] = sum over the slab's tokens of p[h][t] Qv[t][:]; slab = wave
-#pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            const float pv = s[r][tid];
-            float wv[8];
-            unpack8(vq8, wv);
-#pragma unroll
-            for (int c = 0; c < 8; c++) wv[c] *= pv;
-            const float r1 = reduce8_over_wave(wv, lane);
-            if ((lane & 7) == 0) wsl[r][wave][lane >> 3] = r1;
-            if (R16) {
-                unpack8(vq8b, wv);
-#pragma unroll
-                for (int c = 0; c < 8; c++) wv[c] *= pv;
-                const float r2 = reduce8_over_wave(wv, lane);
-                if ((lane & 7) == 0) wsl[r][wave][8 + (lane >> 3)] = r2;
+            for (int d = 16; d >= 1; d >>= 1) {
+                sum += __shfl_xor(sum, d, 64);
+                c0 += __shfl_xor(c0, d, 64);
+                c1 += __shfl_xor(c1, d, 64);
             }
+            if (j == 0) { mlh[h][0] = mx; mlh[h][1] = sum; cst[h][0] = c0; cst[h][1] = c1; }
         }
     }
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.0f;
-    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], acc);
+    for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * MP + CPW * wl, vw[i]);
+    if (a.rv && half_ == 0) {
+        *(uint4*)(tile + dq * MP + AD) = vq8;
+        if (R16) *(uint4*)(tile + dq * MP + AD + 8) = vq8b;
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ 4. outputs of this wave's 32 channel columns
+    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], wave, 0, 8, zero16);
+    if (a.rv) {   // w[m][r] = sum over a slab's tokens of p[m][t] Qv[t][r], slab by slab (contraction steps 0-3 / 4-7)
+        const float16_t w0 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 4, 0, 4, zero16);
+        const float16_t w1 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 4, 4, 8, zero16);
+        if (x31 < RW) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q + 4 * kg < NREP) { ubuf[wave][q + 4 * kg][x31] = w0[q]; ubuf[wave][q + 4 * kg][RW + x31] = w1[q]; }
+        }
+        wave_sync();
+    }
     if (vc_n0 != 0 || vc_n1 != 0) {                        // V outliers of the chunk's two 64-token blocks
         __syncthreads();
         zero_tile();
@@ -1354,7 +1363,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
             const uint32_t* vt = a.vtile + (vb + hb) * (int64_t)a.vtile_cap;
             for (int e = tid; e < n; e += 256) {
                 const uint32_t ve = e == tid ? (hb ? ve1 : ve0) : vt[e];
-                tile[(64 * hb + (int)(ve & 63u)) * ET_PITCH + mt_physical((int)((ve >> 6) & 127u), CPW)] = (uint16_t)(ve >> 16);
+                tile[(64 * hb + (int)(ve & 63u)) * MP + mt_physical((int)((ve >> 6) & 127u), CPW)] = (uint16_t)(ve >> 16);
             }
         }
         if (((dq < 64) ? vc_n0 : vc_n1) < 0 && tok_ok) {   // this token's block overflowed its tile: the row's sorted list, side half_
@@ -1369,63 +1378,38 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
                 const uint32_t word = a.vcode[row * WPR + d / CPW];
                 const float sc = ld_st<ST>(vscale + row * 2 + d / 64), mv = ld_st<ST>(vmn + row * 2 + d / 64);
                 const float deq = fmaf(sc, (float)((word >> (BITS * (d % CPW))) & ((1u << BITS) - 1u)), mv);
-                tile[dq * ET_PITCH + mt_physical(d, CPW)] = f2h_bits(h2f_bits(ov[i]) - deq);
+                tile[dq * MP + mt_physical(d, CPW)] = f2h_bits(h2f_bits(ov[i]) - deq);
             }
         }
         __syncthreads();
-        acc = mfma_pass(&araw[0][0][0], &araw[1][0][0], acc);
+        acc = mfma_pass(&araw[0][0][0], &araw[1][0][0], wave, 0, 8, acc);
     }
-    // the last reads of s (p) are behind us after this barrier: it takes the output rows
-    __syncthreads();
-    {
-        const int ch = mt_logical(32 * wave + x31, CPW);
+    {   // partial output of (head q + 4 kg, channel el_l): + constant term + Pv[segment][channel] . w[head][slab], stored by its owner
+        float t0v[RW], t1v[RW];
+        if (a.rv) {
+            unpack8(vp08, t0v);
+            unpack8(vp18, t1v);
+            if (R16) { unpack8(vp08b, t0v + 8); unpack8(vp18b, t1v + 8); }
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int m = q + 4 * kg;
-            if (m < NREP) s[m][ch] = acc[q] + (cst[m][2 * g_w] + cst[m][2 * g_w + 1]);
-        }
-    }
-    if (a.rv && half_ == 1) {                              // Pv[seg(slab 1)][dq][:] . wsl[h][1] -> ot (slab 0 adds its own below)
-        float t[8], t2[8];
-        unpack8(vp8, t);
-        if (R16) unpack8(vp8b, t2);
-#pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            float accl = 0.0f;
+            if (m < NREP) {
+                float o = acc[q] + cst[m][g_w];
+                if (a.rv) {
+                    float accl = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 8; c++) accl = fmaf(t[c], wsl[r][1][c], accl);
-            if (R16) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) accl = fmaf(t2[c], wsl[r][1][8 + c], accl);
-            }
-            ot[r][dq] = (64 < tn) ? accl : 0.0f;
-        }
-    }
-    __syncthreads();
-    if (half_ == 0) {
-        float t[8], t2[8];
-        unpack8(vp8, t);
-        if (R16) unpack8(vp8b, t2);
-#pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            float o = s[r][dq];
-            if (a.rv) {
-                float accl = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 8; c++) accl = fmaf(t[c], wsl[r][0][c], accl);
-                if (R16) {
-#pragma unroll
-                    for (int c = 0; c < 8; c++) accl = fmaf(t2[c], wsl[r][0][8 + c], accl);
+                    for (int c = 0; c < RW; c++) accl = fmaf(t0v[c], ubuf[wave][m][c], fmaf(t1v[c], ubuf[wave][m][RW + c], accl));
+                    o += accl;
                 }
-                o += accl + ot[r][dq];
-            }
-            const int64_t po = (bhq0 + r) * a.pslots + split;
-            a.part_o[po * AD + dq] = o;
-            if (dq == 0) {
-                a.part_ml[po * 2] = mlh[r][0];
-                a.part_ml[po * 2 + 1] = mlh[r][1];
+                a.part_o[((bhq0 + m) * a.pslots + split) * AD + el_l] = o;
             }
         }
+    }
+    if (tid < NREP) {
+        const int64_t po = (bhq0 + tid) * a.pslots + split;
+        a.part_ml[po * 2] = mlh[tid][0];
+        a.part_ml[po * 2 + 1] = mlh[tid][1];
     }
 }
 
