@@ -1040,22 +1040,34 @@ __device__ __forceinline__ void mt_store_codes(uint16_t* dst, uint32_t w) {
     for (int v4 = 0; v4 < CPW / 8; v4++) ((uint4*)dst)[v4] = make_uint4(z[4 * v4], z[4 * v4 + 1], z[4 * v4 + 2], z[4 * v4 + 3]);
 }
 
-// MFMA operand of lane (x31, kg) from a tile of row pitch PITCH halfs: rows t0 + 8 kg .. + 7 of column 32 I + x31, through the
-// transposing LDS read (ktile.h's load_operand with the pitch as a parameter)
+// MFMA B operands of lane (x31, kg) from a tile of row pitch PITCH halfs, ALL eight contraction steps of column block I at once:
+// bo[2 ks], bo[2 ks + 1] = rows 16 ks + 8 kg .. + 7 of column 32 I + x31, through the transposing LDS read (ktile.h's load_operand
+// with the pitch as a parameter).  Sixteen reads are issued, then ONE wait -- per step (read, wait, MFMA) a pass of 8 steps was eight
+// LDS round trips long, and a workgroup makes five to seven passes.  The wait statement names every result register as an in / out
+// operand: inline asm results count as available to the compiler the moment the statement ends, and nothing else would keep an
+// MFMA from being scheduled in front of the wait.
+typedef short mt_short4 __attribute__((ext_vector_type(4)));
 template <int PITCH>
-__device__ __forceinline__ half8_t mt_operand(const uint16_t* tile, int t0, int I, int lane) {
+__device__ __forceinline__ void mt_operands(const uint16_t* tile, int I, int lane, mt_short4 (&bo)[16]) {
     const int kg = lane >> 5, i = lane & 15, c0 = 32 * I + 16 * ((lane >> 4) & 1);
-    const uint16_t* p = tile + (t0 + 8 * kg + (i >> 2)) * PITCH + c0 + 4 * (i & 3);
+    const uint16_t* p = tile + (8 * kg + (i >> 2)) * PITCH + c0 + 4 * (i & 3);
     const uint32_t addr = (uint32_t)(uintptr_t)p;
-    typedef short short4v __attribute__((ext_vector_type(4)));
-    short4v lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * PITCH * 2) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    union { half8_t h; short4v s[2]; } cv;
-    cv.s[0] = lo;
-    cv.s[1] = hi;
-    return cv.h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+        if (ks < 4) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bo[2 * ks]) : "v"(addr), "n"((16 * (ks & 3)) * PITCH * 2) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bo[2 * ks + 1]) : "v"(addr), "n"((16 * (ks & 3) + 4) * PITCH * 2) : "memory");
+        } else {   // (the 16-bit offset field ends at 65535 bytes: the second half of the rows from a second base)
+            const uint32_t addr2 = addr + 64 * PITCH * 2;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bo[2 * ks]) : "v"(addr2), "n"((16 * (ks & 3)) * PITCH * 2) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bo[2 * ks + 1]) : "v"(addr2), "n"((16 * (ks & 3) + 4) * PITCH * 2) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(bo[0]), "+v"(bo[1]), "+v"(bo[2]), "+v"(bo[3]), "+v"(bo[4]), "+v"(bo[5]), "+v"(bo[6]), "+v"(bo[7]), "+v"(bo[8]),
+                   "+v"(bo[9]), "+v"(bo[10]), "+v"(bo[11]), "+v"(bo[12]), "+v"(bo[13]), "+v"(bo[14]), "+v"(bo[15])
+                 :
+                 : "memory");
 }
 
 // Layout of a workgroup's life (3 workgroup barriers; +3 per side when the chunk has outliers):
@@ -1172,7 +1184,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         for (int i = tid; i < (SC * MP * 2) / 16; i += 256) ((uint4*)tile)[i] = make_uint4(0u, 0u, 0u, 0u);
     };
     // one MFMA pass over the contraction steps [ks0, ks1) of tile column block I with the rows A0 (+ A1) [NREP][AD]
-    auto mfma_pass = [&](const uint16_t* A0, const uint16_t* A1, int I, int ks0, int ks1, float16_t acc) {
+    mt_short4 bo[16];                                   // the B operands of the current column block (mt_operands)
+    auto mfma_pass = [&](const uint16_t* A0, const uint16_t* A1, int ks0, int ks1, float16_t acc) {
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             if (ks < ks0 || ks >= ks1) continue;
@@ -1182,9 +1195,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
                 ah.u = *(const uint4*)(A0 + x31 * AD + 16 * ks + 8 * kg);
                 if (A1) al.u = *(const uint4*)(A1 + x31 * AD + 16 * ks + 8 * kg);
             }
-            const half8_t bo = mt_operand<MP>(tile, 16 * ks, I, lane);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bo, acc, 0, 0, 0);
-            if (A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bo, acc, 0, 0, 0);
+            union { half8_t h; mt_short4 s[2]; } cv;
+            cv.s[0] = bo[2 * ks];
+            cv.s[1] = bo[2 * ks + 1];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, cv.h, acc, 0, 0, 0);
+            if (A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, cv.h, acc, 0, 0, 0);
         }
         return acc;
     };
@@ -1229,9 +1244,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     vsm[1][half_][dq] = vmn1;
     __syncthreads();
     // ------------------------------------------------------------------ 2. scores of this wave's 32 token columns
-    float16_t acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], wave, 0, 8, zero16);
+    mt_operands<MP>(tile, wave, lane, bo);
+    float16_t acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], 0, 8, zero16);
     if (a.rk) {   // u[m][r] of both segments: q (exact) against the pad columns; through the wave's LDS slot to the lanes that need it
-        const float16_t au = mfma_pass(&araw[0][0][0], nullptr, 4, 0, 8, zero16);
+        mt_operands<MP>(tile, 4, lane, bo);
+        const float16_t au = mfma_pass(&araw[0][0][0], nullptr, 0, 8, zero16);
         if (x31 < 2 * RW) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -1267,7 +1284,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
                 }
         }
         __syncthreads();
-        const float16_t ad = mfma_pass(&araw[0][0][0], nullptr, wave, 0, 8, zero16);
+        mt_operands<MP>(tile, wave, lane, bo);
+        const float16_t ad = mfma_pass(&araw[0][0][0], nullptr, 0, 8, zero16);
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[q] = fmaf(a.qscale, ad[q], acc[q]);
     }
@@ -1343,10 +1361,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     }
     __syncthreads();
     // ------------------------------------------------------------------ 4. outputs of this wave's 32 channel columns
-    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], wave, 0, 8, zero16);
+    mt_operands<MP>(tile, wave, lane, bo);
+    acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], 0, 8, zero16);
     if (a.rv) {   // w[m][r] = sum over a slab's tokens of p[m][t] Qv[t][r], slab by slab (contraction steps 0-3 / 4-7)
-        const float16_t w0 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 4, 0, 4, zero16);
-        const float16_t w1 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 4, 4, 8, zero16);
+        mt_operands<MP>(tile, 4, lane, bo);
+        const float16_t w0 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 0, 4, zero16);
+        const float16_t w1 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 4, 8, zero16);
         if (x31 < RW) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -1382,7 +1402,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
             }
         }
         __syncthreads();
-        acc = mfma_pass(&araw[0][0][0], &araw[1][0][0], wave, 0, 8, acc);
+        mt_operands<MP>(tile, wave, lane, bo);
+        acc = mfma_pass(&araw[0][0][0], &araw[1][0][0], 0, 8, acc);
     }
     {   // partial output of (head q + 4 kg, channel el_l): + constant term + Pv[segment][channel] . w[head][slab], stored by its owner
         float t0v[RW], t1v[RW];
