@@ -737,7 +737,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     const int* vcp = has_vtile ? a.vcnt + vb : (const int*)dummy16;
     const uint32_t* vtp = has_vtile ? a.vtile + vb * a.vtile_cap + tid : (const uint32_t*)dummy16;
     const int kc_raw = kcp[0], vc_raw0 = vcp[0], vc_raw1 = vcp[1];
-    const uint32_t ke0 = ktp[0], ke1 = ktp[has_ktile ? 256 : 0], ve0 = vtp[0], ve1 = vtp[has_vtile ? a.vtile_cap : 0];
+    // (the second entries at offsets the compiler cannot compare with the first's: `ktp[has_ktile ? 256 : 0]` became "copy ke0 unless
+    // has_ktile" -- a copy of a value just requested, i.e. s_waitcnt vmcnt(0) in the middle of the requests; found in the ISA)
+    uint32_t koff1 = has_ktile ? 256u : 0u, voff1 = has_vtile ? (uint32_t)a.vtile_cap : 0u;
+    asm volatile("" : "+v"(koff1), "+v"(voff1));
+    const uint32_t ke0 = ktp[0], ke1 = ktp[koff1], ve0 = vtp[0], ve1 = vtp[voff1];
 
     // everything below runs once per query head of the group on the registers loaded above (a rolled loop: the code stays at
     // its one-head size, which is what a cold instruction cache charges for)
@@ -1091,7 +1095,9 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t araw[2][NREP][AD];     // q exact; then p head / remainder
     __shared__ __attribute__((aligned(16))) float s[NREP][SC];              // scores
     __shared__ float vsm[2][2][SC];                                         // V [scale, zero point][channel group][token]
-    __shared__ __attribute__((aligned(16))) float ubuf[4][NREP][2 * RW];    // per wave: Pk^T q of the two segments, then Qv^T p of the two slabs
+    // Pk^T q of the two segments, then Qv^T p of the two slabs.  Every wave computes ALL of it (the pad column block is one more
+    // MFMA pass, cheaper than a workgroup barrier) and stores the same bits to the same place: one copy serves the four waves.
+    __shared__ __attribute__((aligned(16))) float ubuf[NREP][2 * RW];
     __shared__ float cst[NREP][4];
     __shared__ float mlh[NREP][2];
 
@@ -1176,7 +1182,9 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     const int* vcp = has_vtile ? a.vcnt + vb : (const int*)dummy16;
     const uint32_t* vtp = has_vtile ? a.vtile + vb * a.vtile_cap + tid : (const uint32_t*)dummy16;
     const int kc_n = has_ktile ? kcp[0] : 0, vc_n0 = has_vtile ? vcp[0] : 0, vc_n1 = (has_vtile && tn > 64) ? vcp[1] : 0;
-    const uint32_t ke0 = ktp[0], ke1 = ktp[has_ktile ? 256 : 0], ve0 = vtp[0], ve1 = vtp[has_vtile ? a.vtile_cap : 0];
+    uint32_t koff1 = has_ktile ? 256u : 0u, voff1 = has_vtile ? (uint32_t)a.vtile_cap : 0u;      // (as in the vector kernel above)
+    asm volatile("" : "+v"(koff1), "+v"(voff1));
+    const uint32_t ke0 = ktp[0], ke1 = ktp[koff1], ve0 = vtp[0], ve1 = vtp[voff1];
     if (!tok_ok) { vsc1 = 0.0f; vmn1 = 0.0f; }
 
     typedef union { uint4 u; half8_t h; } U8;
@@ -1252,7 +1260,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         if (x31 < 2 * RW) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (q + 4 * kg < NREP) ubuf[wave][q + 4 * kg][x31] = au[q] * a.qscale;
+                if (q + 4 * kg < NREP) ubuf[q + 4 * kg][x31] = au[q] * a.qscale;
         }
         wave_sync();
     }
@@ -1304,7 +1312,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
                 if (a.rk) {
                     float accl = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < RW; c++) accl = fmaf(tq[c], ubuf[wave][m][uo + c], accl);
+                    for (int c = 0; c < RW; c++) accl = fmaf(tq[c], ubuf[m][uo + c], accl);
                     v += accl;
                 }
                 s[m][el_l] = v;
@@ -1370,7 +1378,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         if (x31 < RW) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (q + 4 * kg < NREP) { ubuf[wave][q + 4 * kg][x31] = w0[q]; ubuf[wave][q + 4 * kg][RW + x31] = w1[q]; }
+                if (q + 4 * kg < NREP) { ubuf[q + 4 * kg][x31] = w0[q]; ubuf[q + 4 * kg][RW + x31] = w1[q]; }
         }
         wave_sync();
     }
@@ -1420,7 +1428,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
                 if (a.rv) {
                     float accl = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < RW; c++) accl = fmaf(t0v[c], ubuf[wave][m][c], fmaf(t1v[c], ubuf[wave][m][RW + c], accl));
+                    for (int c = 0; c < RW; c++) accl = fmaf(t0v[c], ubuf[m][c], fmaf(t1v[c], ubuf[m][RW + c], accl));
                     o += accl;
                 }
                 a.part_o[((bhq0 + m) * a.pslots + split) * AD + el_l] = o;
