@@ -1,0 +1,32 @@
+"""Phase clocks of k_main_kernel (library built with GEAR_KF_CLK: temporary instrumentation).  usage: python tools/exp_kmain_clk.py"""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from gear_amd import _lib as L
+from gear_amd import compress as C
+
+lib = L.load()
+fn = lib.gear_debug_kf_clk
+fn.argtypes = [ctypes.c_void_p]
+fn.restype = ctypes.c_int
+Lr, H, T, D, g, bits, rank, k = 32, 32, 4096, 128, 64, 2, 8, 40
+torch.manual_seed(0)
+x = torch.empty((Lr, H, T, D), dtype=torch.float16, device="cuda")
+for l in range(Lr):
+    x[l] = torch.randn((H, T, D), device="cuda").half()
+P0 = torch.rand((Lr, H, D, rank), device="cuda")
+for _ in range(3):
+    pk = C.compress_key(x, bits, g, k_out=k, rank=rank, loop=3, mode="fp32", P0=P0, path="fused")
+    del pk
+torch.cuda.synchronize()
+buf = np.zeros((4096, 8), dtype=np.uint64)
+assert fn(buf.ctypes.data) == 0
+t = buf.astype(np.int64)
+t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]
+d = np.diff(t, axis=1)
+names = ["wait for x (forced vmcnt 0)", "quantize tile", "payload + E tile stores", "issue next loads", "barrier 1", "Gram MFMAs (4 tiles)", "barrier 2"]
+print(f"{len(t)} workgroups, last round of each; cycles mean / median / p90")
+for i, n in enumerate(names):
+    print(f"  {n:32s} {d[:, i].mean():8.0f} {np.median(d[:, i]):8.0f} {np.percentile(d[:, i], 90):8.0f}")
+print("  round total", (t[:, 7] - t[:, 0]).mean())
