@@ -23,10 +23,13 @@ torch.cuda.synchronize()
 buf = np.zeros((4096, 8), dtype=np.uint64)
 assert fn(buf.ctypes.data) == 0
 t = buf.astype(np.int64)
-t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]
+NCLK = int(os.environ.get("KF_NCLK", "8"))
+t = t[(t[:, 0] > 0) & (t[:, NCLK - 1] > 0)][:, :NCLK]
 d = np.diff(t, axis=1)
 names = ["wait for x (forced vmcnt 0)", "quantize tile", "payload + E tile stores", "issue next loads", "barrier 1", "Gram MFMAs (4 tiles)", "barrier 2"]
+if NCLK == 6:
+    names = ["wait for the tile (forced vmcnt 0)", "E half 0 -> LDS", "MFMA + Q store half 0", "E half 1 -> LDS", "(next loads) MFMA + Q store half 1"]
 print(f"{len(t)} workgroups, last round of each; cycles mean / median / p90")
 for i, n in enumerate(names):
     print(f"  {n:32s} {d[:, i].mean():8.0f} {np.median(d[:, i]):8.0f} {np.percentile(d[:, i], 90):8.0f}")
-print("  round total", (t[:, 7] - t[:, 0]).mean())
+print("  round total", (t[:, NCLK - 1] - t[:, 0]).mean())
