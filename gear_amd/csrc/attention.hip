@@ -77,7 +77,11 @@ struct AttnArgs {
     const uint8_t* kochunk;
     const uint8_t* vochunk;
     int nbk, nbv;
+    // log2 of group / seglen / (Hq / Hkv) when they are powers of two, else -1: the short-chunk kernel's index arithmetic then has
+    // no integer division (each is ~20 vector instructions; the kernel is bound by instruction issue at batch 1)
+    int gshift, seglen_shift, nrep_shift;
 };
+__device__ __forceinline__ uint32_t div_sh(uint32_t x, int d, int sh) { return sh >= 0 ? x >> sh : x / (uint32_t)d; }
 
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
 #pragma unroll
@@ -593,8 +597,25 @@ __device__ __forceinline__ float reduce8_over_wave(float (&v)[8], int lane) {
 // grid (splits, B * Hq), any Hq / Hkv.
 // RS: factor row length in the payload (a.rk / a.rv are 0 or RS) -- 4, 8 or 16.  Rank 4 (BASELINE configs[1]) computes at width
 // 8 with the upper half zero: its rows are 8-byte loads.
+// acc[j] += sa * code_j for the CPW codes of word w, two instructions per element instead of three (extract, convert, multiply-add):
+// a code field masked out of the word IS an fp16 number -- the subnormal code * 2^-24 -- and v_fma_mix_f32 takes an fp16 half (low or
+// high, by op_sel) as a factor of an fp32 multiply-add.  One shift + one mask give the pair (j, j + CPW / 2); the caller's scale
+// carries the 2^24.  Same bits as fmaf(sa, (float)code, acc): the product is the same real number, rounded once.
+template <int BITS>
+__device__ __forceinline__ void dq_fma_word(uint32_t w, float sa24, float (&acc)[32 / BITS]) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t FM = ((1u << BITS) - 1u) * 0x00010001u;
+#pragma unroll
+    for (int k = 0; k < CPW / 2; k++) {
+        const uint32_t y = (w >> (BITS * k)) & FM;
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(acc[k]) : "v"(sa24), "v"(y));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc[k + CPW / 2]) : "v"(sa24), "v"(y));
+    }
+}
+constexpr float DQ_2P24 = 16777216.0f;
+
 template <int BITS, typename ST, int RS, int NREP>
-__global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
+__global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_small(AttnArgs a) {
     constexpr bool R16 = RS == 16;
     constexpr int RW = R16 ? 16 : 8;   // factor row width the arithmetic runs at
     constexpr int CPW = 32 / BITS;
@@ -620,15 +641,15 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x;
-    int b, hkv;
+    // grid (chunks, heads of a batch entry -- query heads, or KV heads when a workgroup serves a group --, batch): no division
+    const int b = blockIdx.z;
+    int hkv;
     int64_t bhq0;                      // first (NREP == 1: the only) query head of this workgroup
     if (NREP == 1) {
-        bhq0 = blockIdx.y;
-        b = (int)(bhq0 / a.Hq);
-        hkv = (int)(bhq0 % a.Hq) / (a.Hq / a.Hkv);
+        hkv = (int)div_sh(blockIdx.y, a.Hq / max(a.Hkv, 1), a.nrep_shift);
+        bhq0 = (int64_t)b * a.Hq + blockIdx.y;
     } else {
-        b = (int)blockIdx.y / a.Hkv;
-        hkv = (int)blockIdx.y % a.Hkv;
+        hkv = (int)blockIdx.y;
         bhq0 = (int64_t)b * a.Hq + (int64_t)hkv * NREP;
     }
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     // ------------------------------------------------------------------ every load of the chunk
     const int dq = tid & (AD - 1), slab = tid >> 7;   // factor rows: one (slab, channel) per thread
     // factor segment of each 64-token slab: block-uniform (scalar) arithmetic, then a select by slab
-    auto seg_at = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (t - a.seg0) / a.seglen; };
+    auto seg_at = [&](int t) { return (a.seglen == 0 || t < a.seg0) ? 0 : 1 + (int)div_sh((uint32_t)(t - a.seg0), a.seglen, a.seglen_shift); };
     const int seg_s0 = seg_at(t0), seg_s1 = seg_at(min(t0 + 64, t0 + tn - 1));
     float qvr[NREP];                   // this thread's channel of every query head of the group
 #pragma unroll
@@ -673,12 +694,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
         const ST* ks_b = kscale + bhk * AD * (int64_t)a.lsk;
         const ST* km_b = kmn + bhk * AD * (int64_t)a.lsk;
         const uint32_t lwc = kval ? (uint32_t)lw : 0u;
-        const uint32_t gk = (uint32_t)(t0 + (int)lwc * CPW) / (uint32_t)a.group;
+        const uint32_t gk = div_sh((uint32_t)(t0 + (int)lwc * CPW), a.group, a.gshift);
+        // (one multiply per pitch; the channels of a thread are NDS rows apart: a block-uniform step)
+        const uint32_t ko0 = (uint32_t)dsub * (uint32_t)a.ldk + lwc, kstep = (uint32_t)(NDS * a.ldk);
+        const uint32_t so0 = (uint32_t)dsub * (uint32_t)a.lsk + gk, sstep = (uint32_t)(NDS * a.lsk);
 #pragma unroll
         for (int i = 0; i < KIT; i++) {
-            const uint32_t ch = (uint32_t)(dsub + NDS * i);
-            kw[i] = kc_b[ch * (uint32_t)a.ldk + lwc];
-            const float sc = ld_st<ST>(ks_b + ch * (uint32_t)a.lsk + gk), mv = ld_st<ST>(km_b + ch * (uint32_t)a.lsk + gk);
+            kw[i] = kc_b[ko0 + (uint32_t)i * kstep];
+            const float sc = ld_st<ST>(ks_b + so0 + (uint32_t)i * sstep), mv = ld_st<ST>(km_b + so0 + (uint32_t)i * sstep);
             ksc[i] = kval ? sc : 0.0f;
             kmv[i] = kval ? mv : 0.0f;
         }
@@ -687,7 +710,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     uint32_t vw[VIT];
     float vsc[VIT], vmv[VIT];
     {
-        const uint32_t gv = (uint32_t)(wv * CPW) / (uint32_t)a.group, ngv = (uint32_t)(AD / a.group);
+        const uint32_t gv = div_sh((uint32_t)(wv * CPW), a.group, a.gshift), ngv = div_sh((uint32_t)AD, a.group, a.gshift);
         const uint32_t* vc_b = a.vcode + (bhk * a.tcap_v + t0) * (int64_t)NWV;
         const ST* vs_b = vscale + (bhk * a.tcap_v + t0) * (int64_t)ngv;
         const ST* vm_b = vmn + (bhk * a.tcap_v + t0) * (int64_t)ngv;
@@ -697,7 +720,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
             const bool ok = t < tn;
             const uint32_t tc = ok ? (uint32_t)t : 0u;
             vw[i] = vc_b[tc * NWV + wv];
-            const float sc = ld_st<ST>(vs_b + tc * ngv + gv), mv = ld_st<ST>(vm_b + tc * ngv + gv);
+            const uint32_t so = (a.gshift >= 0 ? tc << (7 - a.gshift) : tc * ngv) + gv;       // (AD = 2^7)
+            const float sc = ld_st<ST>(vs_b + so), mv = ld_st<ST>(vm_b + so);
             vsc[i] = ok ? sc : 0.0f;
             vmv[i] = ok ? mv : 0.0f;
         }
@@ -710,10 +734,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
     const uint4* dummy16 = (const uint4*)(a.q + bhq0 * AD);
     const uint8_t* dummy1 = (const uint8_t*)dummy16;
     const uint32_t trow = (uint32_t)min(tid, tn - 1);                       // (threads past the chunk read its last row)
-    const int64_t fseg = slab ? (int64_t)seg_s1 : (int64_t)seg_s0;
-    const uint4* kpp = a.rk ? (const uint4*)(a.kP + fseg * a.kP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    // (segment offsets: two block-uniform products on the scalar unit and a select, not a 64-bit multiply per lane)
+    const int64_t kfo0 = (int64_t)seg_s0 * a.kP_seg_stride, kfo1 = (int64_t)seg_s1 * a.kP_seg_stride;
+    const int64_t vfo0 = (int64_t)seg_s0 * a.vP_seg_stride, vfo1 = (int64_t)seg_s1 * a.vP_seg_stride;
+    const uint4* kpp = a.rk ? (const uint4*)(a.kP + (slab ? kfo1 : kfo0) + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
     const uint4* kqp = a.rk ? (const uint4*)(a.kQ + (bhk * a.tf_k + t0) * (int64_t)RS + trow * RS) : dummy16;
-    const uint4* vpp = a.rv ? (const uint4*)(a.vP + fseg * a.vP_seg_stride + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
+    const uint4* vpp = a.rv ? (const uint4*)(a.vP + (slab ? vfo1 : vfo0) + bhk * AD * RS + (uint32_t)dq * RS) : dummy16;
     const uint4* vqp = a.rv ? (const uint4*)(a.vQ + (bhk * a.tf_v + t0) * (int64_t)RS + trow * RS) : dummy16;
     auto ldrow = [](const uint4* p) {                  // one factor row: 16 bytes, or 8 (rank 4) with zeros above
         if (RS == 4) { const uint2 t = *(const uint2*)p; return make_uint4(t.x, t.y, 0u, 0u); }
@@ -796,10 +822,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < KIT; i++) {
             const float qd = qs[dsub + NDS * i];
-            const float sa = ksc[i] * qd;
             zacc = fmaf(kmv[i], qd, zacc);
-#pragma unroll
-            for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((kw[i] >> (BITS * j)) & MASK), acc[j]);
+            dq_fma_word<BITS>(kw[i], (ksc[i] * qd) * DQ_2P24, acc);
         }
 #pragma unroll
         for (int j = 0; j < CPW; j++) acc[j] += zacc;
@@ -903,10 +927,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_small(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < VIT; i++) {
             const float pt = s[rsub + NRS * i];
-            const float sa = vsc[i] * pt;
             zacc = fmaf(vmv[i], pt, zacc);
-#pragma unroll
-            for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((vw[i] >> (BITS * j)) & MASK), acc[j]);
+            dq_fma_word<BITS>(vw[i], (vsc[i] * pt) * DQ_2P24, acc);
         }
 #pragma unroll
         for (int j = 0; j < CPW; j++) acc[j] += zacc;
@@ -1689,6 +1711,9 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     GEAR_CHECK_ARG(a.kk_stride >= a.kk && (a.kkb == 0 || (seglen > 0 && kk0 >= 0)), "gear_attn_decode: bad outlier list geometry");
     a.qscale = qscale;
     a.seg0 = seg0; a.seglen = seglen;
+    a.gshift = gear_is_pow2(group) ? __builtin_ctz((unsigned)group) : -1;
+    a.seglen_shift = gear_is_pow2(seglen) ? __builtin_ctz((unsigned)seglen) : -1;
+    a.nrep_shift = (Hkv > 0 && Hq % Hkv == 0 && gear_is_pow2(Hq / Hkv)) ? __builtin_ctz((unsigned)(Hq / Hkv)) : -1;
     a.dyn = (const int*)dyn_state;
     // chunk index of the outlier lists: only with 128-token bounds (K) / one bound per KV head (V), the small kernel's chunks
     a.kochunk = (a.kk && (a.kkb > 0 ? nbk_pitch > 0 : a.kk_stride == a.kk)) ? (const uint8_t*)kochunk : nullptr;
@@ -1736,13 +1761,13 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         const int gq = gear_options().attn_gqa_group;
         const bool group_on = gq > 0 || (gq < 0 && (int64_t)B * Hq * a.splits >= 32768);
         const int nrep_t = (small && group_on && (n_rep == 2 || n_rep == 4 || n_rep == 8)) ? n_rep : 1;
-        const dim3 gridg(a.pslots, (unsigned)(B * Hkv));
+        const dim3 gridg(a.pslots, (unsigned)Hkv, (unsigned)B), grids(a.pslots, (unsigned)Hq, (unsigned)B);
 #define GOS(BI, STT, RSV)                                                                                                  \
     do {                                                                                                                   \
         if (nrep_t == 8) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 8>), gridg, dim3(256), 0, st, a);      \
         else if (nrep_t == 4) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 4>), gridg, dim3(256), 0, st, a); \
         else if (nrep_t == 2) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 2>), gridg, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 1>), grid, dim3(256), 0, st, a);                   \
+        else hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 1>), grids, dim3(256), 0, st, a);                  \
     } while (0)
         // matrix-core variant (see attn_decode_partial_mfma): group 64, no outliers or outliers through sparse tiles
         // Measured (profiles/r5_attn_experiments.md): 1.3 - 1.65 x faster than one workgroup per query head for grouped-query shapes
