@@ -1031,8 +1031,8 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
 //
 // The kernel above is bound by vector instructions per QUERY head: extract + convert + multiply-add per cached element, then
 // ~250 instructions of cross-lane butterflies to sum over channels / tokens -- and for grouped-query attention all of it again for
-// every query head of the group.  Here the chunk's CODES go into an LDS tile once, as exact small integers in fp16 (no scale, no
-// zero point: 1.5 instructions per element, `(w >> s) & 0x00030003 | 0x6400 6400` then a packed subtract of 1024), and
+// every query head of the group.  Here the chunk's CODES go into an LDS tile once, as exact fp16 numbers (no scale, no zero
+// point: one instruction per element -- `(w >> s) & 0x00030003` is the pair of fp16 subnormals code * 2^-24 as it stands), and
 //     S[h, t] = sum_c (q[h, c] sc[c, g(t)]) code[c, t]  +  sum_c q[h, c] mn[c, g(t)]
 //     O[h, d] = sum_t (p[h, t] sc[t, g(d)]) code[t, d]  +  sum_t p[h, t] mn[t, g(d)]
 // are v_mfma_f32_32x32x16_f16 with the scaled q / p rows as the A operand (fp16 head + remainder: exact to 2^-22; up to 8 query
@@ -1051,17 +1051,19 @@ __device__ __forceinline__ int mt_physical(int e, int cpw) {     // element inde
     const int h = cpw >> 1, r = e & (cpw - 1);
     return (e & ~(cpw - 1)) | ((r & (h - 1)) << 1) | (r >= h ? 1 : 0);
 }
-// the CPW codes of a word as fp16 integers, pairs (j, j + CPW/2), into CPW consecutive halfs of a tile row (16-byte aligned)
+// the CPW codes of a word as fp16 numbers, pairs (j, j + CPW/2), into CPW consecutive halfs of a tile row (16-byte aligned).
+// The fields are stored as they stand in the word: an fp16 whose only set bits are a code's is the SUBNORMAL code * 2^-24, exact,
+// and the matrix cores take subnormal fp16 operands at full precision (checked by the parity tests: a flush would zero every
+// score) -- one shift + one mask per pair; the accumulators are multiplied by MT_CODE_SCALE afterwards.  (The first version built
+// 1024 + code by an OR and subtracted 1024: twice the instructions of a kernel that is bound by instruction issue.)
+constexpr float MT_CODE_SCALE = 16777216.0f;
 template <int BITS>
 __device__ __forceinline__ void mt_store_codes(uint16_t* dst, uint32_t w) {
     constexpr int CPW = 32 / BITS;
     constexpr uint32_t FM = ((1u << BITS) - 1u) * 0x00010001u;
     uint32_t z[CPW / 2];
 #pragma unroll
-    for (int k = 0; k < CPW / 2; k++) {
-        const uint32_t y = ((w >> (BITS * k)) & FM) | 0x64006400u;          // (1024 + code k, 1024 + code k + CPW/2), exact
-        asm("v_pk_add_f16 %0, %1, %2" : "=v"(z[k]) : "v"(y), "v"(0xE400E400u));   // - 1024
-    }
+    for (int k = 0; k < CPW / 2; k++) z[k] = (w >> (BITS * k)) & FM;
 #pragma unroll
     for (int v4 = 0; v4 < CPW / 8; v4++) ((uint4*)dst)[v4] = make_uint4(z[4 * v4], z[4 * v4 + 1], z[4 * v4 + 2], z[4 * v4 + 3]);
 }
@@ -1276,6 +1278,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     // ------------------------------------------------------------------ 2. scores of this wave's 32 token columns
     mt_operands<MP>(tile, wave, lane, bo);
     float16_t acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], 0, 8, zero16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] *= MT_CODE_SCALE;
     if (a.rk) {   // u[m][r] of both segments: q (exact) against the pad columns; through the wave's LDS slot to the lanes that need it
         mt_operands<MP>(tile, 4, lane, bo);
         const float16_t au = mfma_pass(&araw[0][0][0], nullptr, 0, 8, zero16);
@@ -1393,6 +1397,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     // ------------------------------------------------------------------ 4. outputs of this wave's 32 channel columns
     mt_operands<MP>(tile, wave, lane, bo);
     acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], 0, 8, zero16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] *= MT_CODE_SCALE;
     if (a.rv) {   // w[m][r] = sum over a slab's tokens of p[m][t] Qv[t][r], slab by slab (contraction steps 0-3 / 4-7)
         mt_operands<MP>(tile, 4, lane, bo);
         const float16_t w0 = mfma_pass(&araw[0][0][0], &araw[1][0][0], 0, 4, zero16);
