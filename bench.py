@@ -350,6 +350,40 @@ def decode_tokens_per_s(cfg, dev, world, rank, new_tokens=64, exchange="both"):
     res.update({"tokens_per_s": best, "ms_per_token": 1e3 / best,
                 "path": "FastGearDecoder (GearKVCache with in-place block compress + fused GEMVs + gear_attn_decode_cache)",
                 "peak_mem_MiB": torch.cuda.max_memory_allocated(dev) / 2 ** 20})
+    if world == 1:
+        # the reference harness's comparison (cuda_supported_gear/test.py:41-62 times the model "None" beside gearl / KIVI): the SAME
+        # decoder over an UNCOMPRESSED fp16 cache (cache.Fp16KVCache + gear_attn_decode_f16), at batch 1 and at a serving batch --
+        # tokens/s = batch x steps / time, eager steps on both sides
+        def by_batch(kind, Bb, n_steps):
+            dec = FastGearDecoder(model, T + n_steps + 72, batch=Bb, cache_kind=kind)
+            idb = ids.expand(Bb, -1).contiguous()
+            nx = dec.prefill(idb).argmax(-1, keepdim=True)
+            for _ in range(2):
+                nx = dec.step(nx).argmax(-1, keepdim=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                nx = dec.step(nx).argmax(-1, keepdim=True)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            cache_bytes = (sum((lw["cache"].kwin.numel() + lw["cache"].vwin.numel()) * 2 for lw in dec.layers) if kind == "fp16" else
+                           sum(t.numel() * t.element_size() for t in dec.pool.buf.values()))       # (allocated capacity, both sides)
+            dec.close()
+            del dec
+            torch.cuda.empty_cache()
+            return Bb * n_steps / dtb, cache_bytes
+        cmp_b = {}
+        for Bb in (1, 16):
+            n_steps = 40 if Bb == 1 else 24                # (stays inside one 64-token block: no block boundary in the timed steps)
+            g_tps, gb = by_batch("gear", Bb, n_steps)
+            f_tps, fb = by_batch("fp16", Bb, n_steps)
+            cmp_b["B%d" % Bb] = {"gear_tokens_per_s": g_tps, "fp16_cache_tokens_per_s": f_tps, "gear_vs_fp16_cache": g_tps / f_tps,
+                                 "gear_cache_MiB": gb / 2 ** 20, "fp16_cache_MiB": fb / 2 ** 20}
+        res["vs_fp16_cache"] = dict(cmp_b, note="same FastGearDecoder, weights and fused GEMVs; cache_kind 'gear' (compressed streaming "
+                                    "cache) against 'fp16' (uncompressed, gear_attn_decode_f16); eager steps, prompt %d tokens; "
+                                    "batch > 4 projects through the library GEMM on both sides; *_cache_MiB = ALLOCATED capacity of all layers (the "
+                                    "compressed side includes its acceleration structures -- sparse tiles, chunk index -- and a channel-"
+                                    "factor slot for every 64-token block of the capacity, used or not)" % prompt)
     if world == 1 and cfg["layers"] * cfg["hidden"] <= 32 * 4096:
         # the reference-shaped attention hook (17-slot tuple cache, torch.cat appends, ~60 eager ops per layer): what a
         # reference user gets from the documented import swap alone (no outliers: the reference's fused path stores none)

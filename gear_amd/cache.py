@@ -479,3 +479,45 @@ class GearKVCache:
             o_off = self.kk0 + ((self.n_comp - self.seg0) // self.R) * self.kk_blk
             self._store(self.kwin, self.vwin, self.R, seg, self.kk_blk, o_off)
             self.n_win = 0
+
+
+class Fp16KVCache:
+    """The UNCOMPRESSED baseline behind the same decoder (the model "None" the reference's harness times beside gearl / KIVI,
+    cuda_supported_gear/test.py:41-62): every token's K / V stays fp16 in a pre-allocated [B, Hkv, capacity, 128] pair, the
+    attention is gear_attn_decode_f16 (the same split / merge kernels as the compressed path).  It has GearKVCache's window
+    interface -- the "window" is the whole cache --, so FastGearDecoder's fused q/k/v projection appends to it unchanged."""
+
+    def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, device, head_dim: int = 128):
+        self.B, self.H, self.D = batch, n_kv_heads, head_dim
+        self.R = max_tokens
+        self.kwin = torch.zeros((batch, n_kv_heads, max_tokens, head_dim), dtype=torch.float16, device=device)
+        self.vwin = torch.zeros_like(self.kwin)
+        self.n_win = 0
+        self.n_comp = 0
+        self.state = None
+
+    @property
+    def seq_len(self) -> int:
+        return self.n_win
+
+    def prefill(self, k: torch.Tensor, v: torch.Tensor):
+        assert self.n_win == 0 and k.shape[2] <= self.R
+        T = k.shape[2]
+        self.kwin[:, :, :T] = k
+        self.vwin[:, :, :T] = v
+        self.n_win = T
+
+    def append_rope(self, qkv: torch.Tensor, n_q_heads: int, pos: int, theta: float) -> torch.Tensor:
+        if self.n_win >= self.R:
+            raise L.GearError(f"Fp16KVCache: capacity {self.R} reached")
+        q = torch.empty((self.B, n_q_heads, 1, self.D), dtype=torch.float16, device=qkv.device)
+        rc = L.load().gear_rope_append(L.ptr(qkv), self.B, n_q_heads, self.H, self.D, pos, theta, L.ptr(q), L.ptr(self.kwin),
+                                       L.ptr(self.vwin), self.n_win, self.R, L.stream_ptr(qkv))
+        L.check(rc, "gear_rope_append")
+        self.n_win += 1
+        return q
+
+    def attend(self, q: torch.Tensor) -> torch.Tensor:
+        from .attention import decode_attention_f16
+        return decode_attention_f16(q, self.kwin, self.vwin, T=self.n_win)
+

@@ -14,13 +14,13 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .cache import GearKVCache, GearKVCachePool
+from .cache import Fp16KVCache, GearKVCache, GearKVCachePool
 from .modeling_llamagear import apply_rotary_pos_emb
 
 
 class FastGearDecoder:
     def __init__(self, model, max_tokens: int, batch: int = 1, seed: int = 0, tp_rank: int = 0, tp_world: int = 1,
-                 tp_group=None, tp_exchange: str = "collective", v_selection: str = "exact"):
+                 tp_group=None, tp_exchange: str = "collective", v_selection: str = "exact", cache_kind: str = "gear"):
         """tp_world > 1: the cache and the attention are sharded head-wise: this rank owns
         Hq / tp_world query heads with their KV heads -- local q/k/v projection rows, local compressed cache, local attention --
         and all-gathers the per-rank attention output (parallel.HeadGather, pre-allocated) in front of the replicated
@@ -32,7 +32,10 @@ class FastGearDecoder:
         one GPU yet (no multi-GPU node was ever available to this build): the collective is the conservative default.
         v_selection: "exact" = the V outliers of a token row are selected over ALL ranks' heads (the reference's row spans the heads:
         compress_function.py:304-311; csrc/vsel.hip through parallel.exact_v_thresholds: two launches + one small all-gather per
-        compress call), "per_shard" = k / world inside the shard's own heads (rounds 1-3)."""
+        compress call), "per_shard" = k / world inside the shard's own heads (rounds 1-3).
+        cache_kind: "gear" (the compressed streaming cache) or "fp16" = cache.Fp16KVCache, the uncompressed baseline the reference's
+        harness times beside the compressed models (cuda_supported_gear/test.py:41-62: model "None"): same weights, same fused GEMVs,
+        same attention split / merge kernels over fp16 rows; eager steps on one GPU only."""
         self.model = model
         cfg = model.config
         self.cfg = cfg
@@ -51,9 +54,14 @@ class FastGearDecoder:
         # pooled cache storage: block boundaries compress every layer's window in one launch sequence
         if v_selection not in ("exact", "per_shard"):
             raise ValueError(f"v_selection {v_selection!r}: 'exact' or 'per_shard'")
+        if cache_kind not in ("gear", "fp16"):
+            raise ValueError(f"cache_kind {cache_kind!r}: 'gear' or 'fp16'")
+        if cache_kind == "fp16" and tp_world > 1:
+            raise NotImplementedError("the fp16-cache baseline runs on one GPU")
+        self.cache_kind = cache_kind
         tp = dict(rank=tp_rank, world=tp_world, group=tp_group, exact=v_selection == "exact") if tp_world > 1 else None
-        self.pool = GearKVCachePool(len(model.model.layers), batch, self.Hkv, max_tokens, cc0, dev, self.D, seed=seed,
-                                    heads_total=self.Hkv_full, tp=tp)
+        self.pool = None if cache_kind == "fp16" else GearKVCachePool(len(model.model.layers), batch, self.Hkv, max_tokens, cc0, dev,
+                                                                      self.D, seed=seed, heads_total=self.Hkv_full, tp=tp)
         for i, layer in enumerate(model.model.layers):
             at, mlp = layer.self_attn, layer.mlp
             assert at.q_proj.bias is None, "attention_bias is not supported by the fused qkv GEMV"
@@ -72,8 +80,9 @@ class FastGearDecoder:
             wgu = torch.stack([mlp.gate_proj.weight, mlp.up_proj.weight], 1).reshape(-1, n2.shape[0]) * n2[None, :]
             self.layers.append(dict(
                 wqkv=wqkv.contiguous(), wqkv_full=wqkv_full if tp_world > 1 else None, wo=at.o_proj.weight, wgu=wgu.contiguous(), wd=mlp.down_proj.weight,
-                cache=GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i,
-                                  pool=self.pool, layer=i, heads_total=self.Hkv_full, tp=tp),
+                cache=(Fp16KVCache(batch, self.Hkv, max_tokens, dev, self.D) if cache_kind == "fp16" else
+                       GearKVCache(batch, self.Hkv, max_tokens, at.compress_config, dev, self.D, seed=seed + i,
+                                   pool=self.pool, layer=i, heads_total=self.Hkv_full, tp=tp)),
                 rotary=at.rotary_emb))
         self.w_head = (model.lm_head.weight * model.model.norm.weight[None, :]).contiguous()
         self.pos = 0
@@ -227,7 +236,7 @@ class FastGearDecoder:
             res = self._linear_add(act, lw["wd"], res)
         self.pos += 1
         self._state_dirty = True          # (the captured graph reads pos / slot / T / W from self.state)
-        if self.layers[0]["cache"].n_win == self.layers[0]["cache"].R:
+        if self.pool is not None and self.layers[0]["cache"].n_win == self.layers[0]["cache"].R:
             self.pool.compress_all()
             self._after_boundary()
         return self._norm_linear(res, self.w_head)
@@ -258,6 +267,8 @@ class FastGearDecoder:
         """One greedy decode token by replaying the captured graph.  token_ids (optional) overrides the token the graph
         produced itself; returns the NEXT token [B,1] (the graph's own argmax).  Block compression (every `residual`
         tokens) runs eagerly between replays."""
+        if self.pool is None:
+            raise NotImplementedError("step_graph(): the fp16-cache baseline has eager steps only")
         if self.gather is not None and not self.gather.capturable:
             raise NotImplementedError("step_graph() with tp_world > 1 needs a capturable exchange: tp_exchange='peer', or the "
                                       "collective on the RCCL backend when its capture probe passed (the one-GPU gloo staging "

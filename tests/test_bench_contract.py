@@ -60,6 +60,11 @@ def test_committed_bench_line_has_the_contract_fields(line):
             assert by_b[b]["fp16_cache_us_per_call"] > 0
             assert abs(by_b[b]["speedup_vs_fp16_cache"] - by_b[b]["fp16_cache_us_per_call"] / by_b[b]["us_per_call"]) < 1e-9
         assert d["decode"]["hook_module_tokens_per_s"] >= 200.0
+        # the reference harness's own comparison: the same decoder over an uncompressed fp16 cache, batch 1 and a serving batch
+        vs = d["decode"]["vs_fp16_cache"]
+        for b in ("B1", "B16"):
+            assert vs[b]["gear_tokens_per_s"] > 0 and vs[b]["fp16_cache_tokens_per_s"] > 0 and vs[b]["gear_cache_MiB"] < vs[b]["fp16_cache_MiB"]
+            assert abs(vs[b]["gear_vs_fp16_cache"] - vs[b]["gear_tokens_per_s"] / vs[b]["fp16_cache_tokens_per_s"]) < 1e-9
     if line.startswith("r4"):
         # round 4: the V chain is rows -> wave-private Gram kernel -> per-head solve -> Q pass; the PMC traffic of the chain is tied to
         # the library that produced the line; the hook module (the documented import swap) runs on its fast path

@@ -312,6 +312,30 @@ def test_fast_decoder_tracks_the_attention_hook_module(n_kv):
     assert fast.layers[0]["cache"].n_comp == 192 and fast.layers[0]["cache"].n_win == 8
 
 
+@pytest.mark.parametrize("batch, n_kv", [(1, 2), (2, 4), (6, 2)])
+def test_fp16_cache_baseline_decoder(batch, n_kv):
+    """cache_kind='fp16' (the uncompressed model "None" of the reference's harness, cuda_supported_gear/test.py:41-62) through the same
+    decoder: a token step over the fp16 cache must give the logits of the dense causal forward over prompt + token (the decoder's own
+    prefill path: torch SDPA), for the fused GEMV path (batch <= 4) and the library-GEMM path (batch 6), MHA-like and grouped heads."""
+    from gear_amd.fast_decode import FastGearDecoder
+    model = _tiny("KIVI", n_kv)
+    torch.manual_seed(batch)
+    ids = torch.randint(0, 1000, (batch, 151)).cuda()
+    dec = FastGearDecoder(model, 256, batch=batch, cache_kind="fp16")
+    ref = FastGearDecoder(model, 256, batch=batch, cache_kind="fp16")
+    with torch.no_grad():
+        dec.prefill(ids[:, :140])
+        for t in range(140, 151):
+            ls = dec.step(ids[:, t:t + 1])
+        lr = ref.prefill(ids)
+    assert dec.layers[0]["cache"].n_win == 151 and dec.pool is None
+    cos = torch.nn.functional.cosine_similarity(ls.float(), lr.float()).min()
+    assert cos > 0.9995, cos
+    assert float((ls.float() - lr.float()).abs().max()) <= 2e-2 * float(lr.float().abs().max())
+    with pytest.raises(NotImplementedError):
+        dec.step_graph()
+
+
 def test_fast_decoder_generate_lowrank_deterministic():
     from gear_amd.fast_decode import FastGearDecoder
     model = _tiny("gearlKIVI")
