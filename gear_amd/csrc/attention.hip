@@ -1098,6 +1098,14 @@ __device__ __forceinline__ void mt_operands(const uint16_t* tile, int I, int lan
                  : "memory");
 }
 
+// Phase clocks of the kernel below (profiles/r5_attn_experiments.md; tools/exp_attn_clk.py): compiled in only with -DGEAR_ATTN_CLK
+// (`make -C gear_amd/csrc CXXFLAGS+=-DGEAR_ATTN_CLK`); thread 0 of the first 8192 workgroups stores s_memtime at the phase boundaries.
+#ifdef GEAR_ATTN_CLK
+__device__ unsigned long long attn_clk_buf[8 * 8192];
+#define ATTN_CLK(k) do { if (tid == 0) { const unsigned bid_ = blockIdx.y * gridDim.x + blockIdx.x; if (bid_ < 8192) attn_clk_buf[bid_ * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define ATTN_CLK(k) do { } while (0)
+#endif
 // Layout of a workgroup's life (3 workgroup barriers; +3 per side when the chunk has outliers):
 //   loads (all up front) | K tile: codes [channel][token] + pad columns = Pk of the chunk's two factor segments; A rows q sc (head +
 //   remainder) per token group; constant term  ||  every wave, for ITS 32 token columns: scores = MFMA(q sc, codes) + const, u =
@@ -1155,6 +1163,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     const ST* kmn = (const ST*)a.kmn;
     const ST* vscale = (const ST*)a.vscale;
     const ST* vmn = (const ST*)a.vmn;
+    ATTN_CLK(0);
 
     // ------------------------------------------------------------------ every load of the chunk (all unconditional)
     const int dq = tid & (AD - 1), half_ = tid >> 7;   // (channel | token, group | slab | side)
@@ -1249,8 +1258,10 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     for (int q = 0; q < 16; q++) zero16[q] = 0.0f;
 
     // ------------------------------------------------------------------ 1. K tile, A rows, constant term
+    ATTN_CLK(1);
 #pragma unroll
     for (int i = 0; i < WPT; i++) mt_store_codes<BITS>(tile + (rsub + RSUB * i) * MP + CPW * wl, kw[i]);
+    ATTN_CLK(2);
     if (a.rk) {
         *(uint4*)(tile + dq * MP + AD + RW * half_) = kp8;
         if (R16) *(uint4*)(tile + dq * MP + AD + RW * half_ + 8) = kp8b;
@@ -1275,6 +1286,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     vsm[0][half_][dq] = vsc1;
     vsm[1][half_][dq] = vmn1;
     __syncthreads();
+    ATTN_CLK(3);
     // ------------------------------------------------------------------ 2. scores of this wave's 32 token columns
     mt_operands<MP>(tile, wave, lane, bo);
     float16_t acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], 0, 8, zero16);
@@ -1346,6 +1358,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         }
     }
     __syncthreads();
+    ATTN_CLK(4);
     // ------------------------------------------------------------------ 3. softmax statistics (32 lanes per query head) and V tile
     {
         const int h = tid >> 5, j = tid & 31;
@@ -1394,6 +1407,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         if (R16) *(uint4*)(tile + dq * MP + AD + 8) = vq8b;
     }
     __syncthreads();
+    ATTN_CLK(5);
     // ------------------------------------------------------------------ 4. outputs of this wave's 32 channel columns
     mt_operands<MP>(tile, wave, lane, bo);
     acc = mfma_pass(&aop[g_w][0][0][0], &aop[g_w][1][0][0], 0, 8, zero16);
@@ -1468,6 +1482,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
         a.part_ml[po * 2] = mlh[tid][0];
         a.part_ml[po * 2 + 1] = mlh[tid][1];
     }
+    ATTN_CLK(6);
 }
 
 // merge the splits (+ the fp16 window, unless it came as one more chunk: a.pslots == a.splits + 1, W_arg == 0), normalise.
@@ -1604,6 +1619,11 @@ int plan_splits(int T, int bits, int64_t bhq, bool fast_ranks, int* tc_out, bool
 }
 
 }  // namespace
+#ifdef GEAR_ATTN_CLK
+extern "C" int gear_debug_attn_clk(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(attn_clk_buf), sizeof(unsigned long long) * 8 * 8192);
+}
+#endif
 
 extern "C" size_t gear_attn_decode_workspace(int B, int Hq, int T, int bits) {
     // sized for the largest plan (64 splits) so that a buffer obtained for the cache capacity serves every shorter length

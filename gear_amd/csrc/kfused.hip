@@ -666,6 +666,31 @@ __device__ __forceinline__ void gram_store(float* __restrict__ gp, int lane, con
 // registers instead of 160, which is what lets two workgroups share a CU, i.e. two waves per SIMD -- one wave's vector
 // arithmetic then overlaps the other's loads, LDS traffic and matrix-core work; with one wave per SIMD those costs simply
 // added up: 350 us of loads + 165 arithmetic + 150 Gram + 150 payload stores + 100 error store).
+// Phase clocks (profiles/r5_kmain_phase_clocks.md; tools/exp_kmain_clk.py): compiled in only with -DGEAR_KF_CLK=1 (k_main_kernel) or
+// =2 (k_qpass_kernel) -- `make -C gear_amd/csrc CXXFLAGS+=-DGEAR_KF_CLK=1` --, thread 0 of the first 4096 workgroups stores s_memtime
+// at the marked places, gear_debug_kf_clk copies the table out.  Not part of the shipped library.
+#ifdef GEAR_KF_CLK
+__device__ unsigned long long kf_clk_buf[8 * 4096];
+#define KF_CLK_AT(k) do { if (threadIdx.x == 0) { const unsigned bid_ = blockIdx.y * gridDim.x + blockIdx.x; if (bid_ < 4096) kf_clk_buf[bid_ * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#define KF_CLK_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define KF_CLK_AT(k) do { } while (0)
+#define KF_CLK_WAIT() do { } while (0)
+#endif
+#if defined(GEAR_KF_CLK) && GEAR_KF_CLK == 1
+#define KM_CLK(k) KF_CLK_AT(k)
+#define KM_WAIT() KF_CLK_WAIT()
+#else
+#define KM_CLK(k) do { } while (0)
+#define KM_WAIT() do { } while (0)
+#endif
+#if defined(GEAR_KF_CLK) && GEAR_KF_CLK == 2
+#define KQ_CLK(k) KF_CLK_AT(k)
+#define KQ_WAIT() KF_CLK_WAIT()
+#else
+#define KQ_CLK(k) do { } while (0)
+#define KQ_WAIT() do { } while (0)
+#endif
 template <int BITS, int MODE, int G, typename ST, bool FAST, bool LR, bool TR>
 __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
     constexpr int CPW = 32 / BITS;
@@ -707,11 +732,15 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
 #pragma unroll 1
     for (int t0 = tile_lo; t0 < tile_hi; t0 += 4) {
         const int tile = t0 + wave;
+        KM_CLK(0);
+        KM_WAIT();
+        KM_CLK(1);
         if (tile < tile_hi) {
             uint32_t ew[64], cwA[NW], cwB[NW];
             float scA[NG], mnA[NG], scB[NG], mnB[NG];
             if (FAST) tile_fast<BITS, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
             else tile_generic<BITS, MODE, G, ST>(xr, mk.x, mk.y, mk.z, mk.w, meanA, meanB, ew, cwA, cwB, scA, mnA, scB, mnB);
+            KM_CLK(2);
             // ---- payload stores: channel-major rows, this tile's words / groups at the token offset
             const int tok = a.t_off + tile * 64;
             uint32_t* cA = a.code + (bh * KD + 2 * lane) * a.ldc + tok / CPW;
@@ -736,9 +765,12 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
             }
         }
         // the registers of x are free: the loads of the wave's next tile fly during the Gram phase
+        KM_CLK(3);
         if (tile + 4 < tile_hi) load_tile(tile + 4);
+        KM_CLK(4);
         if (LR) {
             __syncthreads();
+            KM_CLK(5);
             const int nt = min(4, tile_hi - t0);
             for (int tt = 0; tt < nt; tt++) {
                 const uint16_t* et = etiles + tt * 64 * ET_PITCH;
@@ -747,7 +779,9 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
                 else if (wave == 2) gram_tile<2, TR>(et, lane, acc);
                 else gram_tile<3, TR>(et, lane, acc);
             }
+            KM_CLK(6);
             __syncthreads();
+            KM_CLK(7);
         }
     }
     if (!LR) return;
@@ -906,6 +940,9 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
     if (tile_lo + wave < tile_hi) load_tile(tile_lo + wave);
 #pragma unroll 1
     for (int tile = tile_lo + wave; tile < tile_hi; tile += 4) {
+        KQ_CLK(0);
+        KQ_WAIT();
+        KQ_CLK(1);
         // ---- E half tile (32 tokens) -> LDS (row = token) -> matrix cores, twice
         const uint32_t D[4] = {(mk.x & 0xFFFFu) | (mk.z << 16), (mk.x >> 16) | (mk.z & 0xFFFF0000u),
                                (mk.y & 0xFFFFu) | (mk.w << 16), (mk.y >> 16) | (mk.w & 0xFFFF0000u)};
@@ -922,6 +959,7 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
                 asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(xr[tk]), "v"(dw));
                 ((uint32_t*)(etile + t2 * ET_PITCH))[lane] = vbfi(mask_of(D[tk >> 4], tk & 15), 0u, e2);
             }
+            if (half == 0) KQ_CLK(2); else KQ_CLK(4);
             if (half == 1 && tile + 4 < tile_hi) load_tile(tile + 4);      // the next tile's loads fly during the matrix-core phase
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -958,6 +996,7 @@ __global__ __launch_bounds__(256, 3) void k_qpass_kernel(QpArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();              // the half tile is read before it is overwritten
+            if (half == 0) KQ_CLK(3); else KQ_CLK(5);
         }
     }
 }
@@ -1053,6 +1092,11 @@ void launch_main(const MainArgs& a, int64_t BH, bool fast, bool lr, bool tr, hip
 }
 
 }  // namespace
+#ifdef GEAR_KF_CLK
+extern "C" int gear_debug_kf_clk(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kf_clk_buf), sizeof(unsigned long long) * 8 * 4096);
+}
+#endif
 
 // The per-head solve on partial Gram matrices, for callers outside this file (lowrank_gram.hip: the V-side / K^T Gram kernels
 // hand over [BH][nslab][128][128] complete (mirrored) matrices exactly as k_main_kernel does).

@@ -1,5 +1,7 @@
 """Phase clocks of the matrix-core attention kernel (library built with -DGEAR_ATTN_CLK: a temporary instrumentation, not in the
-shipped build).  usage: python tools/exp_attn_clk.py"""
+shipped build).  usage: python tools/exp_attn_clk.py
+Build first:  touch gear_amd/csrc/attention.hip && make -C gear_amd/csrc EXTRA="-DGEAR_ATTN_CLK"   (then touch it again and
+`python -c "from gear_amd import _lib; _lib.build()"` to return to the shipped library: the clocks are compiled out of it)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

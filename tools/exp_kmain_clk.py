@@ -1,4 +1,6 @@
-"""Phase clocks of k_main_kernel (library built with GEAR_KF_CLK: temporary instrumentation).  usage: python tools/exp_kmain_clk.py"""
+"""Phase clocks of k_main_kernel (library built with GEAR_KF_CLK: temporary instrumentation).  usage: python tools/exp_kmain_clk.py
+Build first:  touch gear_amd/csrc/kfused.hip && make -C gear_amd/csrc EXTRA="-DGEAR_KF_CLK=1"   (then touch it again and
+`python -c "from gear_amd import _lib; _lib.build()"` to return to the shipped library: the clocks are compiled out of it)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
