@@ -84,17 +84,22 @@ def run(variant, args, dev):
     if variant == "gearl" and args.fast:
         from gear_amd.fast_decode import FastGearDecoder
         out = FastGearDecoder(model, args.max_length + 8, batch=args.batch_size).generate(ids, args.max_length)
+    elif variant == "None" and args.fast:
+        # the control through the SAME decoder (fused GEMVs, gear_attn_decode_f16 over cache.Fp16KVCache): gearl and None then
+        # differ in the cache only
+        from gear_amd.fast_decode import FastGearDecoder
+        out = FastGearDecoder(model, args.max_length + 8, batch=args.batch_size, cache_kind="fp16").generate(ids, args.max_length)
     else:
         out = model.generate(ids, args.max_length)
     torch.cuda.synchronize()
     dt = time.time() - t0
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 20
     new = (out.shape[1] - args.prompt_len) * args.batch_size
-    print(f"[{variant}{' (fast path)' if variant == 'gearl' and args.fast else ''}] Peak memory usage on GPU: {peak:.1f} MB")
+    print(f"[{variant}{' (fast path)' if variant in ('gearl', 'None') and args.fast else ''}] Peak memory usage on GPU: {peak:.1f} MB")
     print(f"[{variant}] time {dt:.3f}   ({new / dt:.1f} new tokens/s, batch {args.batch_size}, prompt {args.prompt_len} -> {out.shape[1]})")
     del model
     torch.cuda.empty_cache()
-    return dict(variant=variant, fast=bool(args.fast and variant == "gearl"), batch_size=args.batch_size, prompt_len=args.prompt_len,
+    return dict(variant=variant, fast=bool(args.fast and variant in ("gearl", "None")), batch_size=args.batch_size, prompt_len=args.prompt_len,
                 max_length=int(out.shape[1]), time_s=dt, new_tokens_per_s=new / dt, peak_mem_MiB=peak, layers=args.layers)
 
 

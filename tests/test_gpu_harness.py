@@ -35,3 +35,10 @@ def test_harness_runs_all_variants():
 def test_harness_fast_path_with_outliers():
     res, _ = _run("--model", "gearl", "--fast", "--left", "0.02", "--compress_method", "gearslKIVI", "--rank", "4")
     assert len(res) == 1 and res[0]["fast"] and res[0]["max_length"] == 330 and res[0]["new_tokens_per_s"] > 0
+
+
+def test_harness_control_through_the_fast_decoder():
+    """--model None --fast: the uncompressed control through the SAME decoder as the GEAR fast path (cache.Fp16KVCache,
+    gear_attn_decode_f16), so that the harness's variants differ in the cache only."""
+    res, _ = _run("--model", "None", "--fast")
+    assert len(res) == 1 and res[0]["variant"] == "None" and res[0]["fast"] and res[0]["max_length"] == 330 and res[0]["new_tokens_per_s"] > 0
