@@ -21,7 +21,6 @@ from typing import Optional, Tuple
 
 import torch
 import torch.nn.functional as F
-from torch import nn
 
 from .modeling_llamagear import (LlamaAttention_GEAR, LlamaConfigLite, LlamaForCausalLM_GEARKIVI, _append, _rep,
                                  apply_rotary_pos_emb)

@@ -12,7 +12,6 @@ the prompt is synthetic token ids, which does not change the timing of a greedy 
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
