@@ -640,16 +640,20 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
     __shared__ float vsp[AD];        // V outliers through the sparse tiles: sum of p[t] (value - dequant) per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x;
-    // grid (chunks, heads of a batch entry -- query heads, or KV heads when a workgroup serves a group --, batch): no division
+    // grid (heads of a batch entry -- query heads, or KV heads when a workgroup serves a group --, chunks, batch): no division, and
+    // the HEAD is the fastest dimension: workgroup i runs on XCD i % 8, so with a multiple of 8 heads every chunk of a head runs on
+    // ONE XCD and the sectors its chunks share meet in one L2 -- a K code row's 32 bytes per chunk are half a 64-byte sector, a K
+    // scale / zero-point sector serves 8 chunks, the channel factors every chunk.  PMC at batch 16 (7B layer, 276 MB of payload):
+    // FETCH_SIZE 674 MB with the chunk fastest (2.4 x, at 4.8 TB/s: the kernel was bound by its own re-fetches) -> see DESIGN section 6
+    const int split = blockIdx.y;
     const int b = blockIdx.z;
     int hkv;
     int64_t bhq0;                      // first (NREP == 1: the only) query head of this workgroup
     if (NREP == 1) {
-        hkv = (int)div_sh(blockIdx.y, a.Hq / max(a.Hkv, 1), a.nrep_shift);
-        bhq0 = (int64_t)b * a.Hq + blockIdx.y;
+        hkv = (int)div_sh(blockIdx.x, a.Hq / max(a.Hkv, 1), a.nrep_shift);
+        bhq0 = (int64_t)b * a.Hq + blockIdx.x;
     } else {
-        hkv = (int)blockIdx.y;
+        hkv = (int)blockIdx.x;
         bhq0 = (int64_t)b * a.Hq + (int64_t)hkv * NREP;
     }
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
@@ -1102,7 +1106,7 @@ __device__ __forceinline__ void mt_operands(const uint16_t* tile, int I, int lan
 // (`make -C gear_amd/csrc CXXFLAGS+=-DGEAR_ATTN_CLK`); thread 0 of the first 8192 workgroups stores s_memtime at the phase boundaries.
 #ifdef GEAR_ATTN_CLK
 __device__ unsigned long long attn_clk_buf[8 * 8192];
-#define ATTN_CLK(k) do { if (tid == 0) { const unsigned bid_ = blockIdx.y * gridDim.x + blockIdx.x; if (bid_ < 8192) attn_clk_buf[bid_ * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#define ATTN_CLK(k) do { if (tid == 0) { const unsigned bid_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (bid_ < 8192) attn_clk_buf[bid_ * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define ATTN_CLK(k) do { } while (0)
 #endif
@@ -1134,16 +1138,16 @@ __global__ __launch_bounds__(256) void attn_decode_partial_mfma(AttnArgs a) {
     __shared__ float mlh[NREP][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x;
-    int b, hkv;
+    // grid (heads of a batch entry, chunks, batch), the head fastest: all chunks of a head on one XCD (see the vector kernel)
+    const int split = blockIdx.y;
+    const int b = blockIdx.z;
+    int hkv;
     int64_t bhq0;
     if (NREP == 1) {
-        bhq0 = blockIdx.y;
-        b = (int)(bhq0 / a.Hq);
-        hkv = (int)(bhq0 % a.Hq) / (a.Hq / a.Hkv);
+        hkv = (int)div_sh(blockIdx.x, a.Hq / max(a.Hkv, 1), a.nrep_shift);
+        bhq0 = (int64_t)b * a.Hq + blockIdx.x;
     } else {
-        b = (int)blockIdx.y / a.Hkv;
-        hkv = (int)blockIdx.y % a.Hkv;
+        hkv = (int)blockIdx.x;
         bhq0 = (int64_t)b * a.Hq + (int64_t)hkv * NREP;
     }
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
@@ -1787,7 +1791,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         const int gq = gear_options().attn_gqa_group;
         const bool group_on = gq > 0 || (gq < 0 && (int64_t)B * Hq * a.splits >= 32768);
         const int nrep_t = (small && group_on && (n_rep == 2 || n_rep == 4 || n_rep == 8)) ? n_rep : 1;
-        const dim3 gridg(a.pslots, (unsigned)Hkv, (unsigned)B), grids(a.pslots, (unsigned)Hq, (unsigned)B);
+        const dim3 gridg((unsigned)Hkv, a.pslots, (unsigned)B), grids((unsigned)Hq, a.pslots, (unsigned)B);
 #define GOS(BI, STT, RSV)                                                                                                  \
     do {                                                                                                                   \
         if (nrep_t == 8) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 8>), gridg, dim3(256), 0, st, a);      \
@@ -1804,7 +1808,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         const int mfo = gear_options().attn_mfma;
         const bool mf = small && group == 64 && mfo >= 0 && a.pslots == a.splits && (a.kk == 0 || a.ktile) && (a.kv == 0 || a.vtile) &&
                         (mfo > 0 || (nrep_m > 1 && (int64_t)B * Hkv * a.splits >= 256));
-        const dim3 gridm(a.pslots, (unsigned)(nrep_m > 1 ? B * Hkv : B * Hq));
+        const dim3 gridm((unsigned)(nrep_m > 1 ? Hkv : Hq), a.pslots, (unsigned)B);
 #define GOM(BI, STT, RSV)                                                                                                  \
     do {                                                                                                                   \
         if (nrep_m == 8) hipLaunchKernelGGL((attn_decode_partial_mfma<BI, STT, RSV, 8>), gridm, dim3(256), 0, st, a);       \
