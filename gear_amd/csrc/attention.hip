@@ -1772,10 +1772,23 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     const bool r16 = !r8 && (a.rk == 0 || a.rk == 16) && (a.rv == 0 || a.rv == 16);
     const bool r4 = !r8 && !r16 && (a.rk == 0 || a.rk == 4) && (a.rv == 0 || a.rv == 4);     // (BASELINE configs[1]: rank 4)
     a.splits = plan_splits(T, bits, (int64_t)B * Hq, r8 || r16 || r4, &a.tc, &small);
-    // the fp16 window: the reduce kernel's job (default), or -- option attn_win_chunk, short-chunk kernel -- one more chunk of the
-    // split (its own workgroup per KV head / query head in the same launch; the reduce kernel then only merges: measured 22.3
-    // against 21.1 us per layer at batch 1, the window workgroup is the launch's longest)
-    const bool win_chunk = small && (T > 0 || dyn_state) && kwin && vwin && (W > 0 || dyn_state) && gear_options().attn_win_chunk;
+    // matrix-core variant of the short-chunk kernel (see attn_decode_partial_mfma): group 64, no outliers or outliers through sparse
+    // tiles.  Measured (profiles/r5_attn_experiments.md): 1.3 - 2.5 x faster than one workgroup per query head for grouped-query
+    // shapes once the launch has a workgroup per CU; slower for multi-head attention (one query head per KV head: the vector kernel's
+    // work is not repeated there) and for a single KV head at batch 1.  attn_mfma: 0 = by that rule, 1 = whenever it applies,
+    // -1 = never.
+    const int n_rep = Hq / Hkv;
+    const int nrep_m = (n_rep == 2 || n_rep == 4 || n_rep == 8) ? n_rep : 1;
+    const int mfo = gear_options().attn_mfma;
+    const bool mf_shape = small && group == 64 && mfo >= 0 && (a.kk == 0 || a.ktile) && (a.kv == 0 || a.vtile) &&
+                          (mfo > 0 || (nrep_m > 1 && (int64_t)B * Hkv * a.splits >= 256));
+    // the fp16 window: one more chunk of the split on the vector short-chunk kernel (its own workgroup per query head in the same
+    // launch; the reduce kernel then only merges) -- with every chunk of a head on one XCD this is the faster arrangement (one layer
+    // at batch 1, caches rotated: 21.0 -> 20.0 us; 7B decode 326 -> 335 tok/s graph-replayed; before the XCD mapping it measured 1 us
+    // SLOWER) --, the reduce kernel's job under the matrix-core kernel and the long-context kernel.  attn_win_chunk: 0 = that rule,
+    // 1 = whenever the short-chunk kernel runs (the matrix-core kernel then does not), -1 = never.
+    const int wco = gear_options().attn_win_chunk;
+    const bool win_chunk = small && (T > 0 || dyn_state) && kwin && vwin && (W > 0 || dyn_state) && (wco > 0 || (wco == 0 && !mf_shape));
     a.pslots = a.splits + (win_chunk ? 1 : 0);
     a.kwin = (const uint16_t*)kwin; a.vwin = (const uint16_t*)vwin; a.W = W; a.wcap = wcap;
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1787,7 +1800,6 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         dim3 grid(a.pslots, (unsigned)(B * Hq));
         // grouped-query attention on the short-chunk kernel: option attn_gqa_group = 1: one workgroup per (chunk, KV head) serves the
         // group's 2 / 4 / 8 query heads; default: one workgroup per query head (see common.h for the measurement)
-        const int n_rep = Hq / Hkv;
         const int gq = gear_options().attn_gqa_group;
         const bool group_on = gq > 0 || (gq < 0 && (int64_t)B * Hq * a.splits >= 32768);
         const int nrep_t = (small && group_on && (n_rep == 2 || n_rep == 4 || n_rep == 8)) ? n_rep : 1;
@@ -1799,15 +1811,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         else if (nrep_t == 2) hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 2>), gridg, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 1>), grids, dim3(256), 0, st, a);                  \
     } while (0)
-        // matrix-core variant (see attn_decode_partial_mfma): group 64, no outliers or outliers through sparse tiles
-        // Measured (profiles/r5_attn_experiments.md): 1.3 - 1.65 x faster than one workgroup per query head for grouped-query shapes
-        // once the launch has a workgroup per CU; slower for multi-head attention (one query head per KV head: the vector kernel's
-        // work is not repeated there) and for a single KV head at batch 1.  attn_mfma: 0 = by that rule, 1 = whenever it applies,
-        // -1 = never.
-        const int nrep_m = (n_rep == 2 || n_rep == 4 || n_rep == 8) ? n_rep : 1;
-        const int mfo = gear_options().attn_mfma;
-        const bool mf = small && group == 64 && mfo >= 0 && a.pslots == a.splits && (a.kk == 0 || a.ktile) && (a.kv == 0 || a.vtile) &&
-                        (mfo > 0 || (nrep_m > 1 && (int64_t)B * Hkv * a.splits >= 256));
+        const bool mf = mf_shape && a.pslots == a.splits;
         const dim3 gridm((unsigned)(nrep_m > 1 ? Hkv : Hq), a.pslots, (unsigned)B);
 #define GOM(BI, STT, RSV)                                                                                                  \
     do {                                                                                                                   \

@@ -51,8 +51,9 @@ struct GearOptions {
     int attn_mfma;         // decode attention, matrix-core variant of the short-chunk kernel: 0 = for grouped-query shapes with a
                            // workgroup per CU (measured faster there), 1 = whenever it applies (tests, A/B runs), -1 = never
     int attn_keep_chunk_index;  // decode attention over a cache with sparse tiles: also load the outlier chunk indices (round 4)
-    int attn_win_chunk;    // decode attention: the fp16 window as one more chunk of the split (measured 1 us slower at batch 1 than the
-                           // window inside the reduce kernel, the default)
+    int attn_win_chunk;    // decode attention: the fp16 window as one more chunk of the split: 0 = when the vector short-chunk kernel runs
+                           // (faster since every chunk of a head runs on one XCD: 21.0 -> 20.0 us per layer at batch 1), 1 = whenever
+                           // the short-chunk kernel runs, -1 = never (the window inside the reduce kernel: rounds 1 - 4)
 };
 GearOptions& gear_options();
 

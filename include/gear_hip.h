@@ -46,7 +46,7 @@ int gear_abi_version(void);
  * paths ordinary inputs do not).  Names: "attn_generic", "lowrank_generic", "rows_hist_only", "rows_wg_only", "rows_v1",
  * "kfused_generic", "kselect_slow", "kfused_no_tr", "gram_fused", "gram_nstg", "decomp_general", "kfused_nslab", and for the decode
  * attention "attn_gqa_group" (one workgroup per KV head serves its 2 / 4 / 8 query heads), "attn_win_chunk" (fp16 window as one more
- * chunk of the split), "attn_keep_chunk_index", "attn_mfma" (the matrix-core variant of the short-chunk kernel: 0 = for grouped-query
+ * chunk of the split: 0 = on the vector short-chunk kernel, 1 = always, -1 = never), "attn_keep_chunk_index", "attn_mfma" (the matrix-core variant of the short-chunk kernel: 0 = for grouped-query
  * shapes, 1 = always, -1 = never) -- measured alternatives of round 5, all off / automatic by default (gear_amd/csrc/common.h says
  * what each measured).  Each is also read once from the environment (GEAR_<NAME>) when the library is first used.  Returns 0, or -1
  * for an unknown name. */

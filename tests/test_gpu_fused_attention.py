@@ -188,9 +188,10 @@ def test_fp16_cache_attention_baseline(B, Hq, Hkv, T, tcap):
 
 @pytest.mark.parametrize("Hq,Hkv,T,W,rank,k_out", [(4, 4, 512, 1, 8, 4), (4, 2, 1024, 64, 8, 0), (8, 1, 384, 100, 16, 6), (2, 2, 4096, 37, 0, 0)])
 def test_window_as_one_more_chunk_equals_window_in_the_reduce_kernel(Hq, Hkv, T, W, rank, k_out):
-    """Round 5 (option attn_win_chunk): the fp16 window as one more chunk of the short-chunk kernel's split (its own workgroup in the
-    same launch), the reduce kernel only merges; default = window scores and values inside the reduce kernel (measured faster).
-    Same softmax, merged in a different order: equal to fp32 rounding."""
+    """Option attn_win_chunk: the fp16 window as one more chunk of the short-chunk kernel's split (its own workgroup in the same
+    launch; the reduce kernel only merges: 1 = always, 0 = when the vector short-chunk kernel runs -- the default since the head
+    became the fastest grid dimension) against -1 = window scores and values inside the reduce kernel (rounds 1 - 4).  Same softmax,
+    merged in a different order: equal to fp32 rounding."""
     from gear_amd import _lib as L
     from gear_amd import compress as C
     from gear_amd.attention import decode_attention
@@ -202,12 +203,15 @@ def test_window_as_one_more_chunk_equals_window_in_the_reduce_kernel(Hq, Hkv, T,
     kw, vw = torch.randn(B, Hkv, W, D).half().cuda(), torch.randn(B, Hkv, W, D).half().cuda()
     pk = C.compress_key(k, 2, 64, k_out=k_out, rank=rank, loop=3, mode="fp32")
     pv = C.compress_value(v, 2, 64, k_out=k_out, rank=rank, loop=3, mode="fp32")
-    out_r, lse_r = decode_attention(q, pk, pv, kw, vw, return_lse=True)
-    L.set_option("attn_win_chunk", 1)
+    L.set_option("attn_win_chunk", -1)
     try:
+        out_r, lse_r = decode_attention(q, pk, pv, kw, vw, return_lse=True)
+        L.set_option("attn_win_chunk", 1)
         out_c, lse_c = decode_attention(q, pk, pv, kw, vw, return_lse=True)
     finally:
         L.set_option("attn_win_chunk", 0)
+    out_d, lse_d = decode_attention(q, pk, pv, kw, vw, return_lse=True)          # the default rule takes one of the two
+    assert rel_fro(host(out_d).astype(np.float64), host(out_r).astype(np.float64)) < 5e-4 and torch.allclose(lse_d, lse_r, rtol=0, atol=1e-4)
     assert rel_fro(host(out_c).astype(np.float64), host(out_r).astype(np.float64)) < 5e-4      # (one fp16 rounding of the output)
     assert torch.allclose(lse_c, lse_r, rtol=0, atol=1e-4)
     ref = ref_attention(host(q), reconstruct(pk), reconstruct(pv), host(kw), host(vw), Hq // Hkv)
