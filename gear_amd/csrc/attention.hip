@@ -100,6 +100,22 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// the same without the leading barrier: for a `red` array nobody can still be reading (its first use in a pass, or a second array)
+__device__ __forceinline__ float block_reduce_max_nb(float v, float* red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float block_reduce_sum_nb(float v, float* red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
 // first index i in [0, n) with a[i] >= key (a ascending)
 __device__ __forceinline__ int lower_bound_u16(const uint16_t* a, int n, int key) {
     int lo = 0, hi = n;
@@ -521,10 +537,10 @@ __device__ __forceinline__ void f16_chunk(const AttnArgs& a, const uint16_t* __r
         }
         __syncthreads();
         const float sv = tid < tn ? s[min(tid, SC - 1)] : -INFINITY;
-        const float m = block_reduce_max(sv, red);
+        const float m = block_reduce_max_nb(sv, red);           // (red: 8 floats -- maximum and sum have their own four, no leading barriers)
         const float p = tid < tn ? __expf(sv - m) : 0.0f;
         if (tid < SC) s[tid] = p;
-        const float l = block_reduce_sum(p, red);      // (contains the barrier that publishes s[])
+        const float l = block_reduce_sum_nb(p, red + 4);        // (contains the barrier that publishes s[])
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) acc[c] = 0.0f;
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
     __shared__ float ot[2][AD];      // Pv[seg(slab)] (Qv^T p)_slab
     __shared__ float oacc[AD];
     __shared__ float wsl[2][RW];      // Qv^T p of the two slabs
-    __shared__ float red[4];
+    __shared__ float red[8];         // [0..3]: chunk maximum per wave, [4..7]: exponent sum per wave
     __shared__ float ksp[SC];        // K outliers through the sparse tile: sum of q[d] (value - dequant) per token
     __shared__ float vsp[AD];        // V outliers through the sparse tiles: sum of p[t] (value - dequant) per channel
 
@@ -905,10 +921,12 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
         if (tid < SC) sv = s[tid];
     }
     // ------------------------------------------------------------------ 2. chunk softmax statistics
-    const float m = block_reduce_max(sv, red);
+    // (two arrays and no leading barriers: red[0..3] was last read before the previous barrier of this pass, red[4..7] before the
+    // loop-top barrier of the previous head -- two workgroup barriers fewer on the chunk's critical path)
+    const float m = block_reduce_max_nb(sv, red);
     const float p = tid < tn ? __expf(sv - m) : 0.0f;
     if (tid < SC) s[tid] = p;
-    const float l = block_reduce_sum(p, red);   // (contains the barrier that publishes s[])
+    const float l = block_reduce_sum_nb(p, red + 4);   // (contains the barrier that publishes s[])
     // ------------------------------------------------------------------ 3. V side
     if (vtile_ok) {   // block tiles: vsp[d] += p[t] * (value - dequant); read after the barriers of the dense part below
         const int vc_n0 = vc_raw0, vc_n1 = (tn > 64) ? vc_raw1 : 0;
@@ -1855,7 +1873,7 @@ __global__ __launch_bounds__(256) void attn_f16_partial_kernel(AttnArgs a, const
                                                                const uint16_t* __restrict__ v, int tcap) {
     __shared__ float s[SC];
     __shared__ float op[4][AD];
-    __shared__ float red[4];
+    __shared__ float red[8];
     const int split = blockIdx.x;
     int b, hkv;
     int64_t bhq0;
