@@ -216,6 +216,37 @@ def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank:
     return Payload("v", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
 
 
+def compress_value_fused(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3, mode="fp32",
+                         P0: Optional[torch.Tensor] = None) -> Payload:
+    """V [B,H,T,128] fp16 -> Payload through ONE gear_compress_value_fused call (csrc/kfused.hip: the chain the streaming cache
+    and bench.py run -- row compressor writing the cache geometry, Gram, per-head solve, Q pass) with tcap = T, t_off = 0, so
+    the cache tensors ARE the payload tensors.  Same result as compress_value (which drives the leaf entry points one by one)."""
+    assert v.dim() == 4 and v.dtype == torch.float16
+    v = v.contiguous()
+    L.require_gpu(v)
+    B, H, T, D = v.shape
+    assert D == 128, "gear_compress_value_fused: head_dim 128"
+    m = _MODES[mode]
+    dev = v.device
+    code, scale, mn, oidx, oval = _alloc_rows(v.shape, B * T, group, bits, m, k_out, dev)
+    P = Q = None
+    if rank > 0:
+        if P0 is None:
+            P0 = draw_p0(B, H, T, D, rank, dev)
+        P0 = P0.to(device=dev, dtype=torch.float32).contiguous()
+        P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
+        Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
+    lib = L.load()
+    ws = _workspace(lib.gear_compress_value_fused_workspace(B, H, T, rank), dev)
+    rc = lib.gear_compress_value_fused(L.ptr(v), B, H, T, group, bits, m, k_out, L.ptr(code), L.ptr(scale), L.ptr(mn), T, 0, rank,
+                                       loop, L.ptr(P0) if rank > 0 else None, L.ptr(P), B * H, 0, L.ptr(Q), T, 0, L.ptr(oidx),
+                                       L.ptr(oval), L.ptr(ws), ws.numel(), L.stream_ptr(v))
+    L.check(rc, "gear_compress_value_fused")
+    if oidx is not None:
+        oidx, oval = oidx.view(B, T, 2 * k_out), oval.view(B, T, 2 * k_out)
+    return Payload("v", (B, H, T, D), bits, group, m, code, scale, mn, P, Q, oidx, oval, k_out)
+
+
 def key_fused_supported(T: int, D: int, group: int, bits: int, k_out: int) -> bool:
     """Shapes the fused token-major K path (gear_compress_key_fused) covers; everything else takes the row compressor."""
     return D == 128 and T % 64 == 0 and 64 <= T <= 16384 and group in (32, 64) and bits in (2, 4) and 2 * k_out <= T
