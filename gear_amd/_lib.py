@@ -73,6 +73,8 @@ SIGNATURES = {
     "gear_compress_block_workspace": (_sz, [_i64, _i]),
     "gear_compress_block": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
     "gear_compress_block_status_ptr": (_vp, [_vp]),
+    "gear_kone_timeouts": (_i, []),
+    "gear_kone_fallback_heads": (_i, []),
     "gear_xchg_bytes": (_sz, [_i, _sz]),
     "gear_xchg_alloc": (_i, [_sz, C.POINTER(_vp)]),
     "gear_xchg_free": (_i, [_vp]),

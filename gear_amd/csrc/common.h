@@ -48,6 +48,8 @@ struct GearOptions {
                            // loaded once); 0 = one workgroup per query head (default: measured 2 - 3 x faster up to batch 4, profiles/
                            // r5_attn_experiments.md -- the repeated reads hit L2 and the chip wants the parallelism); -1 = by launch size
     int kfused_nslab;      // fused K path: slabs per head of k_main_kernel (0 = by head count)
+    int kfused_one;        // fused K path, fp32 arithmetic: the single-read kernel (kone.hip: selection + dense part + Gram in one launch):
+                           // 1 = wherever its plan fits; 0 / -1 = never (select + main as two kernels: faster, profiles/r6_kone.md)
     int attn_mfma;         // decode attention, matrix-core variant of the short-chunk kernel: 0 = for grouped-query shapes with a
                            // workgroup per CU (measured faster there), 1 = whenever it applies (tests, A/B runs), -1 = never
     int attn_keep_chunk_index;  // decode attention over a cache with sparse tiles: also load the outlier chunk indices (round 4)

@@ -47,6 +47,14 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
                             int64_t o_seg_stride, int o_list_outer, int group, int bits, int mode, int k, void* code,
                             void* scale, void* mn, void* err, void* oidx, void* oval, void* omean, void* stream);
 
+// kone.hip: selection + dense part + Gram in ONE launch with one read of K (fp32 arithmetic, shapes it plans for)
+bool gear_kone_supported(int64_t BH, int T, int group, int bits, int mode, int k);
+size_t gear_kone_workspace(int64_t BH, int T, int k);
+const uint32_t* gear_kone_headfail(void* ws, int64_t BH, int T, int k);
+int gear_kone_launch(const void* x, int64_t BH, int T, int group, int bits, int k, void* code, void* scale, void* mn, int64_t ldc,
+                     int64_t lds, int t_off, void* obits, void* oidx, void* oval, int kcap, int o_off, float* G, void* ws,
+                     hipStream_t st);
+
 namespace {
 
 
@@ -90,6 +98,7 @@ struct SelArgs {
     int kcap, o_off, tok_base;
     uint32_t* todo_cnt;     // lists the candidate path could not decide (count outside [k, KS_CAP]): handled by k_select_fix_kernel
     uint32_t* todo;         // [BH * 256] entries (bh * 128 + channel) * 2 + side
+    const uint32_t* only_if; // null, or [BH] words: heads whose word is 0 are skipped (the exact chain behind kone.hip)
 };
 
 __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
@@ -105,6 +114,7 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     int q;
     int64_t bh;
     select_block_map((int)blockIdx.x, a.BH, q, bh);
+    if (a.only_if && a.only_if[bh] == 0u) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c2 = lane & 15, ts = lane >> 4, s = wave * 4 + ts;      // channel pair in the quarter, stream id (16 streams)
     const int T = a.T, k = a.k;
@@ -503,6 +513,7 @@ struct MainArgs {
     int64_t ldc, lds;
     int t_off;               // token offset of this call inside the payload rows (multiple of 64)
     float* gpart;            // [BH][nslab][128][128] partial Gram matrices (blocks on / above the block diagonal), or null
+    const uint32_t* only_if; // null, or [BH] words: heads whose word is 0 are skipped
 };
 
 // Mode-1 (fp32 simulated arithmetic) tile on packed registers: everything that is exact in fp16 stays packed (min / max
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slab = blockIdx.x;
     const int64_t bh = blockIdx.y;
+    if (a.only_if && a.only_if[bh] == 0u) return;
     const int T = a.T, ntiles = T >> 6;
     uint16_t* etiles = (uint16_t*)smem;                         // [4][64][ET_PITCH]
     uint16_t* etile = etiles + wave * 64 * ET_PITCH;            // this wave's error tile
@@ -796,11 +808,13 @@ __global__ __launch_bounds__(256, 2) void k_main_kernel(MainArgs a) {
 // ================================================================================================ solve
 // grid (BH): G = sum of the slabs' partial Gram matrices, then the solve of lowrank_solve.h.
 // P_out head bh lives at (bh / p_inner) * p_outer_stride + (bh % p_inner) * 128 * r elements.
+// upper: the matrices hold the 32x32 blocks on and above the block diagonal only (kone.hip adds nothing else): an element below is
+// read from its mirror image -- G[e][d], contiguous over the threads of a wave like the direct read.
 template <int RP>
 __global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict__ gpart, int nslab, int loop,
                                                          const float* __restrict__ P0, int r, float* __restrict__ Wout,
                                                          void* __restrict__ P_out, int out_f16, int64_t p_inner,
-                                                         int64_t p_outer_stride) {
+                                                         int64_t p_outer_stride, int upper) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Pa = (float*)smem;
     float* Pb = Pa + GS_GD * RP;
@@ -816,14 +830,26 @@ __global__ __launch_bounds__(256, 2) void k_solve_kernel(const float* __restrict
         const int d = tid >> 1, h = tid & 1;
 #pragma unroll
         for (int i = 0; i < 64; i++) greg[i] = 0.0f;
-        for (int s = 0; s < nslab; s++) {
-            const float4* r0 = (const float4*)(gp + s * (int64_t)(KD * KD) + d * KD + 32 * h);
-            const float4* r1 = r0 + 16;                       // + 64 columns
+        if (upper) {
+            const int dlow = d & ~31;
+            for (int s = 0; s < nslab; s++) {
+                const float* g = gp + s * (int64_t)(KD * KD);
 #pragma unroll
-            for (int v = 0; v < 8; v++) {
-                const float4 a = r0[v], b = r1[v];
-                greg[4 * v] += a.x; greg[4 * v + 1] += a.y; greg[4 * v + 2] += a.z; greg[4 * v + 3] += a.w;
-                greg[32 + 4 * v] += b.x; greg[32 + 4 * v + 1] += b.y; greg[32 + 4 * v + 2] += b.z; greg[32 + 4 * v + 3] += b.w;
+                for (int i = 0; i < 64; i++) {
+                    const int e = (i & 31) + 64 * (i >> 5) + 32 * h;
+                    greg[i] += (e < dlow) ? g[e * KD + d] : g[d * KD + e];
+                }
+            }
+        } else {
+            for (int s = 0; s < nslab; s++) {
+                const float4* r0 = (const float4*)(gp + s * (int64_t)(KD * KD) + d * KD + 32 * h);
+                const float4* r1 = r0 + 16;                       // + 64 columns
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    const float4 a = r0[v], b = r1[v];
+                    greg[4 * v] += a.x; greg[4 * v + 1] += a.y; greg[4 * v + 2] += a.z; greg[4 * v + 3] += a.w;
+                    greg[32 + 4 * v] += b.x; greg[32 + 4 * v + 1] += b.y; greg[32 + 4 * v + 2] += b.z; greg[32 + 4 * v + 3] += b.w;
+                }
             }
         }
     }
@@ -1041,10 +1067,11 @@ double inv_norm_cdf(double p) {  // Acklam's rational approximation (relative er
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KfWs {       // workspace carve-up
-    size_t obits, omean, gpart, W, todo, total;
+    size_t obits, omean, gpart, W, todo, kone, total;
     int nslab, tiles_per_slab;
 };
-KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
+// one: the single-read kernel (kone.hip) does selection + dense part + Gram; its Gram matrix is ONE matrix per head
+KfWs kf_workspace(int64_t BH, int T, int k, int rank, bool one = false) {
     KfWs w;
     const int ntiles = T / 64;
     // slabs: enough workgroups to fill the chip (>= ~2 per CU) without drowning the solve in partial Gram traffic
@@ -1054,6 +1081,7 @@ KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
         nslab = gear_options().kfused_nslab;
         while (nslab > 1 && ntiles / nslab < 4) nslab /= 2;
     }
+    if (one) nslab = 1;
     w.nslab = nslab;
     w.tiles_per_slab = (ntiles + nslab - 1) / nslab;
     const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
@@ -1063,6 +1091,7 @@ KfWs kf_workspace(int64_t BH, int T, int k, int rank) {
     w.gpart = off; off += align256(rank > 0 ? (size_t)BH * nslab * KD * KD * 4 : 0);
     w.W = off;     off += align256(rank > 0 ? (size_t)BH * KD * RP * 4 : 0);
     w.todo = off;  off += align256(k > 0 ? 256 + (size_t)BH * 256 * 4 : 0);   // counter (first 256 bytes) + list ids
+    w.kone = off;  off += align256(one ? gear_kone_workspace(BH, T, k) : 0);
     w.total = off + 256;
     return w;
 }
@@ -1100,8 +1129,8 @@ extern "C" int gear_debug_kf_clk(unsigned long long* out) {
 
 // The per-head solve on partial Gram matrices, for callers outside this file (lowrank_gram.hip: the V-side / K^T Gram kernels
 // hand over [BH][nslab][128][128] complete (mirrored) matrices exactly as k_main_kernel does).
-int gear_ksolve_launch(const float* gpart, int nslab, int loop, const float* P0, int r, int64_t BH, float* Wout, void* P_out,
-                       int out_f16, int64_t p_inner, int64_t p_outer_stride, hipStream_t st) {
+static int ksolve_launch(const float* gpart, int nslab, int loop, const float* P0, int r, int64_t BH, float* Wout, void* P_out,
+                         int out_f16, int64_t p_inner, int64_t p_outer_stride, int upper, hipStream_t st) {
     const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
     const size_t shmem = gram_solve_lds_bytes(RP) - (size_t)GS_GD * GS_GP * 4;      // no G in LDS: it lives in registers
 #define KF_SOLVE(RPV)                                                                                                    \
@@ -1109,16 +1138,22 @@ int gear_ksolve_launch(const float* gpart, int nslab, int loop, const float* P0,
         auto kfn = k_solve_kernel<RPV>;                                                                                  \
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);             \
         hipLaunchKernelGGL(kfn, dim3((unsigned)BH), dim3(256), shmem, st, gpart, nslab, loop, P0, r, Wout, P_out,        \
-                           out_f16, p_inner, p_outer_stride);                                                            \
+                           out_f16, p_inner, p_outer_stride, upper);                                                     \
     } while (0)
     if (RP == 4) KF_SOLVE(4); else if (RP == 8) KF_SOLVE(8); else KF_SOLVE(16);
 #undef KF_SOLVE
     return 0;
 }
+int gear_ksolve_launch(const float* gpart, int nslab, int loop, const float* P0, int r, int64_t BH, float* Wout, void* P_out,
+                       int out_f16, int64_t p_inner, int64_t p_outer_stride, hipStream_t st) {
+    return ksolve_launch(gpart, nslab, loop, P0, r, BH, Wout, P_out, out_f16, p_inner, p_outer_stride, 0, st);
+}
 
 extern "C" size_t gear_compress_key_fused_workspace(int64_t BH, int T, int k, int rank) {
     if (BH <= 0 || T <= 0 || T % 64) return 0;
-    return kf_workspace(BH, T, k, rank).total;
+    const size_t a = kf_workspace(BH, T, k, rank).total;
+    const size_t b = gear_kone_workspace(BH, T, k) ? kf_workspace(BH, T, k, rank, true).total : 0;
+    return a > b ? a : b;
 }
 
 extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int group, int bits, int mode, int k, void* code,
@@ -1142,7 +1177,14 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         GEAR_CHECK_ARG(p_inner >= 1 && q_tcap >= q_toff + T, "gear_compress_key_fused: bad factor geometry");
     }
     if (k > 0) GEAR_CHECK_ARG(oidx && oval && kcap >= o_off + k && t_off + T <= 65536 && T <= 16384, "gear_compress_key_fused: bad outlier geometry");
-    const KfWs ws = kf_workspace(BH, T, k, rank);
+    // the single-read kernel (kone.hip) replaces select + main with option kfused_one = 1 wherever its plan fits.  It is NOT the
+    // default: measured 1.85 ms against the chain's 1.00 ms up to the Gram matrices at bench size (profiles/r6_kone.md: the LDS holds
+    // two slabs per CU for the ~50 us that three exchanges take).  Variant bits 8 / 32 (measurement hooks of the chain's kernels),
+    // 2 and 64 keep the chain
+    const int one_opt = gear_options().kfused_one;
+    const bool one = one_opt > 0 && !(variant & (8 | 32 | 64 | 2)) && !gear_options().kselect_slow && !gear_options().kfused_generic &&
+                     gear_kone_supported(BH, T, group, bits, mode, k);
+    const KfWs ws = kf_workspace(BH, T, k, rank, one);
     GEAR_CHECK_ARG(workspace_bytes >= ws.total, "gear_compress_key_fused: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1150,16 +1192,25 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     float* omean = k > 0 ? (float*)(base + ws.omean) : nullptr;
     float* gpart = rank > 0 ? (float*)(base + ws.gpart) : nullptr;
     float* Wws = rank > 0 ? (float*)(base + ws.W) : nullptr;
+    const uint32_t* only_if = nullptr;
+    if (one) {
+        const int rc = gear_kone_launch(x, BH, T, group, bits, k, code, scale, mn, ldc, lds, t_off, obits, oidx, oval, kcap, o_off, gpart,
+                                        base + ws.kone, st);
+        if (rc != 0) return rc;
+        if (k == 0) goto after_main;
+        only_if = gear_kone_headfail(base + ws.kone, BH, T, k);       // the chain below redoes the heads whose guess failed
+    }
 
     if (k > 0 && !(variant & 8)) {
         SelArgs sa;
         sa.x = (const uint16_t*)x; sa.BH = BH; sa.T = T; sa.k = k;
+        sa.only_if = only_if;
         // candidates per side and row: k + 5 sqrt(k) + 8 expected.  Measured on the 7B / 4k tensor (k = 40): a target of 56 / 64 /
         // 72 / 80 / 92 gives 542 / 591 / 598 / 610 / 628 us of select + 673 / 101 / 79 / 77 / 74 us of fix kernel (the guess is validated by the counts; lists hold KS_CAP)
         const double target = k + 5.0 * sqrt((double)k) + 8.0;
         double p = target / (double)T;
         if (p > 0.5) p = 0.5;
-        sa.zthr = (target > 0.6 * KS_CAP || (variant & 2) || gear_options().kselect_slow) ? 1e30f : (float)(-inv_norm_cdf(p));   // huge z: no candidates -> slow exact path
+        sa.zthr = (target > 0.6 * KS_CAP || (variant & 2) || gear_options().kselect_slow || one) ? 1e30f : (float)(-inv_norm_cdf(p));   // huge z: no candidates -> slow exact path
         sa.sstride = max(1, T / 1024);
         sa.rlen = 1.0f / (float)T;
         sa.obits = obits; sa.omean = omean; sa.oidx = (uint16_t*)oidx; sa.oval = (uint16_t*)oval;
@@ -1177,11 +1228,13 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(select fix)");
         if (variant & 32) return 0;
     }
+    {
     MainArgs ma;
     ma.x = (const uint16_t*)x; ma.obits = obits; ma.omean = omean; ma.T = T;
     ma.tiles_per_slab = ws.tiles_per_slab; ma.nslab = ws.nslab;
     ma.code = (uint32_t*)code; ma.scale = scale; ma.mn = mn; ma.ldc = ldc; ma.lds = lds; ma.t_off = t_off;
     ma.gpart = gpart;                        // no error matrix in HBM: the Q pass rebuilds it (k_qpass_kernel)
+    ma.only_if = only_if;
     const bool fast = (variant & 1) == 0 && !gear_options().kfused_generic, lr = rank > 0;
     const bool tr = (variant & 4) == 0 && !gear_options().kfused_no_tr;
 #define KF_DISPATCH(B, M, GG, STT) launch_main<B, M, GG, STT>(ma, BH, fast, lr, tr, st)
@@ -1194,10 +1247,12 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     }
 #undef KF_DISPATCH
     GEAR_CHECK_LAUNCH("gear_compress_key_fused(main)");
+    }
+after_main:
     if (variant & 16) return 0;
     if (rank > 0) {
         const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
-        gear_ksolve_launch(gpart, ws.nslab, loop, (const float*)P0, rank, BH, Wws, P_out, 1, p_inner, p_outer_stride, st);
+        ksolve_launch(gpart, ws.nslab, loop, (const float*)P0, rank, BH, Wws, P_out, 1, p_inner, p_outer_stride, one ? 1 : 0, st);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
         QpArgs qa;
         qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T;

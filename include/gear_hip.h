@@ -44,7 +44,8 @@ const char* gear_last_error(void);
 int gear_abi_version(void);
 /* Run-time options: switches that select an alternative, equally exact code path (used by the tests to reach the
  * paths ordinary inputs do not).  Names: "attn_generic", "lowrank_generic", "rows_hist_only", "rows_wg_only", "rows_v1",
- * "kfused_generic", "kselect_slow", "kfused_no_tr", "gram_fused", "gram_nstg", "decomp_general", "kfused_nslab", and for the decode
+ * "kfused_generic", "kselect_slow", "kfused_no_tr", "gram_fused", "gram_nstg", "decomp_general", "kfused_nslab", "kfused_one" (the
+ * single-read K kernel, csrc/kone.hip: 1 = wherever it applies; off by default -- measured slower than the chain), and for the decode
  * attention "attn_gqa_group" (one workgroup per KV head serves its 2 / 4 / 8 query heads), "attn_win_chunk" (fp16 window as one more
  * chunk of the split: 0 = on the vector short-chunk kernel, 1 = always, -1 = never), "attn_keep_chunk_index", "attn_mfma" (the matrix-core variant of the short-chunk kernel: 0 = for grouped-query
  * shapes, 1 = always, -1 = never) -- measured alternatives of round 5, all off / automatic by default (gear_amd/csrc/common.h says
@@ -398,6 +399,16 @@ int gear_compress_block(const gear_cache_view* c, int t_off, int o_off, int loop
                         void* vP_out, int64_t p_inner, int64_t kp_outer_stride, int64_t vp_outer_stride, void* sync_ws,
                         size_t sync_ws_bytes, void* stream);
 const void* gear_compress_block_status_ptr(const void* sync_ws);
+
+/* gear_compress_key_fused's single-read kernel (csrc/kone.hip; fp32 arithmetic, prompt-size tensors) exchanges outlier candidates
+ * between the workgroups of a head inside ONE launch; every wait of that exchange is bounded.  Returns how many waits ran into their
+ * bound since the library was loaded -- 0 on a healthy device; anything else means the payload of that call is invalid (the device
+ * could not co-schedule a head's workgroups).  Replaces nothing in the reference (it has no in-kernel exchange).  Synchronises the
+ * device.  -1: the query itself failed. */
+int gear_kone_timeouts(void);
+/* Heads of single-read-kernel calls whose outlier threshold guess failed and which the exact kernel chain redid (cumulative since the
+ * library was loaded; 0 on ordinary data; results are exact either way).  Synchronises the device.  -1: the query failed. */
+int gear_kone_fallback_heads(void);
 /* Chunk index over lists that live inside larger tensors (the streaming cache keeps its tables up to date block by block):
  * lists (o, i), o < n_outer, i < inner, list id = o * outer_pitch + first + i; list `id` is oidx + id * list_stride with k valid
  * entries; out[id * out_pitch + b] = first position whose index is >= b * step, b < n_bounds.

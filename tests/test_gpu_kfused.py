@@ -37,6 +37,22 @@ def C():
     return compress
 
 
+@pytest.fixture(params=["chain", "one"], autouse=True)
+def kpath(request):
+    """Every test of this module runs twice: through the kernel chain (select -> main -> solve -> Q pass) and with the single-read
+    kernel of csrc/kone.hip (selection + dense part + Gram in one launch, the slabs of a head exchanging candidates inside the
+    launch) wherever its plan takes the shape (fp32 arithmetic; variants 2 / 8 / 32 / 64 and the fp16-stepwise mode keep the chain).
+    No exchange wait may have run into its bound, and -- ordinary data -- no head may have needed the exact fall-back chain unless
+    the test is about hard rows."""
+    from gear_amd import _lib as L
+    lib = L.load()
+    lib.gear_set_option(b"kfused_one", 1 if request.param == "one" else -1)
+    t0 = lib.gear_kone_timeouts()
+    yield request.param
+    lib.gear_set_option(b"kfused_one", 0)
+    assert lib.gear_kone_timeouts() == t0, "an exchange wait of the single-read K kernel timed out"
+
+
 def _oracle_key(xn, k, g, b, mode=1):
     """Oracle on K rows (channels x tokens): selection, fill, quantization.  Returns dict + index sets."""
     B, H, T, D = xn.shape
