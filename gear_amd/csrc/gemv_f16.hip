@@ -65,6 +65,7 @@ struct GemvArgs {
     float log2_theta;
     const int* dyn;
     uint16_t *q_out, *kwin, *vwin;
+    int half_n;               // EPI_SWIGLU with BLOCKED weights [gate rows | up rows]: N / 2 (0: the rows are interleaved gate, up, gate, ...)
 };
 
 template <int NB, int SK, int NORM, int EPI>
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_ker
         row = head * 128 + 2 * pu + (rsub & 1) + 64 * (rsub >> 1);
     } else {
         row = min((int)blockIdx.x * RPB + rsub, a.N - 1);
+        // (gate_proj / up_proj as the modules hold them -- two row blocks of one buffer: pair (2 j, 2 j + 1) = rows j and N / 2 + j)
+        if (EPI == EPI_SWIGLU && a.half_n) row = (row & 1) * a.half_n + (row >> 1);
     }
     const int nchunk = a.K / 8;
     float acc[NB], ss[NB];
@@ -93,7 +96,9 @@ __global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_ker
     const uint4* nv = (const uint4*)a.nw;
     uint4* rv = (uint4*)a.res_out;
     // NORM 1: the residual stream as it is (norm weight folded into W) -- a loop without run-time branches, so that it
-    // unrolls with four weight loads in flight like the plain GEMV; NORM 2: optional addend / norm weight / residual write
+    // unrolls with four weight loads in flight like the plain GEMV; NORM 2: optional addend / norm weight / residual write;
+    // NORM 3 (round 6): the norm weight applied on the fly and nothing else -- the attention hook's usual step (the modules' own
+    // weights, no addend): NORM 2's run-time branches kept its loop from unrolling (gate / up 34.8 us against 28.9 folded)
     const bool writer = NORM == 2 && a.res_out && blockIdx.x == 0 && rsub == 0;   // this row's K parts cover every chunk once
 #pragma unroll 4
     for (int c = lane + 64 * kp; c < nchunk; c += 64 * SK) {
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(EPI == EPI_ROPE ? 256 * SK : 256) void gemv_tok_ker
             if (NORM == 2) {
                 if (a.nw) xa = hmul8(xa, nv[c]);
             }
+            if (NORM == 3) xa = hmul8(xa, nv[c]);      // norm weight on the fly, nothing else: no run-time branch in the loop
             acc[b] = dot8(w, xa, acc[b]);
         }
     }
@@ -234,11 +240,15 @@ extern "C" int gear_gemv_f16_norm(const void* x, const void* delta, const void* 
     a.res_out = delta ? (uint16_t*)res_out : nullptr;
     a.eps = eps; a.W = (const uint16_t*)W; a.y = (uint16_t*)y; a.K = K; a.N = N;
     const bool folded = !delta && !norm_w;
+    a.half_n = swiglu == 2 ? N / 2 : 0;
+    const bool nw_only = !delta && norm_w;
     if (swiglu) {
         if (folded) launch_sk<1, EPI_SWIGLU>(pick_sk(K, N, 2), B, N, (hipStream_t)stream, a);
+        else if (nw_only) launch_sk<3, EPI_SWIGLU>(pick_sk(K, N, 2), B, N, (hipStream_t)stream, a);
         else launch_sk<2, EPI_SWIGLU>(pick_sk(K, N, 2), B, N, (hipStream_t)stream, a);
     } else {
         if (folded) launch_sk<1, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
+        else if (nw_only) launch_sk<3, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
         else launch_sk<2, EPI_PLAIN>(pick_sk(K, N, 4), B, N, (hipStream_t)stream, a);
     }
     GEAR_CHECK_LAUNCH("gear_gemv_f16_norm");
@@ -262,12 +272,14 @@ extern "C" int gear_gemv_qkv_rope(const void* x, const void* delta, const void* 
     a.Hq = Hq; a.Hkv = Hkv; a.pos = pos; a.slot = slot; a.wcap = wcap; a.log2_theta = log2f(theta);
     a.dyn = (const int*)dyn_state; a.q_out = (uint16_t*)q_out; a.kwin = (uint16_t*)kwin; a.vwin = (uint16_t*)vwin;
     const unsigned blocks = (unsigned)((Hq + 2 * Hkv) * 32);
-    const bool folded = !delta && !norm_w;
+    const bool folded = !delta && !norm_w, nw_only = !delta && norm_w;
     if (pick_sk(K, a.N, 2) == 2) {
         if (folded) launch_nb<2, 1, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
+        else if (nw_only) launch_nb<2, 3, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
         else launch_nb<2, 2, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
     } else {
         if (folded) launch_nb<1, 1, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
+        else if (nw_only) launch_nb<1, 3, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
         else launch_nb<1, 2, EPI_ROPE>(B, blocks, (hipStream_t)stream, a);
     }
     GEAR_CHECK_LAUNCH("gear_gemv_qkv_rope");

@@ -267,6 +267,7 @@ __device__ __forceinline__ void ko_dense(unsigned char* slab, int row0, int cp, 
         }
     }
     // ---- the outlier slots: code = quant(mean) (fill, then quantize: compress_function.py:276-286), error = 0
+    asm volatile("" ::: "memory");      // (the 2-byte stores below hit words stored above through another type: keep the order)
     if (mA | mB) {
         constexpr int CPW = 32 / BITS;
         float cmA = 0.f, cmB = 0.f;

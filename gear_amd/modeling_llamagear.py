@@ -307,6 +307,21 @@ class GearHookCache:
         return tuple(own(self[i]) for i in range(17))
 
 
+_cache_full_warned = False
+
+
+def _warn_cache_full(c):
+    """The pre-allocated cache behind a GearHookCache is full: the hook continues on the reference-shaped tuple path (materialize(),
+    torch.cat appends, ~60 eager launches per layer and token) -- correct, several times slower.  Said once per process."""
+    global _cache_full_warned
+    if not _cache_full_warned:
+        _cache_full_warned = True
+        import warnings
+        warnings.warn(f"gear_amd: the pre-allocated KV cache ({c.Tmax} tokens = prompt + config.gear_max_new_tokens) is full; decoding "
+                      "continues on the tuple-shaped path, which is several times slower -- set config.gear_max_new_tokens to the "
+                      "number of tokens you generate", RuntimeWarning, stacklevel=3)
+
+
 class LlamaAttention_GEAR(nn.Module):
     """modeling_llamagear.py:113-484: attention whose cache is the packed GEAR payload plus an fp16 residual
     window of `residual` tokens; a block is compressed whenever the window fills."""
@@ -450,20 +465,48 @@ class LlamaAttention_GEAR(nn.Module):
             self._wqkv = w
         return w
 
-    def decode_token_fused(self, res, delta, norm_weight, eps: float, hc: GearHookCache):
+    def folded_qkv(self, norm_weight):
+        """The fused q/k/v weight with the input RMSNorm's weight folded into its columns (fp16(W * n): the GEMV then streams the
+        weights without the norm-weight loads and multiplies in its loop -- 17.4 us against 21.0 per layer on Llama-2-7B shapes).
+        A second copy of the projection weights (LlamaDecoderLayer_GEAR.fold_norm_weights = False keeps to the modules' own); rebuilt
+        when either parameter changed."""
+        w = self.fused_weights()
+        key = (w.data_ptr(), w._version, norm_weight.data_ptr(), norm_weight._version)
+        if getattr(self, "_wqkv_folded_key", None) != key:
+            with torch.no_grad():
+                self._wqkv_folded = (w * norm_weight[None, :]).contiguous()
+            self._wqkv_folded_key = key
+        return self._wqkv_folded
+
+    def decode_token_fused(self, res, delta, norm_weight, eps: float, hc: GearHookCache, dyn=None, fold: bool = False):
         """The hook's decode step for the decoder layer's fused path (batch <= 4, implicit positions, stock rotary, no bias, one
         rank): [residual add + RMSNorm + q/k/v GEMV + RoPE + window append] = ONE launch (gear_gemv_qkv_rope), fused attention over
         the packed cache, compress of a full window in place.  Returns (res + delta, attention output [B, Hq * 128], new cache) or
         None when the cache is full (the caller takes the tuple path)."""
         c = hc.cache
+        B, K = res.shape
+        wqkv = self.fused_weights()
+        if fold:
+            wqkv, norm_weight = self.folded_qkv(norm_weight), None
+        if dyn is not None:
+            # the launches of a captured token step (_HookGraph): position, window slot and lengths come from the device state
+            # {pos, slot, T, W}; no host-side counter moves here
+            res1 = torch.empty_like(res) if delta is not None else res
+            q = torch.empty((B, self.num_heads, 1, self.head_dim), dtype=res.dtype, device=res.device)
+            rc = L.load().gear_gemv_qkv_rope(L.ptr(res), L.ptr(delta), L.ptr(norm_weight), eps, L.ptr(wqkv), B, K,
+                                             self.num_heads, self.num_key_value_heads, self.head_dim, 0, 0, c.R,
+                                             float(self.rope_theta), L.ptr(dyn), L.ptr(res1) if delta is not None else None, L.ptr(q),
+                                             L.ptr(c.kwin), L.ptr(c.vwin), L.stream_ptr(res))
+            L.check(rc, "gear_gemv_qkv_rope")
+            return res1, c.attend_dyn(q).view(B, self.num_heads * self.head_dim), None
         hc.check_live()
         if c.n_comp + c.n_win + 1 > c.Tmax:
+            _warn_cache_full(c)
             return None
-        B, K = res.shape
         kv_seq_len = hc.seq_len + 1
         res1 = torch.empty_like(res) if delta is not None else res
         q = torch.empty((B, self.num_heads, 1, self.head_dim), dtype=res.dtype, device=res.device)
-        rc = L.load().gear_gemv_qkv_rope(L.ptr(res), L.ptr(delta), L.ptr(norm_weight), eps, L.ptr(self.fused_weights()), B, K,
+        rc = L.load().gear_gemv_qkv_rope(L.ptr(res), L.ptr(delta), L.ptr(norm_weight), eps, L.ptr(wqkv), B, K,
                                          self.num_heads, self.num_key_value_heads, self.head_dim, kv_seq_len - 1, c.n_win, c.R,
                                          float(self.rope_theta), None, L.ptr(res1) if delta is not None else None, L.ptr(q),
                                          L.ptr(c.kwin), L.ptr(c.vwin), L.stream_ptr(res))
@@ -481,6 +524,7 @@ class LlamaAttention_GEAR(nn.Module):
         c = hc.cache
         hc.check_live()
         if c.n_comp + c.n_win + 1 > c.Tmax:
+            _warn_cache_full(c)
             return None                                  # capacity: the caller continues on the tuple path
         if qkv_flat is not None:
             # RoPE at position kv_seq_len - 1 on q and k + window append in ONE launch (gear_rope_append: the reference's
@@ -673,7 +717,26 @@ class LlamaDecoderLayer_GEAR(nn.Module):
             self._wgu = w
         return w
 
-    def decode_step(self, res: torch.Tensor, delta: Optional[torch.Tensor], past):
+    fold_norm_weights = True        # decode steps: norm weights folded into second copies of q/k/v and gate/up (+ ~9 GB at 7B)
+
+    def folded_gate_up(self):
+        """fused_gate_up() with post_attention_layernorm's weight folded into its columns (a second copy; see folded_qkv)."""
+        w, n = self.fused_gate_up(), self.post_attention_layernorm.weight
+        key = (w.data_ptr(), w._version, n.data_ptr(), n._version)
+        if getattr(self, "_wgu_folded_key", None) != key:
+            with torch.no_grad():
+                self._wgu_folded = (w * n[None, :]).contiguous()
+            self._wgu_folded_key = key
+        return self._wgu_folded
+
+    def fused_step_ok(self, B: int, past) -> bool:
+        """The layer's token step can run as the six fused launches (batch <= 4, pre-allocated cache, one rank, stock rotary, no biases)."""
+        at, mlp = self.self_attn, self.mlp
+        return (B <= 4 and isinstance(past, GearHookCache) and at.tp_world == 1 and at.q_proj.bias is None and at.fused_rope
+                and at.fast_decode and type(at.rotary_emb) is LlamaRotaryEmbedding and mlp.down_proj.bias is None
+                and mlp.gate_proj.weight.shape[0] % 2 == 0)
+
+    def decode_step(self, res: torch.Tensor, delta: Optional[torch.Tensor], past, dyn=None):
         """One token through the layer with the glue fused (csrc/decode_ops.hip; the same fp16 arithmetic op by op as the modules
         above): res [B, hidden] is the residual stream BEFORE `delta` (the previous layer's MLP output, or None) is added.
         [residual add + RMSNorm] -> attention hook (its reference signature) -> [residual add + RMSNorm] -> gate / up ->
@@ -683,23 +746,22 @@ class LlamaDecoderLayer_GEAR(nn.Module):
         st = L.stream_ptr(res)
         ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
         at, mlp = self.self_attn, self.mlp
-        if (B <= 4 and isinstance(past, GearHookCache) and at.tp_world == 1 and at.q_proj.bias is None and at.fused_rope
-                and at.fast_decode and type(at.rotary_emb) is LlamaRotaryEmbedding and mlp.down_proj.bias is None):
-            # 7 launches: [add + norm + qkv + RoPE + append] -> attention (2) -> [o_proj + add] -> [norm + gate/up] -> [SiLU * up]
-            # -> [down + add]; the weights are the modules' own (q/k/v and gate/up fused by re-pointing the parameters at slices)
-            r = at.decode_token_fused(res, delta, ln1.weight, ln1.variance_epsilon, past)
+        if self.fused_step_ok(B, past):
+            # 6 launches: [add + norm + qkv + RoPE + append] -> attention (2) -> [o_proj + add] -> [norm + gate/up + SiLU * up]
+            # -> [down + add]; the weights are the modules' own (q/k/v and gate/up fused by re-pointing the parameters at slices of
+            # one buffer: gate rows, then up rows -- the GEMV pairs row j with row I + j)
+            fold = self.fold_norm_weights
+            r = at.decode_token_fused(res, delta, ln1.weight, ln1.variance_epsilon, past, dyn, fold)
             if r is not None:
                 res1, a, present = r
                 res2 = torch.empty_like(res)
                 L.check(lib.gear_gemv_f16_add(L.ptr(a), L.ptr(at.o_proj.weight), B, a.shape[1], Hd, L.ptr(res1), L.ptr(res2), st),
                         "gear_gemv_f16_add")
-                wgu = self.fused_gate_up()
+                wgu = self.folded_gate_up() if fold else self.fused_gate_up()
                 I = wgu.shape[0] // 2
-                gu = torch.empty((B, 2 * I), dtype=res.dtype, device=res.device)
-                L.check(lib.gear_gemv_f16_norm(L.ptr(res2), None, L.ptr(ln2.weight), ln2.variance_epsilon, L.ptr(wgu), B, Hd,
-                                               2 * I, 0, None, L.ptr(gu), st), "gear_gemv_f16_norm")
                 act = torch.empty((B, I), dtype=res.dtype, device=res.device)
-                L.check(lib.gear_silu_mul(L.ptr(gu), B, I, L.ptr(act), st), "gear_silu_mul")
+                L.check(lib.gear_gemv_f16_norm(L.ptr(res2), None, None if fold else L.ptr(ln2.weight), ln2.variance_epsilon, L.ptr(wgu),
+                                               B, Hd, 2 * I, 2, None, L.ptr(act), st), "gear_gemv_f16_norm")
                 res3 = torch.empty_like(res)
                 L.check(lib.gear_gemv_f16_add(L.ptr(act), L.ptr(mlp.down_proj.weight), B, I, Hd, L.ptr(res2), L.ptr(res3), st),
                         "gear_gemv_f16_add")
@@ -723,8 +785,71 @@ class LlamaDecoderLayer_GEAR(nn.Module):
         return res2, mlp.down_proj(act), present
 
 
+class _HookGraph:
+    """The decode step of LlamaModel_GEAR over GearHookCache layers as ONE hipGraph: embedding -> per layer the six launches of
+    LlamaDecoderLayer_GEAR.decode_step with position / window slot / lengths read from a device-side {pos, slot, T, W} state that
+    every layer's cache shares -> final RMSNorm -> state advance.  Same kernels, same order, same arithmetic as the eager fused
+    step (the reference-trace tests run through it); what disappears is ~200 ctypes calls and ~200 tensor allocations of host work
+    per token, which is what the eager hook step was bound by (282 tokens/s against FastGearDecoder's 340 in round 5: VERDICT r5
+    item 6).  Block boundaries (every `residual` tokens) run eagerly between replays, exactly as the eager step does them.
+    A graph belongs to one set of caches (one prompt): LlamaModel_GEAR builds it at the third decode step of a generation."""
+
+    def __init__(self, model, caches, B: int):
+        self.caches = caches
+        dev = model.embed_tokens.weight.device
+        self.state = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.tok = torch.zeros((B,), dtype=torch.long, device=dev)
+        for c in caches:
+            c.state = self.state
+        self.key = tuple(id(c) for c in caches)
+        self._sync()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            res, delta = model.embed_tokens(self.tok), None
+            for layer, c in zip(model.layers, caches):
+                res, delta, _ = layer.decode_step(res, delta, _DynPast(c), self.state)
+            y = torch.empty_like(res)
+            L.check(L.load().gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(model.norm.weight), B, res.shape[1],
+                                              model.norm.variance_epsilon, None, L.ptr(y), L.stream_ptr(res)), "gear_add_rmsnorm")
+            L.check(L.load().gear_decode_state_advance(L.ptr(self.state), L.stream_ptr(res)), "gear_decode_state_advance")
+        self.graph, self.y = g, y
+
+    def _sync(self):
+        c = self.caches[0]
+        self.state.copy_(torch.tensor([c.n_comp + c.n_win, c.n_win, c.n_comp, c.n_win + 1], dtype=torch.int32))
+
+    def step(self, model, token, pasts):
+        """token [B] -> final hidden state [B, hidden] (a static buffer) and the layers' new GearHookCache objects."""
+        self.tok.copy_(token)
+        self.graph.replay()
+        presents = []
+        boundary = False
+        for layer, c, hc in zip(model.layers, self.caches, pasts):
+            c.n_win += 1
+            if c.n_win == c.R:
+                layer.self_attn._store_block(c, c.kwin, c.vwin, c.R)
+                c.n_win = 0
+                boundary = True
+            presents.append(GearHookCache(c, hc.lowrank, hc.seq_len + 1))
+        if boundary:
+            self._sync()
+        return self.y, tuple(presents)
+
+
+class _DynPast(GearHookCache):
+    """What a captured step hands to LlamaDecoderLayer_GEAR.decode_step in place of the caller's GearHookCache: only the cache."""
+
+    def __init__(self, cache):
+        self.cache = cache
+
+
 class LlamaModel_GEAR(nn.Module):
     fused_decode_glue = True        # decode steps over GearHookCache layers use LlamaDecoderLayer_GEAR.decode_step
+    graph_decode = False            # ... replayed as one hipGraph from the third decode step of a generation on (_HookGraph).
+                                    # Off: measured SLOWER than the eager launches (304 against 313 tokens/s, 7B at 4k) -- the
+                                    # step is bound by its kernels, not by the host, and the captured attention runs over the
+                                    # cache's capacity instead of its length
 
     def __init__(self, config, compress_config):
         super().__init__()
@@ -733,6 +858,37 @@ class LlamaModel_GEAR(nn.Module):
         self.layers = nn.ModuleList([LlamaDecoderLayer_GEAR(config, i, compress_config)
                                      for i in range(config.num_hidden_layers)])
         self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self._hook_graph = None
+        self._hook_steps = (None, 0)
+
+    def _graph_step(self, input_ids, past_key_values):
+        """The captured token step when it applies (see _HookGraph), else None."""
+        if not self.graph_decode or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+            return None
+        bsz = input_ids.shape[0]
+        caches = [pk.cache for pk in past_key_values]
+        c0 = caches[0]
+        key = tuple(id(c) for c in caches)
+        if any((c.n_comp, c.n_win, c.R, c.Tmax) != (c0.n_comp, c0.n_win, c0.R, c0.Tmax) for c in caches):
+            return None
+        if c0.n_comp + c0.n_win + 1 > c0.Tmax or not all(l.fused_step_ok(bsz, pk) for l, pk in zip(self.layers, past_key_values)):
+            return None
+        for pk in past_key_values:
+            pk.check_live()
+        g = self._hook_graph
+        if g is None or g.key != key:
+            # a new generation (new caches): two eager steps first (short generations never pay for a capture), then the graph
+            last, n = self._hook_steps
+            n = n + 1 if last == key else 1
+            self._hook_steps = (key, n)
+            if n < 3:
+                return None
+            g = self._hook_graph = _HookGraph(self, caches, bsz)
+        elif (int(c0.n_comp + c0.n_win), c0.n_win) != getattr(g, "_expect", (int(c0.n_comp + c0.n_win), c0.n_win)):
+            g._sync()                  # somebody stepped these caches eagerly in between
+        y, presents = g.step(self, input_ids[:, 0], past_key_values)
+        g._expect = (int(c0.n_comp + c0.n_win), c0.n_win)
+        return y.unsqueeze(1), presents
 
     def forward(self, input_ids, past_key_values=None, use_cache=True):
         bsz, q_len = input_ids.shape
@@ -741,6 +897,9 @@ class LlamaModel_GEAR(nn.Module):
                 and self.embed_tokens.weight.dtype == torch.float16 and self.embed_tokens.weight.is_cuda
                 and self.config.hidden_size % 8 == 0 and self.config.hidden_size <= 8192
                 and self.layers[0].mlp.gate_proj.bias is None):
+            r = self._graph_step(input_ids, past_key_values)
+            if r is not None:
+                return r
             # decode step over pre-allocated caches: fused glue around the attention hook (LlamaDecoderLayer_GEAR.decode_step)
             res, delta = self.embed_tokens(input_ids[:, 0]), None
             presents = []
@@ -778,7 +937,16 @@ class LlamaForCausalLM_GEARKIVI(nn.Module):
 
     def forward(self, input_ids, past_key_values=None, use_cache=True):
         hidden, presents = self.model(input_ids, past_key_values, use_cache)
-        return self.lm_head(hidden[:, -1:, :]), presents
+        h = hidden[:, -1:, :]
+        w = self.lm_head.weight
+        if (h.shape[0] <= 4 and h.is_cuda and h.dtype == torch.float16 and w.dtype == torch.float16 and w.is_contiguous()
+                and h.shape[-1] % 8 == 0 and not torch.is_grad_enabled()):
+            # one token: the weight-streaming GEMV of the token step (csrc/gemv_f16.hip) instead of the library GEMM
+            x = h.reshape(h.shape[0], -1).contiguous()
+            y = torch.empty((x.shape[0], w.shape[0]), dtype=h.dtype, device=h.device)
+            L.check(L.load().gear_gemv_f16(L.ptr(x), L.ptr(w), x.shape[0], x.shape[1], w.shape[0], L.ptr(y), L.stream_ptr(x)), "gear_gemv_f16")
+            return y.unsqueeze(1), presents
+        return self.lm_head(h), presents
 
     @torch.no_grad()
     def generate(self, input_ids, max_length: int, use_cache: bool = True):

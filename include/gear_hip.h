@@ -431,8 +431,9 @@ int gear_gemv_f16_add(const void* x, const void* W, int B, int K, int N, const v
  * (cuda_supported_gear/modeling_llamagear.py:502-560: input_layernorm / post_attention_layernorm, :193-205 q/k/v + rotary,
  * LlamaMLP act_fn(gate) * up) into the weight stream:
  *   gear_gemv_f16_norm : v = x + delta (delta may be NULL; otherwise res_out [B,K] receives v and must not alias x/delta);
- *                        y = W . (norm_w * v) * rsqrt(mean(v^2) + eps)  (norm_w NULL: already folded into W's columns).   swiglu != 0: W rows are interleaved
- *                        (gate_0, up_0, gate_1, up_1, ...) and y [B, N/2] = fp16(silu(gate)) * up.
+ *                        y = W . (norm_w * v) * rsqrt(mean(v^2) + eps)  (norm_w NULL: already folded into W's columns).   swiglu = 1: W rows are interleaved
+ *                        (gate_0, up_0, gate_1, up_1, ...), swiglu = 2: blocked [N/2 gate rows | N/2 up rows] (gate_proj / up_proj
+ *                        as the modules hold them); y [B, N/2] = fp16(silu(gate)) * up.
  *   gear_gemv_qkv_rope : the same prologue, W = [q heads | k heads | v heads] x 128 rows; RoPE (HF rotate_half, fp16 op by
  *                        op) on q and k at `pos`; q -> q_out [B,Hq,128]; k, v -> window slot `slot` of kwin / vwin
  *                        [B*Hkv, wcap, 128].  dyn_state != NULL: pos and slot are read from the device state

@@ -312,6 +312,57 @@ def test_fast_decoder_tracks_the_attention_hook_module(n_kv):
     assert fast.layers[0]["cache"].n_comp == 192 and fast.layers[0]["cache"].n_win == 8
 
 
+def _hook_run(model, ids, n, teacher=None):
+    model.model._hook_graph = None
+    outs, toks = [], []
+    with torch.no_grad():
+        torch.manual_seed(7)          # (block boundaries draw their power-iteration bases from torch's generator)
+        logits, past = model(ids, None, True)
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        for i in range(n):
+            if teacher is not None:
+                nxt = teacher[i]
+            toks.append(nxt)
+            logits, past = model(nxt, past, True)
+            outs.append(logits[:, -1].clone())
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+    return outs, toks, past
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_hook_decode_step_variants_agree(batch):
+    """The attention hook's fused decode step: (a) with the norm weights folded into second copies of q/k/v and
+    gate/up (the default: 345 against 316 tokens/s at 7B shapes) against the modules' own weights with the norm weight applied
+    in the GEMV loop -- fp16 rounding apart; (b) the same step replayed as ONE hipGraph (LlamaModel_GEAR.graph_decode) against
+    the eager launches -- the same kernels in the same order: logits equal to an fp16 ulp over 150 tokens and two block
+    boundaries, cache counters and slot 8 identical."""
+    from gear_amd.modeling_llamagear import LlamaDecoderLayer_GEAR
+    model = _tiny("gearlKIVI", 2)
+    ids = torch.randint(0, 1000, (batch, 200 if batch == 1 else 70)).cuda()
+    n = 150 if batch == 1 else 80
+    old = LlamaDecoderLayer_GEAR.fold_norm_weights
+    try:
+        LlamaDecoderLayer_GEAR.fold_norm_weights = False
+        own, toks, _ = _hook_run(model, ids, n)
+        LlamaDecoderLayer_GEAR.fold_norm_weights = True
+        fold, _, past_e = _hook_run(model, ids, n, teacher=toks)
+        worst = min(float(torch.nn.functional.cosine_similarity(a.float(), b.float()).min()) for a, b in zip(own, fold))
+        assert worst > 0.999, worst
+        model.model.graph_decode = True
+        graph, _, past_g = _hook_run(model, ids, n, teacher=toks)
+        assert model.model._hook_graph is not None, "the graph path was not taken"
+        diff = max(float((a.float() - b.float()).abs().max()) for a, b in zip(fold, graph))
+        scale = max(float(a.float().abs().max()) for a in fold)
+        assert diff <= 2e-3 * scale, (diff, scale)
+        assert past_g[0][8] == past_e[0][8] == ids.shape[1] + n
+        ce, cg = past_e[0].cache, past_g[0].cache
+        assert (ce.n_comp, ce.n_win) == (cg.n_comp, cg.n_win)
+        assert torch.equal(ce.kcode[..., :ce.n_comp // ce.fpi], cg.kcode[..., :cg.n_comp // cg.fpi])
+    finally:
+        LlamaDecoderLayer_GEAR.fold_norm_weights = old
+        model.model.graph_decode = False
+
+
 @pytest.mark.parametrize("batch, n_kv", [(1, 2), (2, 4), (6, 2)])
 def test_fp16_cache_baseline_decoder(batch, n_kv):
     """cache_kind='fp16' (the uncompressed model "None" of the reference's harness, cuda_supported_gear/test.py:41-62) through the same
@@ -427,7 +478,7 @@ def test_fused_norm_gemv_matches_the_unfused_chain(B):
     norm.weight.data = (1 + 0.1 * torch.randn(K)).half().cuda()
     W = (torch.randn(N, K) / K ** 0.5).half().cuda()
     for d in (delta, None):
-        for swiglu in (0, 1):
+        for swiglu in (0, 1, 2):     # 1: (gate, up) rows interleaved; 2: blocked [gate rows | up rows], as the modules hold them
             y = torch.empty(B, N // 2 if swiglu else N).half().cuda()
             ro = torch.empty_like(res)
             L.check(lib.gear_gemv_f16_norm(L.ptr(res), L.ptr(d), L.ptr(norm.weight), 1e-5, L.ptr(W), B, K, N, swiglu,
@@ -436,9 +487,17 @@ def test_fused_norm_gemv_matches_the_unfused_chain(B):
             if d is not None:
                 assert torch.equal(ro, v)
             ref = torch.nn.functional.linear(norm(v).float(), W.float())
-            if swiglu:
+            if swiglu == 1:
                 ref = torch.nn.functional.silu(ref[:, 0::2]) * ref[:, 1::2]
+            elif swiglu == 2:
+                ref = torch.nn.functional.silu(ref[:, :N // 2]) * ref[:, N // 2:]
             assert float((y.float() - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+    # blocked == interleaved on the permuted weight, bit for bit (the same pairs, the same arithmetic)
+    Wi = torch.stack([W[:N // 2], W[N // 2:]], 1).reshape(N, K).contiguous()
+    y1, y2 = torch.empty(B, N // 2).half().cuda(), torch.empty(B, N // 2).half().cuda()
+    L.check(lib.gear_gemv_f16_norm(L.ptr(res), None, L.ptr(norm.weight), 1e-5, L.ptr(Wi), B, K, N, 1, None, L.ptr(y1), L.stream_ptr()), "il")
+    L.check(lib.gear_gemv_f16_norm(L.ptr(res), None, L.ptr(norm.weight), 1e-5, L.ptr(W), B, K, N, 2, None, L.ptr(y2), L.stream_ptr()), "bl")
+    assert torch.equal(y1, y2)
     # norm weight folded into W's columns (norm_w NULL) + the residual-add GEMV, in place
     Wf = (W.float() * norm.weight.float()[None, :]).half()
     y = torch.empty(B, N).half().cuda()
