@@ -487,7 +487,12 @@ class Fp16KVCache:
     attention is gear_attn_decode_f16 (the same split / merge kernels as the compressed path).  It has GearKVCache's window
     interface -- the "window" is the whole cache --, so FastGearDecoder's fused q/k/v projection appends to it unchanged."""
 
+    MAX_TOKENS = 8320      # gear_attn_decode_f16: 65 chunks of 128 tokens in one merge (csrc/attention.hip RS_MAX)
+
     def __init__(self, batch: int, n_kv_heads: int, max_tokens: int, device, head_dim: int = 128):
+        if max_tokens > self.MAX_TOKENS:
+            raise L.GearError(f"Fp16KVCache: capacity {max_tokens} > {self.MAX_TOKENS} tokens, the longest context "
+                              "gear_attn_decode_f16 merges in one launch (the baseline would fail at its first attend())")
         self.B, self.H, self.D = batch, n_kv_heads, head_dim
         self.R = max_tokens
         self.kwin = torch.zeros((batch, n_kv_heads, max_tokens, head_dim), dtype=torch.float16, device=device)

@@ -43,9 +43,14 @@ class Payload:
     mn: torch.Tensor
     P: Optional[torch.Tensor] = None
     Q: Optional[torch.Tensor] = None
-    oidx: Optional[torch.Tensor] = None
-    oval: Optional[torch.Tensor] = None
+    oidx: Optional[torch.Tensor] = None      # sorted outlier positions per row and side.  A head SHARD's V payload (compress_value_sharded)
+    oval: Optional[torch.Tensor] = None      # pads its lists with index 0xFFFF / value 0: mask with `valid_outliers()` before indexing
     k_out: int = 0
+
+    def valid_outliers(self) -> Optional[torch.Tensor]:
+        """bool mask of the list slots that hold an outlier (all of them except the 0xFFFF padding of a head shard's V lists): the
+        HIP decompressor and attention kernels skip the padding; a torch-side consumer that scatters oval at oidx must too."""
+        return None if self.oidx is None else (self.oidx.to(torch.int32) & 0xFFFF) != 0xFFFF
 
     @property
     def rank(self):
@@ -149,11 +154,14 @@ def compress_rows_once(x, geom, group, bits, mode, k, want_err, err=None):
     return out + (err,)
 
 
-def compress_value_sharded(v: torch.Tensor, bits: int, group: int, k_out: int, rank: int, loop: int, mode, P0, shard) -> Payload:
+def compress_value_sharded(v: torch.Tensor, bits: int, group: int, k_out: int, rank: int, loop: int, mode, P0, shard,
+                           thresholds=None) -> Payload:
     """One head shard of a V tensor whose token rows span the heads of `world` ranks: v [B,H_local,T,128], k_out = the FULL row's
     count per side, shard = (tp_rank, tp_world, process group or None).  The selection is the unsharded one (csrc/vsel.hip through
-    parallel.exact_v_thresholds: two launches + one all-gather), the rest is compress_value's; oidx holds LOCAL columns
-    (h_local * 128 + d), unused slots 0xFFFF."""
+    parallel.exact_v_thresholds: two launches + one all-gather) unless `thresholds` = a ready (thr, fill) pair is passed in (the
+    single-process tests and bench.py's emulation of one rank's shard); the rest is compress_value's.  oidx holds LOCAL columns
+    (h_local * 128 + d); a row has 2 k_out slots but only the outliers that fall into THIS shard's heads fill them: unused slots
+    carry index 0xFFFF and value 0 (see Payload.oidx)."""
     from .parallel import exact_v_thresholds
     tp_rank, tp_world, tp_group = shard
     B, H, T, D = v.shape
@@ -167,8 +175,9 @@ def compress_value_sharded(v: torch.Tensor, bits: int, group: int, k_out: int, r
         P0 = P0.to(device=dev, dtype=torch.float32).contiguous()
         P = torch.empty((B, H, D, rank), dtype=torch.float16, device=dev)
         Q = torch.empty((B, H, T, rank), dtype=torch.float16, device=dev)
-    # (tp_group may also be a ready (thr, fill) pair: the single-process tests and bench.py's emulation pass the thresholds in)
-    thr, fill = tp_group if isinstance(tp_group, tuple) else exact_v_thresholds(v, k_out, tp_rank, tp_world, tp_group, mode=m)
+    if thresholds is None and isinstance(tp_group, tuple):       # (rounds 4 - 5 passed the pair in the group's place)
+        thresholds, tp_group = tp_group, None
+    thr, fill = thresholds if thresholds is not None else exact_v_thresholds(v, k_out, tp_rank, tp_world, tp_group, mode=m)
     lib = L.load()
     wsb = lib.gear_compress_value_fused_workspace(B, H, T, rank)
     ws = _workspace(wsb, dev)
@@ -182,14 +191,15 @@ def compress_value_sharded(v: torch.Tensor, bits: int, group: int, k_out: int, r
 
 
 def compress_value(v: torch.Tensor, bits: int, group: int, k_out: int = 0, rank: int = 0, loop: int = 3,
-                   mode="fp32", P0: Optional[torch.Tensor] = None, shard=None) -> Payload:
+                   mode="fp32", P0: Optional[torch.Tensor] = None, shard=None, thresholds=None) -> Payload:
     """V [B,H,T,D] fp16 -> Payload (per-token groups along D; outliers per token row across heads).
-    shard = (tp_rank, tp_world, group): v holds this rank's heads of rows that span `tp_world` ranks -- see compress_value_sharded."""
+    shard = (tp_rank, tp_world, group): v holds this rank's heads of rows that span `tp_world` ranks; thresholds = a ready
+    (thr, fill) pair instead of the exchange -- see compress_value_sharded."""
     assert v.dim() == 4 and v.dtype == torch.float16
     v = v.contiguous()
     L.require_gpu(v)
     if shard is not None and k_out > 0 and shard[1] > 1:
-        return compress_value_sharded(v, bits, group, k_out, rank, loop, mode, P0, shard)
+        return compress_value_sharded(v, bits, group, k_out, rank, loop, mode, P0, shard, thresholds)
     B, H, T, D = v.shape
     m = _MODES[mode]
     dev = v.device

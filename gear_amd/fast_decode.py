@@ -177,6 +177,8 @@ class FastGearDecoder:
         cache = lw["cache"]
         B, K = res.shape
         if self._fused(B, K):
+            if not dyn and cache.n_win >= cache.R:
+                raise L.GearError(f"FastGearDecoder: the cache window is full ({cache.n_win} of {cache.R} slots): capacity reached")
             q = torch.empty((B, self.Hq, 1, self.D), dtype=res.dtype, device=res.device)
             rc = L.load().gear_gemv_qkv_rope(
                 L.ptr(res), None, None, self.eps, L.ptr(lw["wqkv"]), B, K, self.Hq, self.Hkv, self.D,
@@ -269,6 +271,17 @@ class FastGearDecoder:
         tokens) runs eagerly between replays."""
         if self.pool is None:
             raise NotImplementedError("step_graph(): the fp16-cache baseline has eager steps only")
+        if self.gather is not None and not self.gather.capturable and not getattr(self, "_peer_tried", False):
+            # the collective cannot be captured here (its probe failed, on every rank alike): a graph step needs the peer exchange
+            # (csrc/xchg.hip, always capturable) -- set it up now, collectively, and keep the collective if that fails too
+            self._peer_tried = True
+            from .parallel import PeerHeadGather
+            g = PeerHeadGather(self.tp_world, self.tp_rank, self.batch, self.Hq * self.D, torch.float16, self.dev,
+                               getattr(self.gather, "group", None))
+            if g.ok:
+                self.gather = g
+            else:
+                self.exchange_error = g.error
         if self.gather is not None and not self.gather.capturable:
             raise NotImplementedError("step_graph() with tp_world > 1 needs a capturable exchange: tp_exchange='peer', or the "
                                       "collective on the RCCL backend when its capture probe passed (the one-GPU gloo staging "

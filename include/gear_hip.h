@@ -188,7 +188,10 @@ int gear_compress_value_fused(const void* x, int64_t B, int H, int T, int group,
  *                          that fall into its heads (0 .. k per side and row; unused list slots: index 0xFFFF, value 0).
  * The concatenated shard payloads are the unsharded payload (mode 0: bit for bit; mode 1: the unsharded kernel's fill is an fp32
  * tree sum, here it is the correctly rounded mean -- the last place of the fill can differ, the selection cannot).
- * The reference has no multi-GPU path; this keeps its single-GPU semantics under head sharding. */
+ * The reference has no multi-GPU path; this keeps its single-GPU semantics under head sharding.
+ * Range of the "shard payloads == unsharded payload, bit for bit" guarantee: |x| < 2^12 -- there the fp64 row sums behind the fill
+ * value are exact and hence independent of how the row is split; larger magnitudes can move a fill by one unit in the last place.
+ */
 int gear_vsel_candidates(const void* x, int64_t n_rows, int rows_inner, int64_t outer_stride, int64_t inner_stride, int nseg,
                          int seglen, int64_t seg_stride, int k, int col0, void* cand, void* stream);
 int gear_vsel_thresholds(const void* cand_all, int world, int64_t n_rows, int k, int64_t row_len_total, int mode, void* thr,

@@ -232,7 +232,7 @@ def _shard_payloads(C, P, v, world, k, bits, rank_, mode, P0):
     cand_all = torch.stack([P.v_candidates(s, k, r) for r, s in enumerate(shards)])
     thr, fill = P.v_thresholds(cand_all, k, H * D, m)
     return [C.compress_value(s, bits, 64, k_out=k, rank=rank_, loop=3, mode=mode,
-                             P0=None if P0 is None else P0[:, r * Hl:(r + 1) * Hl].contiguous(), shard=(r, world, (thr, fill)))
+                             P0=None if P0 is None else P0[:, r * Hl:(r + 1) * Hl].contiguous(), shard=(r, world, None), thresholds=(thr, fill))
             for r, s in enumerate(shards)], thr, fill
 
 
