@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void vsel_thr_kernel(const uint32_t* __restric
         // (a rank's sum and the total are exact in fp64 -- hence independent of the order -- as long as the row's |x| stay below
         // 2^12: fp16 values are multiples of 2^-24, 65535 of them below 2^12 sum to less than 2^28 = 52 bits of 2^-24.  Beyond that
         // the fill of a shard can differ from the unsharded kernel's in the last place: gear_hip.h states the range)
+        double tot = 0.0;
         for (int w = 0; w < world; w++) {
             const uint32_t* sp = cand_all + ((int64_t)w * n_rows + r) * pitch + 2 * k;
             tot += __longlong_as_double((long long)((unsigned long long)sp[0] | ((unsigned long long)sp[1] << 32)));
