@@ -740,6 +740,21 @@ def main():
                         "ms": ms_main, "alg_bytes": b_main,
                         "not_counted": "the partial Gram matrices (64 KB per head and slab); no error matrix is written: the Q pass rebuilds it"})
         kernels.append({"kernel": "fused K chain (select, main, per-head solve, Q pass)", "ms": ms_full, "alg_bytes": alg["k_compress"]})
+        # the single-read alternative (csrc/kone.hip, option kfused_one; round 6): selection + dense part + Gram in
+        # ONE launch with one read of K -- measured beside the chain in every run, not the default (profiles/r6_kone.md says why)
+        from gear_amd import _lib as _L
+        _lib = _L.load()
+        if _lib.gear_set_option(b"kfused_one", 1) == 0:
+            try:
+                ms_one = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=16))
+                ms_chain_to_gram = timed(lambda: (_lib.gear_set_option(b"kfused_one", 0), C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=16), _lib.gear_set_option(b"kfused_one", 1)))
+                kernels.append({"kernel": "k_one_kernel (K: selection + fill + quantize + pack + Gram in ONE launch, one read of K; option kfused_one = 1, NOT the default)",
+                                "ms": ms_one, "alg_bytes": b_main + BH * D * 2 * k_key * 6,
+                                "chain_ms_up_to_the_gram_matrices": ms_chain_to_gram,
+                                "exchange_timeouts": _lib.gear_kone_timeouts(), "fallback_heads": _lib.gear_kone_fallback_heads(),
+                                "evidence": "profiles/r6_kone.md (phase clocks, PMC traffic 2.68 GB against 3.09 GB)"})
+            finally:
+                _lib.gear_set_option(b"kfused_one", 0)
     for kx in kernels:
         kx["achieved"] = kx["alg_bytes"] / (kx["ms"] * 1e-3) / 1e9 if kx["ms"] else None
         kx["frac"] = kx["achieved"] / HBM_PEAK_GBS if kx["ms"] else None
