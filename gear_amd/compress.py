@@ -86,12 +86,60 @@ def outlier_count(B, H, T, D, sparsity) -> int:
     return int(sparsity_num / B / T / 2)
 
 
+_pin_ring = {}
+_p0_queue = []        # bases drawn ahead of their use, in the order they will be asked for: [(key, device, tensor)]
+
+
+def _draw_p0_now(B, H, S, Dm, rank, device):
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        p = torch.rand(B, H, Dm, rank)
+        _ = torch.rand(B, H, S, rank)
+        return p.to(dev)
+    # through a small ring of PINNED staging buffers with a non-blocking copy: a pageable `.to(device)` stalls the host until the
+    # stream has drained
+    key = (B, H, Dm, rank)
+    ring = _pin_ring.get(key)
+    if ring is None:
+        ring = _pin_ring[key] = {"bufs": [torch.empty(key, dtype=torch.float32).pin_memory() for _ in range(4)],
+                                 "events": [None] * 4, "next": 0}
+    i = ring["next"]
+    ring["next"] = (i + 1) % 4
+    if ring["events"][i] is not None:
+        ring["events"][i].synchronize()          # (four draws later: long done)
+    buf = ring["bufs"][i]
+    torch.rand(key, out=buf)
+    _ = torch.rand(B, H, S, rank)
+    p = buf.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ring["events"][i] = ev
+    return p
+
+
 def draw_p0(B, H, S, Dm, rank, device):
     """Initial bases exactly as the reference draws them: torch.rand on the CPU generator, P first, then a Q that is
-    discarded (new_pack.py:296-297, compress_function.py:83-84) -- keeps the RNG stream aligned with the reference."""
-    p = torch.rand(B, H, Dm, rank)
-    _ = torch.rand(B, H, S, rank)
-    return p.to(device)
+    discarded (new_pack.py:296-297, compress_function.py:83-84) -- keeps the RNG stream aligned with the reference.
+    A basis that prefetch_p0() drew ahead (same request, same order) is handed out instead of drawing now."""
+    if _p0_queue:
+        key, dev, t = _p0_queue[0]
+        if key == (B, H, S, Dm, rank) and dev == torch.device(device):
+            _p0_queue.pop(0)
+            return t
+        _p0_queue.clear()       # something else is being compressed (a new prompt): the bases drawn ahead are dropped
+    return _draw_p0_now(B, H, S, Dm, rank, device)
+
+
+def prefetch_p0(specs, device, limit: int = 256):
+    """Draw the bases of upcoming draw_p0(B, H, S, Dm, rank) calls NOW, in the given order (the order they will be asked for).
+    The values and their order in torch's CPU generator stream are those of drawing at use time -- as long as nothing else draws
+    from that generator in between; what moves is the 2 ns per random number of host time (6 ms per decode-time block boundary of a
+    32-layer model: two thirds of it the reference's discarded Q draws), from the boundary, where the GPU waits for it, into the
+    token steps before it, where the host has slack.  Used by LlamaModel_GEAR's decode loop."""
+    for sp in specs:
+        if len(_p0_queue) >= limit:
+            break
+        _p0_queue.append((tuple(sp), torch.device(device), _draw_p0_now(*sp, device)))
 
 
 def lowrank(E: torch.Tensor, rank: int, loop: int, P0: torch.Tensor, transposed: bool = False, out_dtype=torch.float16,
@@ -115,7 +163,7 @@ def lowrank(E: torch.Tensor, rank: int, loop: int, P0: torch.Tensor, transposed:
         P, Q = out
         assert P.is_contiguous() and Q.is_contiguous() and P.dtype == out_dtype and Q.dtype == out_dtype
     wsb = lib.gear_lowrank_workspace(B * H, S, Dm, rank)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=E.device)
+    ws = _workspace(wsb, E.device)
     rc = lib.gear_lowrank(L.ptr(E), 0 if E.dtype == torch.float16 else 1, 1 if transposed else 0, B * H, S, Dm, rank,
                           loop, L.ptr(P0), L.ptr(P), L.ptr(Q), 0 if out_dtype == torch.float16 else 1, L.ptr(ws), wsb,
                           L.stream_ptr())

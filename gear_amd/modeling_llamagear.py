@@ -411,17 +411,13 @@ class LlamaAttention_GEAR(nn.Module):
         t0, seg = c.n_comp, c._segment_of(c.n_comp)
         kc, ks, km, kp, kq = key_compression(k_src.transpose(2, 3).contiguous(), cc)
         vc, vs, vm, vp, vq = value_compression(v_src.contiguous(), cc)
-        c.kcode[..., t0 // c.fpi:(t0 + T) // c.fpi] = kc
-        c.kscale[..., t0 // c.group:(t0 + T) // c.group] = ks
-        c.kmn[..., t0 // c.group:(t0 + T) // c.group] = km
-        c.vcode[:, :, t0:t0 + T] = vc
-        c.vscale[:, :, t0:t0 + T] = vs
-        c.vmn[:, :, t0:t0 + T] = vm
+        dst = [c.kcode[..., t0 // c.fpi:(t0 + T) // c.fpi], c.kscale[..., t0 // c.group:(t0 + T) // c.group],
+               c.kmn[..., t0 // c.group:(t0 + T) // c.group], c.vcode[:, :, t0:t0 + T], c.vscale[:, :, t0:t0 + T], c.vmn[:, :, t0:t0 + T]]
+        src = [kc, ks, km, vc, vs, vm]
         if kp is not None:
-            c.kQtok[:, :, t0:t0 + T] = kp
-            c.kPseg[seg] = kq
-            c.vQtok[:, :, t0:t0 + T] = vq
-            c.vPseg[seg] = vp
+            dst += [c.kQtok[:, :, t0:t0 + T], c.kPseg[seg], c.vQtok[:, :, t0:t0 + T], c.vPseg[seg]]
+            src += [kp, kq, vq, vp]
+        torch._foreach_copy_(dst, src)          # (the ten slice assignments of a boundary as one multi-tensor copy)
         c.n_comp += T
 
     def _fast_prefill_cache(self, key_states, value_states):
@@ -861,6 +857,34 @@ class LlamaModel_GEAR(nn.Module):
         self._hook_graph = None
         self._hook_steps = (None, 0)
 
+    prefetch_bases = True           # draw the next block boundary's power-iteration bases during the token steps before it
+
+    def _prefetch_bases(self, presents):
+        """The next block boundary asks, layer by layer, for one basis per K block (headwise_lrap on E^T [B,H,128,R]: P0 [B,H,R,rank])
+        and one per V block (E [B,H,R,128]: P0 [B,H,128,rankv]) from torch's CPU generator (new_pack.py:296-297) -- 3 M random
+        numbers for 32 layers, 6 ms of host time during which the GPU waits.  Draw them in that very order a few per token step
+        instead (compress.prefetch_p0): same values, same order in the generator's stream."""
+        if not self.prefetch_bases or not presents or not all(isinstance(p, GearHookCache) and p.lowrank for p in presents):
+            return
+        c0 = presents[0].cache
+        n_layers = len(presents)
+        from . import compress as Cm
+        if getattr(self, "_pf_owner", None) != id(c0):
+            # another generation's caches: whatever was drawn ahead for the old ones must not be handed to these
+            Cm._p0_queue.clear()
+            self._pf_owner, self._pf_done = id(c0), 0
+        if c0.n_win == 0:
+            self._pf_done = 0                      # a boundary has just consumed its bases (or the window is empty after the prefill)
+        done = getattr(self, "_pf_done", 0)
+        if done >= n_layers or c0.n_win == 0:
+            return
+        per_step = -(-n_layers // max(1, c0.R // 2))          # all drawn by the middle of the window
+        for li in range(done, min(n_layers, done + per_step)):
+            c = presents[li].cache
+            cc = self.layers[li].self_attn.compress_config
+            Cm.prefetch_p0([(c.B, c.H, c.D, c.R, int(cc["rank"])), (c.B, c.H, c.R, c.D, int(cc["rankv"]))], c.kwin.device)
+        self._pf_done = min(n_layers, done + per_step)
+
     def _graph_step(self, input_ids, past_key_values):
         """The captured token step when it applies (see _HookGraph), else None."""
         if not self.graph_decode or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
@@ -909,7 +933,12 @@ class LlamaModel_GEAR(nn.Module):
             y = torch.empty_like(res)
             L.check(L.load().gear_add_rmsnorm(L.ptr(res), L.ptr(delta), L.ptr(self.norm.weight), bsz, res.shape[1],
                                               self.norm.variance_epsilon, None, L.ptr(y), L.stream_ptr(res)), "gear_add_rmsnorm")
+            self._prefetch_bases(presents)
             return y.unsqueeze(1), tuple(presents)
+        if past_key_values is None:
+            from . import compress as Cm
+            Cm._p0_queue.clear()                   # a new prompt: no basis drawn ahead for an earlier one survives
+            self._pf_owner = None
         past_len = past_key_values[0][8] if past_key_values is not None else 0     # slot 8 (:624)
         position_ids = torch.arange(past_len, past_len + q_len, device=input_ids.device).unsqueeze(0)
         hidden_states = self.embed_tokens(input_ids)

@@ -348,6 +348,12 @@ def test_hook_decode_step_variants_agree(batch):
         fold, _, past_e = _hook_run(model, ids, n, teacher=toks)
         worst = min(float(torch.nn.functional.cosine_similarity(a.float(), b.float()).min()) for a, b in zip(own, fold))
         assert worst > 0.999, worst
+        # the block boundaries' random bases drawn ahead during the token steps (LlamaModel_GEAR.prefetch_bases) are the bases drawn
+        # at the boundary: same values in the same order of torch's CPU generator -> the same logits, bit for bit
+        model.model.prefetch_bases = False
+        nopf, _, _ = _hook_run(model, ids, n, teacher=toks)
+        model.model.prefetch_bases = True
+        assert all(torch.equal(a, b) for a, b in zip(fold, nopf)), "prefetched bases changed the result"
         model.model.graph_decode = True
         graph, _, past_g = _hook_run(model, ids, n, teacher=toks)
         assert model.model._hook_graph is not None, "the graph path was not taken"
@@ -361,6 +367,7 @@ def test_hook_decode_step_variants_agree(batch):
     finally:
         LlamaDecoderLayer_GEAR.fold_norm_weights = old
         model.model.graph_decode = False
+        model.model.prefetch_bases = True
 
 
 @pytest.mark.parametrize("batch, n_kv", [(1, 2), (2, 4), (6, 2)])

@@ -301,3 +301,28 @@ def test_fused_key_appends_into_a_pitched_cache(C):
         assert torch.equal(oidx[..., oo:oo + k].to(torch.int32), ri)
         assert torch.equal(oval[..., oo:oo + k], ref.oval.view(B, H, D, 2, k))
     assert int(code[..., 256 // fpi:].abs().max()) == 0 and float(Q[:, :, 256:].abs().max()) == 0.0
+
+
+def test_single_read_kernel_falls_back_per_head_and_stays_exact(C):
+    """csrc/kone.hip: a head whose threshold guess fails (here: columns of two values, so that every candidate list either
+    overflows or stays empty) is flagged inside the launch and redone by the exact kernel chain -- that head only; the other heads
+    keep the single-read result; the payload is the oracle's either way and no exchange wait runs into its bound."""
+    from gear_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(77)
+    B, H, T, D, k = 1, 4, 2048, 128, 12
+    x = torch.randn(B, H, T, D)
+    x[0, 2] = torch.where(torch.rand(T, D) < 0.5, torch.tensor(1.0), torch.tensor(-1.0))     # head 2: no tail beyond any threshold
+    x = x.half()
+    lib.gear_set_option(b"kfused_one", 1)
+    try:
+        f0, t0 = lib.gear_kone_fallback_heads(), lib.gear_kone_timeouts()
+        p = C.compress_key_fused(x.cuda(), 2, 64, k_out=k, mode="fp32")
+        assert lib.gear_kone_fallback_heads() - f0 == 1, "exactly the degenerate head takes the exact chain"
+        assert lib.gear_kone_timeouts() == t0
+        _check_payload(p, x.numpy(), k, 64, 2)
+        f1 = lib.gear_kone_fallback_heads()
+        p = C.compress_key_fused(randn_half(78, (B, H, T, D)).cuda(), 2, 64, k_out=k, mode="fp32")
+        assert lib.gear_kone_fallback_heads() == f1, "ordinary data: no head falls back"
+    finally:
+        lib.gear_set_option(b"kfused_one", 0)
