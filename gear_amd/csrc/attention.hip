@@ -80,6 +80,12 @@ struct AttnArgs {
     // log2 of group / seglen / (Hq / Hkv) when they are powers of two, else -1: the short-chunk kernel's index arithmetic then has
     // no integer division (each is ~20 vector instructions; the kernel is bound by instruction issue at batch 1)
     int gshift, seglen_shift, nrep_shift;
+    // merge folded into the partial kernel (round 6): 1 = every workgroup publishes its partial result with agent-scope stores,
+    // counts itself in on arrive[bhq] and the LAST one of a query head merges all of the head's partials into out_fold (what
+    // attn_decode_reduce_kernel does in a launch of its own)
+    int fold;
+    uint32_t* arrive;        // [B*Hq] arrival counters (zero between launches: the merging workgroup resets its head's)
+    uint16_t* out_fold;      // [B*Hq, 128]
 };
 __device__ __forceinline__ uint32_t div_sh(uint32_t x, int d, int sh) { return sh >= 0 ? x >> sh : x / (uint32_t)d; }
 
@@ -478,18 +484,107 @@ constexpr int SC = 128;
 // compressed cache -- one more chunk of the flash-decoding split, so that the reduce kernel only merges -- and, chunk after chunk,
 // for the UNCOMPRESSED fp16 cache that the reference's harness times beside the compressed models (cuda_supported_gear/test.py:41-62).
 // K: 8 threads per token (16 channels each), 32 tokens per pass; V: 16 threads per token row (8 channels each), 16 token subsets.
+// ---------------------------------------------------------------------------------------------------------------------
+// Publishing a chunk's partial result -- and, with a.fold, the merge of a query head's partials by the LAST workgroup to arrive.
+// Protocol (MI355X_MICROARCH.md, inter-workgroup visibility; the one block_fused.hip / kone.hip use): partials by agent-scope
+// (write-through) 8-byte stores, `s_waitcnt vmcnt(0)`, barrier, ONE returning agent-scope add on the head's counter; whoever reads
+// pslots - 1 is last, loads every partial with agent-scope loads and merges exactly as attn_decode_reduce_kernel does (same slot
+// partition, same order of additions: bit-identical output), then puts the counter back to 0.  Saves the reduce launch and the
+// kernel boundary in front of it (~6 us per layer at batch 1 against ~4 us of drain + counter + merge here).
+constexpr int RS_MAX_F = 66;     // (= RS_MAX below: 65 chunks of 128 tokens + the window)
+// arrival counters: eight regions of 65536 heads, a launch takes the next region (two launches in flight on different streams never
+// share a counter); zero at load time, zero again after every launch
+__device__ uint32_t g_attn_arrive[8 * 65536];
+
+typedef __attribute__((address_space(1))) unsigned long long attn_gu64;
+typedef __attribute__((address_space(1))) uint32_t attn_gu32;
+__device__ __forceinline__ void st_agent2f(float* p, float x, float y) {
+    __hip_atomic_store((attn_gu64*)p, (unsigned long long)__builtin_bit_cast(uint32_t, x) | ((unsigned long long)__builtin_bit_cast(uint32_t, y) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_agent2f(const float* p) {
+    const unsigned long long v = __hip_atomic_load((attn_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (uint32_t)v), __builtin_bit_cast(float, (uint32_t)(v >> 32)));
+}
+
+// o: this thread's channel (tid < 128) of the partial output; m, l: the chunk's maximum and exponent sum (block-uniform).
+// scr: >= 224 floats of LDS, og: >= 512 floats of LDS, both free at this point.  256 threads.
+template <bool FOLD_OK>
+__device__ __forceinline__ void part_publish(const AttnArgs& a, int64_t bhq, int slot, float o, float m, float l, float* __restrict__ scr,
+                                             float* __restrict__ og) {
+    const int tid = threadIdx.x;
+    const int64_t po = bhq * a.pslots + slot;
+    if (!FOLD_OK || !a.fold) {
+        if (tid < AD) a.part_o[po * AD + tid] = o;
+        if (tid == 0) {
+            a.part_ml[po * 2] = m;
+            a.part_ml[po * 2 + 1] = l;
+        }
+        return;
+    }
+    const float o2 = __shfl_down(o, 1, 64);
+    if (tid < AD && !(tid & 1)) st_agent2f(a.part_o + po * AD + tid, o, o2);
+    if (tid == 0) st_agent2f(a.part_ml + po * 2, m, l);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* flag = (uint32_t*)scr;
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add((attn_gu32*)(a.arrive + bhq), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ns = a.pslots;
+    if (flag[0] + 1u != (uint32_t)ns) return;
+    // ---- the last workgroup of this query head: merge
+    float* sml = scr + 8;                 // [2][RS_MAX_F]
+    float* coef = sml + 2 * RS_MAX_F;     // [RS_MAX_F]
+    float* stat = coef + RS_MAX_F + 3;    // [2]
+    const int d2 = tid & 63, grp = tid >> 6;
+    float2 mlv = make_float2(-INFINITY, 0.0f);
+    if (tid < ns) mlv = ld_agent2f(a.part_ml + (bhq * ns + tid) * 2);
+    constexpr int NPO = (RS_MAX_F + 3) / 4;
+    float2 pv[NPO];
+#pragma unroll
+    for (int i = 0; i < NPO; i++) {
+        const int sl = min(grp + 4 * i, ns - 1);                       // (clamped: every load unconditional)
+        pv[i] = ld_agent2f(a.part_o + (bhq * ns + sl) * AD + 2 * d2);
+    }
+    if (tid < RS_MAX_F) { sml[tid] = mlv.x; sml[RS_MAX_F + tid] = mlv.y; }
+    __syncthreads();
+    if (tid < 64) {   // softmax statistics over <= 65 slots: two slots per lane (attn_decode_reduce_kernel's arithmetic, no window)
+        const float m1 = tid < ns ? sml[tid] : -INFINITY, l1 = tid < ns ? sml[RS_MAX_F + tid] : 0.0f;
+        const float m2 = tid + 64 < ns ? sml[tid + 64] : -INFINITY, l2 = tid + 64 < ns ? sml[RS_MAX_F + tid + 64] : 0.0f;
+        float M = fmaxf(fmaxf(m1, m2), fmaxf(-INFINITY, -INFINITY));
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) M = fmaxf(M, __shfl_xor(M, x, 64));
+        const float c1 = tid < ns ? __expf(m1 - M) : 0.0f;
+        const float c2 = tid + 64 < ns ? __expf(m2 - M) : 0.0f;
+        coef[tid] = c1;
+        if (tid + 64 < RS_MAX_F) coef[tid + 64] = c2;
+        float L = fmaf(c1, l1, fmaf(c2, l2, 0.0f)) + 0.0f;
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) L += __shfl_xor(L, x, 64);
+        if (tid == 0) { stat[0] = M; stat[1] = L; }
+    }
+    __syncthreads();
+    float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPO; i++) {
+        const int sl = grp + 4 * i;
+        if (sl < ns) { o0 = fmaf(coef[sl], pv[i].x, o0); o1 = fmaf(coef[sl], pv[i].y, o1); }
+    }
+    og[grp * AD + 2 * d2] = o0;
+    og[grp * AD + 2 * d2 + 1] = o1;
+    __syncthreads();
+    if (tid < AD) a.out_fold[bhq * AD + tid] = f2h_bits(((og[tid] + og[AD + tid]) + (og[2 * AD + tid] + og[3 * AD + tid])) / stat[1]);
+    if (tid == 0) __hip_atomic_store((attn_gu32*)(a.arrive + bhq), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NREP>
 __device__ __forceinline__ void f16_chunk(const AttnArgs& a, const uint16_t* __restrict__ kb, const uint16_t* __restrict__ vb, int tn,
                                           int64_t bhq0, int slot, float* __restrict__ s, float (*__restrict__ op)[AD],
-                                          float* __restrict__ red) {
+                                          float* __restrict__ red, float* __restrict__ fscr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tn <= 0) {
 #pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            const int64_t pe = (bhq0 + r) * a.pslots + slot;
-            if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
-            if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
-        }
+        for (int r = 0; r < NREP; r++) part_publish<NREP == 1>(a, bhq0 + r, slot, 0.0f, -INFINITY, 0.0f, fscr, &op[0][0]);
         return;
     }
     const int part = tid & 7, j0 = tid >> 3;           // K: channels 16 part .., tokens j0 + 32 i
@@ -562,12 +657,9 @@ __device__ __forceinline__ void f16_chunk(const AttnArgs& a, const uint16_t* __r
             *(float4*)&op[wave][c8 * 8 + 4] = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
         __syncthreads();
-        const int64_t po = (bhq0 + r) * a.pslots + slot;
-        if (tid < AD) a.part_o[po * AD + tid] = (op[0][tid] + op[1][tid]) + (op[2][tid] + op[3][tid]);
-        if (tid == 0) {
-            a.part_ml[po * 2] = m;
-            a.part_ml[po * 2 + 1] = l;
-        }
+        const float ov = tid < AD ? (op[0][tid] + op[1][tid]) + (op[2][tid] + op[3][tid]) : 0.0f;
+        if (NREP == 1 && a.fold) __syncthreads();        // (op is about to be reused by the merge)
+        part_publish<NREP == 1>(a, bhq0 + r, slot, ov, m, l, fscr, &op[0][0]);
     }
 }
 
@@ -675,7 +767,8 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
     if (split == a.splits) {           // the extra workgroup of the row: the fp16 window as one more chunk (a.pslots == a.splits + 1)
         const int Wn = a.dyn ? a.dyn[3] : a.W;
-        f16_chunk<NREP>(a, a.kwin + bhk * a.wcap * (int64_t)AD, a.vwin + bhk * a.wcap * (int64_t)AD, Wn, bhq0, a.splits, s, op, red);
+        f16_chunk<NREP>(a, a.kwin + bhk * a.wcap * (int64_t)AD, a.vwin + bhk * a.wcap * (int64_t)AD, Wn, bhq0, a.splits, s, op, red,
+                        &sp[0][0]);
         return;
     }
     const int t0 = split * SC;
@@ -683,11 +776,7 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
     const int tn = min(SC, Tc - t0);
     if (tn <= 0) {
 #pragma unroll 1
-        for (int r = 0; r < NREP; r++) {
-            const int64_t pe = (bhq0 + r) * a.pslots + split;
-            if (tid < AD) a.part_o[pe * AD + tid] = 0.0f;
-            if (tid == 0) { a.part_ml[pe * 2] = -INFINITY; a.part_ml[pe * 2 + 1] = 0.0f; }
-        }
+        for (int r = 0; r < NREP; r++) part_publish<NREP == 1>(a, bhq0 + r, split, 0.0f, -INFINITY, 0.0f, &sp[0][0], &op[0][0]);
         return;
     }
     const ST* kscale = (const ST*)a.kscale;
@@ -796,7 +885,6 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
     float qv = qvr[0];
 #pragma unroll
     for (int rr = 1; rr < NREP; rr++) qv = (r == rr) ? qvr[rr] : qv;
-    const int64_t po = (bhq0 + r) * a.pslots + split;
     if (NREP > 1 && r > 0) __syncthreads();          // (the previous head's reads of the LDS arrays are done)
     // Outliers through the sparse tiles (the streaming cache's normal case) ride on the barriers the dense path has anyway: the
     // K entries are added into ksp[] while the dense scores are being computed, the V entries into vsp[] while the dense V products
@@ -1040,11 +1128,8 @@ __global__ __launch_bounds__(256, NREP == 1 ? 5 : 1) void attn_decode_partial_sm
         __syncthreads();
         if (tid < AD) o = oacc[tid];
     }
-    if (tid < AD) a.part_o[po * AD + tid] = o;
-    if (tid == 0) {
-        a.part_ml[po * 2] = m;
-        a.part_ml[po * 2 + 1] = l;
-    }
+    if (NREP == 1 && a.fold) __syncthreads();          // (sp / op are about to be reused by the merge)
+    part_publish<NREP == 1>(a, bhq0 + r, split, o, m, l, &sp[0][0], &op[0][0]);
     }   // query heads of the group
 }
 
@@ -1624,6 +1709,23 @@ __global__ __launch_bounds__(512) void attn_decode_reduce_kernel(AttnArgs a, con
     }
 }
 
+// arrival counters of a folded launch: the next of the eight regions of g_attn_arrive
+uint32_t* fold_counters() {
+    static uint32_t* base = nullptr;
+    static unsigned next = 0;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_attn_arrive)) != hipSuccess) return nullptr;
+    const unsigned r = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) & 7u;
+    return base + (size_t)r * 65536;
+}
+// fold the merge into the partial kernel?  Only with option attn_fold = 1.  Measured (round 6, 7B layer at 4k, caches rotated /
+// warm): batch 1 compressed 20.0 / 17.2 -> 19.7 / 18.3 us, fp16 baseline 18.4 -> 20.0 us, batch 4 43.7 -> 44.9 us, decode 335.8 ->
+// 331.6 tokens/s: the drain of the write-through partials + the returning counter add + the last workgroup's round trip for the
+// partials cost what the reduce launch and its boundary cost.  VERDICT r5 item 5's fold, built and not adopted.
+bool fold_wanted(int64_t n_workgroups) {
+    (void)n_workgroups;
+    return gear_options().attn_fold > 0;
+}
+
 int plan_splits(int T, int bits, int64_t bhq, bool fast_ranks, int* tc_out, bool* small) {
     *small = false;
     if (T <= 0) { *tc_out = 64; return 1; }
@@ -1814,6 +1916,8 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
     a.part_w = a.part_o + (size_t)B * Hq * a.pslots * AD;
     a.part_ml = a.part_w + (size_t)B * Hq * a.pslots * 16;
     hipStream_t st = (hipStream_t)stream;
+    a.fold = 0; a.arrive = nullptr; a.out_fold = (uint16_t*)out;
+    bool fold_possible = false;
     if (T > 0 || a.dyn) {
         dim3 grid(a.pslots, (unsigned)(B * Hq));
         // grouped-query attention on the short-chunk kernel: option attn_gqa_group = 1: one workgroup per (chunk, KV head) serves the
@@ -1830,6 +1934,11 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
         else hipLaunchKernelGGL((attn_decode_partial_small<BI, STT, RSV, 1>), grids, dim3(256), 0, st, a);                  \
     } while (0)
         const bool mf = mf_shape && a.pslots == a.splits;
+        // the merge inside the partial launch: vector short-chunk kernel with one query head per workgroup, nothing left for the
+        // reduce kernel but the merge (the window is a chunk of the split, or there is none), no log-sum-exp output wanted
+        fold_possible = small && !mf && nrep_t == 1 && !lse && (win_chunk || (W == 0 && !dyn_state)) && a.pslots <= RS_MAX_F &&
+                        fold_wanted((int64_t)B * Hq * a.pslots);
+        if (fold_possible && (a.arrive = fold_counters()) != nullptr) a.fold = 1;
         const dim3 gridm((unsigned)(nrep_m > 1 ? Hkv : Hq), a.pslots, (unsigned)B);
 #define GOM(BI, STT, RSV)                                                                                                  \
     do {                                                                                                                   \
@@ -1855,6 +1964,7 @@ int attn_decode_impl(const void* q, const void* kcode, const void* kscale, const
 #undef GOM
         GEAR_CHECK_LAUNCH("gear_attn_decode(partial)");
     }
+    if (a.fold) return 0;                                  // (the last workgroup of every query head has merged)
     hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(512), 0, st, a, (const uint16_t*)kwin,
                        (const uint16_t*)vwin, W, wcap, (uint16_t*)out, (float*)lse);
     GEAR_CHECK_LAUNCH("gear_attn_decode(reduce)");
@@ -1874,6 +1984,7 @@ __global__ __launch_bounds__(256) void attn_f16_partial_kernel(AttnArgs a, const
     __shared__ float s[SC];
     __shared__ float op[4][AD];
     __shared__ float red[8];
+    __shared__ float fscr[224];
     const int split = blockIdx.x;
     int b, hkv;
     int64_t bhq0;
@@ -1889,7 +2000,7 @@ __global__ __launch_bounds__(256) void attn_f16_partial_kernel(AttnArgs a, const
     const int64_t bhk = (int64_t)b * a.Hkv + hkv;
     const int t0 = split * SC;
     const int64_t row0 = (bhk * tcap + t0) * (int64_t)AD;
-    f16_chunk<NREP>(a, k + row0, v + row0, min(SC, a.T - t0), bhq0, split, s, op, red);
+    f16_chunk<NREP>(a, k + row0, v + row0, min(SC, a.T - t0), bhq0, split, s, op, red, fscr);
 }
 }  // namespace
 
@@ -1917,12 +2028,15 @@ extern "C" int gear_attn_decode_f16(const void* q, const void* k, const void* v,
     const bool group_on = gq > 0 || (gq < 0 && (int64_t)B * Hq * a.splits >= 32768);
     const int nrep_t = (group_on && (n_rep == 2 || n_rep == 4 || n_rep == 8)) ? n_rep : 1;
     const dim3 grid(a.splits, (unsigned)(nrep_t > 1 ? B * Hkv : B * Hq));
+    a.out_fold = (uint16_t*)out;
+    if (nrep_t == 1 && !lse && a.pslots <= RS_MAX_F && fold_wanted((int64_t)B * Hq * a.pslots) && (a.arrive = fold_counters()) != nullptr) a.fold = 1;
     const uint16_t *kp = (const uint16_t*)k, *vp = (const uint16_t*)v;
     if (nrep_t == 8) hipLaunchKernelGGL(attn_f16_partial_kernel<8>, grid, dim3(256), 0, st, a, kp, vp, tcap);
     else if (nrep_t == 4) hipLaunchKernelGGL(attn_f16_partial_kernel<4>, grid, dim3(256), 0, st, a, kp, vp, tcap);
     else if (nrep_t == 2) hipLaunchKernelGGL(attn_f16_partial_kernel<2>, grid, dim3(256), 0, st, a, kp, vp, tcap);
     else hipLaunchKernelGGL(attn_f16_partial_kernel<1>, grid, dim3(256), 0, st, a, kp, vp, tcap);
     GEAR_CHECK_LAUNCH("gear_attn_decode_f16(partial)");
+    if (a.fold) return 0;
     hipLaunchKernelGGL(attn_decode_reduce_kernel, dim3((unsigned)(B * Hq)), dim3(512), 0, st, a, (const uint16_t*)nullptr,
                        (const uint16_t*)nullptr, 0, 0, (uint16_t*)out, (float*)lse);
     GEAR_CHECK_LAUNCH("gear_attn_decode_f16(reduce)");

@@ -48,6 +48,9 @@ struct GearOptions {
                            // loaded once); 0 = one workgroup per query head (default: measured 2 - 3 x faster up to batch 4, profiles/
                            // r5_attn_experiments.md -- the repeated reads hit L2 and the chip wants the parallelism); -1 = by launch size
     int kfused_nslab;      // fused K path: slabs per head of k_main_kernel (0 = by head count)
+    int attn_fold;         // decode attention (vector short-chunk kernel, fp16 baseline): the merge of a head's partial results folded into
+                           // the partial launch (last-arriving workgroup merges): 1 = on; off by default (measured no faster than the
+                           // reduce kernel as a second launch: csrc/attention.hip, fold_wanted)
     int kfused_one;        // fused K path, fp32 arithmetic: the single-read kernel (kone.hip: selection + dense part + Gram in one launch):
                            // 1 = wherever its plan fits; 0 / -1 = never (select + main as two kernels: faster, profiles/r6_kone.md)
     int attn_mfma;         // decode attention, matrix-core variant of the short-chunk kernel: 0 = for grouped-query shapes with a

@@ -64,6 +64,17 @@ def _ref_attn(q, K, V, kw, vw, n_rep):
     return np.einsum("bht,bhtd->bhd", a, V)[:, :, None]
 
 
+@pytest.fixture(params=[0, 1], ids=["reduce-launch", "folded-merge"], autouse=True)
+def attn_fold(request):
+    """Every test of this module also runs with the merge of the attention's partial results folded into the partial launch (option
+    attn_fold: the last workgroup of a query head to arrive merges -- same slot partition, same order of additions as the reduce
+    kernel, so the same bits)."""
+    from gear_amd import _lib as L
+    L.load().gear_set_option(b"attn_fold", request.param)
+    yield request.param
+    L.load().gear_set_option(b"attn_fold", 0)
+
+
 @pytest.fixture
 def attn_option():
     """Select the generic (variable-chunk) decode-attention kernel for one test; always restored."""
