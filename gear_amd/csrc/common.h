@@ -51,6 +51,8 @@ struct GearOptions {
     int attn_fold;         // decode attention (vector short-chunk kernel, fp16 baseline): the merge of a head's partial results folded into
                            // the partial launch (last-arriving workgroup merges): 1 = on; off by default (measured no faster than the
                            // reduce kernel as a second launch: csrc/attention.hip, fold_wanted)
+    int kfused_main;       // fused K path, fp32 arithmetic: 1 = k_main_kernel (register-resident tiles with outlier masks, rounds 2 - 5) instead of
+                           // k_dense_kernel (LDS-resident slabs, substituted outliers, round 6)
     int kfused_one;        // fused K path, fp32 arithmetic: the single-read kernel (kone.hip: selection + dense part + Gram in one launch):
                            // 1 = wherever its plan fits; 0 / -1 = never (select + main as two kernels: faster, profiles/r6_kone.md)
     int attn_mfma;         // decode attention, matrix-core variant of the short-chunk kernel: 0 = for grouped-query shapes with a

@@ -54,6 +54,8 @@ const uint32_t* gear_kone_headfail(void* ws, int64_t BH, int T, int k);
 int gear_kone_launch(const void* x, int64_t BH, int T, int group, int bits, int k, void* code, void* scale, void* mn, int64_t ldc,
                      int64_t lds, int t_off, void* obits, void* oidx, void* oval, int kcap, int o_off, float* G, void* ws,
                      hipStream_t st);
+int gear_kdense_launch(const void* x, const void* obits, const void* omean, int64_t BH, int T, int group, int bits, void* code, void* scale,
+                       void* mn, int64_t ldc, int64_t lds, int t_off, float* gpart, int nwg, const uint32_t* only_if, hipStream_t st);
 
 namespace {
 
@@ -1193,6 +1195,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     float* gpart = rank > 0 ? (float*)(base + ws.gpart) : nullptr;
     float* Wws = rank > 0 ? (float*)(base + ws.W) : nullptr;
     const uint32_t* only_if = nullptr;
+    bool upper_gram = one;                   // the Gram matrices hold the upper 32x32 blocks only (k_solve_kernel mirrors on load)
     if (one) {
         const int rc = gear_kone_launch(x, BH, T, group, bits, k, code, scale, mn, ldc, lds, t_off, obits, oidx, oval, kcap, o_off, gpart,
                                         base + ws.kone, st);
@@ -1236,6 +1239,16 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     ma.gpart = gpart;                        // no error matrix in HBM: the Q pass rebuilds it (k_qpass_kernel)
     ma.only_if = only_if;
     const bool fast = (variant & 1) == 0 && !gear_options().kfused_generic, lr = rank > 0;
+    // fp32 arithmetic: the slab kernel of kone.hip (k_dense_kernel: LDS-resident 256-token slabs, outliers substituted, mask-free
+    // dense part, Gram in registers across the slabs) in place of k_main_kernel; variant bit 128 / option kfused_main keep k_main_kernel
+    bool dense_done = false;
+    if (mode == GEAR_MODE_FP32 && fast && !(variant & (128 | 4)) && !gear_options().kfused_main && !gear_options().kfused_no_tr) {
+        const int rc = gear_kdense_launch(x, obits, omean, BH, T, group, bits, code, scale, mn, ldc, lds, t_off, gpart, ws.nslab, only_if, st);
+        if (rc < 0) return rc;
+        dense_done = rc == 0;
+    }
+    upper_gram = upper_gram || dense_done;
+    if (!dense_done) {
     const bool tr = (variant & 4) == 0 && !gear_options().kfused_no_tr;
 #define KF_DISPATCH(B, M, GG, STT) launch_main<B, M, GG, STT>(ma, BH, fast, lr, tr, st)
     if (mode == GEAR_MODE_FP32) {
@@ -1248,11 +1261,12 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
 #undef KF_DISPATCH
     GEAR_CHECK_LAUNCH("gear_compress_key_fused(main)");
     }
+    }
 after_main:
     if (variant & 16) return 0;
     if (rank > 0) {
         const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
-        ksolve_launch(gpart, ws.nslab, loop, (const float*)P0, rank, BH, Wws, P_out, 1, p_inner, p_outer_stride, one ? 1 : 0, st);
+        ksolve_launch(gpart, ws.nslab, loop, (const float*)P0, rank, BH, Wws, P_out, 1, p_inner, p_outer_stride, upper_gram ? 1 : 0, st);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
         QpArgs qa;
         qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T;

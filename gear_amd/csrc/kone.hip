@@ -73,8 +73,14 @@ __device__ uint32_t g_kone_fallbacks = 0u;      // heads handed to the exact cha
 #ifdef GEAR_KO_CLK
 __device__ unsigned long long ko_clk_buf[16 * 16384];
 #define KO_CLK(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) ko_clk_buf[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define KD_CLK_DECL unsigned long long kd_t_ = __builtin_readcyclecounter(), kd_acc_[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long kd_t0_ = kd_t_
+#define KD_CLK(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); kd_acc_[k] += n_ - kd_t_; kd_t_ = n_; } while (0)
+#define KD_CLK_OUT do { const unsigned id_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && id_ < 16384) { ko_clk_buf[id_ * 16] = kd_t0_; for (int q_ = 0; q_ < 6; q_++) ko_clk_buf[id_ * 16 + 1 + q_] = kd_acc_[q_]; ko_clk_buf[id_ * 16 + 7] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define KO_CLK(k) do { } while (0)
+#define KD_CLK_DECL do { } while (0)
+#define KD_CLK(k) do { } while (0)
+#define KD_CLK_OUT do { } while (0)
 #endif
 
 struct KoArgs {
@@ -187,12 +193,16 @@ __device__ __forceinline__ void ko_dense(unsigned char* slab, int row0, int cp, 
     uint32_t base[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) base[r] = (uint32_t)row0 * 256u + (uint32_t)((((cp >> 2) + 4 * r) & 15) << 4) + (uint32_t)((cp & 3) << 2);
-    uint32_t w[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) w[i] = *(const uint32_t*)(slab + base[i & 3] + 256 * i);
+    // (two passes over the lane's 32 words in LDS -- min / max, then quantize half word by half word -- instead of 32 registers held
+    // across both: k_dense_kernel keeps 32 Gram accumulators alive through this function at four waves per SIMD)
     uint32_t lo2 = PINF, hi2 = NINF;
 #pragma unroll
-    for (int i = 0; i < 32; i++) { lo2 = pkmin16(lo2, w[i]); hi2 = pkmax16(hi2, w[i]); }
+    for (int i = 0; i < 32; i += 2) {       // (three-operand packed min / max of gfx950: two new words per instruction)
+        const uint32_t w0 = *(const uint32_t*)(slab + base[i & 3] + 256 * i);
+        const uint32_t w1 = *(const uint32_t*)(slab + base[(i + 1) & 3] + 256 * (i + 1));
+        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(lo2) : "v"(lo2), "v"(w0), "v"(w1));
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(hi2) : "v"(hi2), "v"(w0), "v"(w1));
+    }
     if (G == 64) {
         lo2 = pkmin16(lo2, (uint32_t)__shfl_xor((int)lo2, 32, 64));
         hi2 = pkmax16(hi2, (uint32_t)__shfl_xor((int)hi2, 32, 64));
@@ -228,24 +238,31 @@ __device__ __forceinline__ void ko_dense(unsigned char* slab, int row0, int cp, 
     qsA_o = qsA; loA_o = loA; qsB_o = qsB; loB_o = loB;
     const float2v inv2 = {invA, invB}, qs2 = {qsA, qsB}, mn2 = {loA, loB};
     const float nloA = -loA, nloB = -loB;
+    const float2v magic2 = {12582912.0f, 12582912.0f}, radix2 = {(float)(1 << BITS), (float)(1 << BITS)};
 #pragma unroll
     for (int hb = 0; hb < 32 / HC; hb++) {
         const int tb = hb * HC;
         float2v rq[HC];
         float dmax = 0.0f;
+        uint32_t w[HC];
+#pragma unroll
+        for (int j = 0; j < HC; j++) w[j] = *(const uint32_t*)(slab + base[(tb + j) & 3] + 256 * (tb + j));
+        // quotient by reciprocal multiply, rounded to an integer by the 1.5 * 2^23 addend inside ONE fused multiply-add (rint of the
+        // exact product; 0 <= quotient <= levels), distance to that integer by a second one: three packed fp32 instructions where
+        // multiply + 2 x v_rndne_f32 + subtract were four of the same issue class (profiles/r6_valu_rate.md)
 #pragma unroll
         for (int j = 0; j < HC; j++) {
-            const float2v t = {ko_mix<0>(w[tb + j], nloA), ko_mix<1>(w[tb + j], nloB)};
-            const float2v c = t * inv2;
-            const float2v rr = {rintf(c.x), rintf(c.y)};
-            const float2v d = c - rr;
+            const float2v t = {ko_mix<0>(w[j], nloA), ko_mix<1>(w[j], nloB)};
+            const float2v sb = __builtin_elementwise_fma(t, inv2, magic2);
+            const float2v rr = sb - magic2;
+            const float2v d = __builtin_elementwise_fma(t, inv2, -rr);
             rq[j] = rr;
             asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
         }
         if (dmax > TIE) {                                // within 1e-5 of a rounding tie: redo by exact division
 #pragma unroll
             for (int j = 0; j < HC; j++) {
-                const float xa = h2f_bits((uint16_t)(w[tb + j] & 0xFFFFu)), xb = h2f_bits((uint16_t)(w[tb + j] >> 16));
+                const float xa = h2f_bits((uint16_t)(w[j] & 0xFFFFu)), xb = h2f_bits((uint16_t)(w[j] >> 16));
                 rq[j].x = (qsA != 0.0f) ? rintf(div_rn(xa - loA, qsA)) : 0.0f;
                 rq[j].y = (qsB != 0.0f) ? rintf(div_rn(xb - loB, qsB)) : 0.0f;
             }
@@ -253,7 +270,7 @@ __device__ __forceinline__ void ko_dense(unsigned char* slab, int row0, int cp, 
         // every element lies in [mn, mx] (the substitutes too): 0 <= quotient <= levels, no clamp
         float2v hn = {0.0f, 0.0f};
 #pragma unroll
-        for (int j = HC - 1; j >= 0; j--) hn = hn * (float)(1 << BITS) + rq[j];      // exact: < 2^16
+        for (int j = HC - 1; j >= 0; j--) hn = __builtin_elementwise_fma(hn, radix2, rq[j]);      // exact: < 2^16
         const uint32_t hwA = (uint32_t)hn.x, hwB = (uint32_t)hn.y;
         if ((hb & 1) == 0) { cwA[hb >> 1] = hwA; cwB[hb >> 1] = hwB; }
         else { cwA[hb >> 1] |= hwA << 16; cwB[hb >> 1] |= hwB << 16; }
@@ -262,9 +279,12 @@ __device__ __forceinline__ void ko_dense(unsigned char* slab, int row0, int cp, 
             const float2v dq = rq[j] * qs2 + mn2;        // -ffp-contract=off: v_pk_mul_f32, v_pk_add_f32
             const uint32_t dw = f2h2_bits(dq.x, dq.y);
             uint32_t e2;
-            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(w[tb + j]), "v"(dw));
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(w[j]), "v"(dw));
             *(uint32_t*)(slab + base[(tb + j) & 3] + 256 * (tb + j)) = e2;
         }
+        // (no instruction moves across: without it the scheduler hoists the later blocks' LDS reads and conversions over this one and
+        // the function's live range grows by 60 registers -- which a wave alone cannot use anyway: profiles/r6_valu_rate.md)
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- the outlier slots: code = quant(mean) (fill, then quantize: compress_function.py:276-286), error = 0
     asm volatile("" ::: "memory");      // (the 2-byte stores below hit words stored above through another type: keep the order)
@@ -790,6 +810,220 @@ __global__ __launch_bounds__(KO_THREADS, 4) void k_one_kernel(KoArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- the chain's dense kernel
+// k_dense_kernel: what k_main_kernel (kfused.hip) does -- fill + quantize + pack + error + per-head Gram, behind k_select_kernel's
+// bitmap and row means -- with this file's slab machinery instead of register-resident tiles.  A workgroup of 256 threads walks
+// `spw` consecutive 128-token slabs of one head through TWO LDS buffers: the next slab arrives by LDS-DMA (global_load_lds_dwordx4,
+// no registers, nothing to wait for until the buffer is needed: the rotation of the slab layout is applied on the SOURCE side, lane
+// l of a 4-row piece fetching the 16-byte chunk that belongs at its linear place) while the current one is worked on:
+//   barrier -> substitute (the outliers of k_select's bitmap replaced in LDS by fp16(mean): one 2-byte store each) -> barrier ->
+//   dense part (ko_dense: mask-free, half of tile_fast's vector instructions; error left in place) -> barrier ->
+//   Gram: the ten upper 32x32 blocks of G = E^T E split 3 / 3 / 2 / 2 over the four waves, accumulated IN REGISTERS across the slabs.
+// No exchange, no atomics: the partial Gram matrix of the workgroup is stored once (upper blocks; k_solve_kernel mirrors on load
+// and adds the workgroups of a head).  Bit-identical payload to k_main_kernel (same arithmetic); the Gram sums differ in their
+// order of additions only.  (First version, 512 threads / 256-token slabs / register prefetch at four waves per SIMD: 1.0 ms against
+// k_main_kernel's 0.55 -- 128 registers do not hold the accumulators, the prefetch and the dense part, and a scratch reload
+// between a prefetch and its use waits for the prefetch.)
+struct KdArgs {
+    const uint16_t* x;       // [BH][T][128]
+    const uint32_t* obits;   // [BH][T/64][128][2] or null
+    const float* omean;      // [BH][128] (with obits)
+    int T, spw, nwg;         // slabs per workgroup, workgroups per head
+    uint32_t* code; void* scale; void* mn;
+    int64_t ldc, lds;
+    int t_off;
+    float* gpart;            // [BH][nwg][128][128] (upper 32x32 blocks written), or null
+    const uint32_t* only_if;
+};
+
+constexpr int KD_NT = 2;                  // 64-token tiles per slab
+constexpr int KD_ROWS = 64 * KD_NT;
+constexpr int KD_THREADS = 256;
+constexpr int KD_BUF = KD_ROWS * 256;     // bytes of one slab buffer
+constexpr int KD_XB = KD_NT * KD * 2 * 4; // bytes of one slab's bitmap
+constexpr int KD_LDS = 2 * KD_BUF + 2 * KD_XB + KD * 4;
+
+typedef short kd_s4 __attribute__((ext_vector_type(4)));
+
+// one LDS-DMA piece: 64 lanes x 16 bytes from the lanes' own global addresses to lds_addr + 16 lane (M0 saved and restored: the
+// compiler owns it).  Invisible to the compiler's wait counting: the caller waits (s_waitcnt vmcnt) before the data is read.
+__device__ __forceinline__ void kd_dma16(const void* g, uint32_t lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+// workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also drains the vector-memory queue: the DMA in flight)
+__device__ __forceinline__ void kd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// MFMA operand of k-step ks from the rotated slab through the compiler's own transposing read (its wait counts, its scheduling):
+// `off` = the lane's byte offset for k-step 0 (ko_operand's address), + 4096 per k-step (16 rows of 256 bytes, same rotation)
+__device__ __forceinline__ half8_t kd_operand(unsigned char* slab, uint32_t off) {
+    typedef __attribute__((address_space(3))) kd_s4* lp_t;
+    union { half8_t h; kd_s4 s[2]; } cv;
+    cv.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(slab + off));
+    cv.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(slab + off + 1024u));
+    return cv.h;
+}
+__device__ __forceinline__ uint32_t kd_operand_off(int S, int lane) {
+    const int kg = lane >> 5, i = lane & 15, c0 = 32 * S + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    return ko_off(8 * kg + (i >> 2), c0);
+}
+
+// Which upper 32x32 blocks a wave accumulates (kfused.hip's split: 10 operand-set reads per k-step over the workgroup)
+// w0: (0,0) (0,1) (1,1)   w1: (2,2) (2,3) (3,3)   w2: (0,2) (0,3)   w3: (1,2) (1,3)
+template <int W> struct KdBlocks;
+template <> struct KdBlocks<0> { static constexpr int n = 3; static constexpr int I[3] = {0, 0, 1}, J[3] = {0, 1, 1}; static constexpr int need = 0x3; };
+template <> struct KdBlocks<1> { static constexpr int n = 3; static constexpr int I[3] = {2, 2, 3}, J[3] = {2, 3, 3}; static constexpr int need = 0xC; };
+template <> struct KdBlocks<2> { static constexpr int n = 2; static constexpr int I[3] = {0, 0, 0}, J[3] = {2, 3, 3}; static constexpr int need = 0xD; };
+template <> struct KdBlocks<3> { static constexpr int n = 2; static constexpr int I[3] = {1, 1, 1}, J[3] = {2, 3, 3}; static constexpr int need = 0xE; };
+
+template <int W>
+__device__ __forceinline__ void kd_gram(unsigned char* buf, int ks_n, int lane, float16_t (&acc)[3]) {
+    typedef KdBlocks<W> WB;
+    uint32_t off[4];
+#pragma unroll
+    for (int S = 0; S < 4; S++) off[S] = kd_operand_off(S, lane);
+#pragma unroll 2
+    for (int ks = 0; ks < ks_n; ks++) {
+        half8_t f[4];
+#pragma unroll
+        for (int S = 0; S < 4; S++)
+            if (WB::need & (1 << S)) f[S] = kd_operand(buf, off[S] + 4096u * ks);
+#pragma unroll
+        for (int b = 0; b < WB::n; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[WB::I[b]], f[WB::J[b]], acc[b], 0, 0, 0);
+    }
+}
+template <int W>
+__device__ __forceinline__ void kd_gram_store(float* g, int lane, const float16_t (&acc)[3]) {
+    typedef KdBlocks<W> WB;
+    const int x31 = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < WB::n; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) g[(32 * WB::I[b] + (q & 3) + 8 * (q >> 2) + 4 * kg) * KD + 32 * WB::J[b] + x31] = acc[b][q];
+}
+
+template <int BITS, int G>
+__global__ __launch_bounds__(KD_THREADS, 2) void k_dense_kernel(KdArgs a) {
+    constexpr int CPW = 32 / BITS;
+    constexpr int NWL = 32 * BITS / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    float* mean_l = (float*)(sm + 2 * KD_BUF + 2 * KD_XB);            // [128]
+    const int wg = blockIdx.x;
+    const int64_t bh = blockIdx.y;
+    if (a.only_if && a.only_if[bh] == 0u) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, ntiles = T >> 6;
+    const int nslab = (ntiles + KD_NT - 1) / KD_NT;
+    const int s_lo = wg * a.spw, s_hi = min(nslab, s_lo + a.spw);
+    if (s_lo >= s_hi) return;                                         // (the launcher leaves no workgroup without a slab when gpart is read)
+    if (tid < KD) mean_l[tid] = a.obits ? a.omean[bh * KD + tid] : 0.0f;
+    if (!a.obits) {
+        for (int i = tid; i < 2 * KD_XB / 4; i += KD_THREADS) ((uint32_t*)(sm + 2 * KD_BUF))[i] = 0u;
+    }
+    float16_t acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[b][q] = 0.0f;
+    // DMA source of this lane inside a 4-row piece: row lane >> 4, the chunk whose rotated place is lane & 15
+    const unsigned char* xl = (const unsigned char*)(a.x + bh * (int64_t)T * KD) + (lane >> 4) * 256 + ((((lane & 15) - 4 * (lane >> 4)) & 15) << 4);
+    const unsigned char* bl = a.obits ? (const unsigned char*)(a.obits + bh * (int64_t)ntiles * (KD * 2)) + lane * 16 : nullptr;
+    const uint32_t sm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sm);
+    // wave w brings rows 32 w .. 32 w + 31 of the slab (8 pieces), waves 0 / 1 one half of the slab's bitmap each
+    auto dma_slab = [&](int slab, int b) {
+        const int row0 = slab * KD_ROWS + 32 * wave;
+        const unsigned char* g = xl + (int64_t)row0 * 256;
+        const uint32_t l = sm0 + (uint32_t)(b * KD_BUF + 32 * wave * 256);
+        if (row0 < T) {                                               // (T is a multiple of 64: a wave's 32 rows are all there or none is)
+#pragma unroll
+            for (int j = 0; j < 8; j++) kd_dma16(g + j * 1024, l + j * 1024);
+        }
+        if (bl && wave < KD_NT && slab * KD_NT + wave < ntiles) {
+            // (tile = 128 channels x 8 bytes = 1 KiB: the wave's piece)
+            kd_dma16(bl + (int64_t)(slab * KD_NT + wave) * 1024, sm0 + (uint32_t)(2 * KD_BUF + b * KD_XB + wave * 1024));
+        }
+    };
+    dma_slab(s_lo, 0);
+    const int btile = tid >> 7, bch = tid & 127;
+    KD_CLK_DECL;
+#pragma unroll 1
+    for (int slab = s_lo; slab < s_hi; slab++) {
+        const int b = (slab - s_lo) & 1;
+        unsigned char* buf = sm + b * KD_BUF;
+        const uint32_t* X = (const uint32_t*)(sm + 2 * KD_BUF + b * KD_XB);
+        const int ntl = min(KD_NT, ntiles - slab * KD_NT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the slab have landed
+        kd_barrier();                                                 // ... everyone's; and everyone is done with the other buffer
+        KD_CLK(0);
+        if (slab + 1 < s_hi) dma_slab(slab + 1, b ^ 1);
+        if (a.obits && btile < ntl) {   // substitute: one 2-byte store per outlier of (tile, channel)
+            const uint2 bm = *(const uint2*)&X[(btile * KD + bch) * 2];
+            unsigned long long m = (unsigned long long)bm.x | ((unsigned long long)bm.y << 32);
+            const uint16_t sv = f2h_bits(mean_l[bch]);
+            while (m) {
+                const int t = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                *(uint16_t*)(buf + ko_off(btile * 64 + t, bch)) = sv;
+            }
+        }
+        kd_barrier();
+        KD_CLK(1);
+        {
+            const int tl = wave >> 1;
+            if (tl < ntl) {
+                const int hf = lane >> 5, cp = 32 * (wave & 1) + (lane & 31);
+                const uint4 m4 = *(const uint4*)&X[(tl * KD + 2 * cp) * 2];                    // A.w0, A.w1, B.w0, B.w1
+                const uint32_t mA = hf ? m4.y : m4.x, mB = hf ? m4.w : m4.z;
+                const bool gA = G == 64 ? ((m4.x | m4.y) != 0u) : (mA != 0u), gB = G == 64 ? ((m4.z | m4.w) != 0u) : (mB != 0u);
+                const float meanA = mean_l[2 * cp], meanB = mean_l[2 * cp + 1];
+                uint32_t cwA[NWL], cwB[NWL];
+                float qsA, loA, qsB, loB;
+                ko_dense<BITS, G>(buf, tl * 64 + hf * 32, cp, hf, mA, mB, gA, gB, meanA, meanB, f2h_bits(meanA), f2h_bits(meanB), cwA, cwB,
+                                  qsA, loA, qsB, loB);
+                const int tok = a.t_off + (slab * KD_NT + tl) * 64 + hf * 32;
+                uint32_t* cA = a.code + (bh * KD + 2 * cp) * a.ldc + tok / CPW;
+                uint32_t* cB = cA + a.ldc;
+                if constexpr (NWL == 2) {
+                    *(uint2*)cA = make_uint2(cwA[0], cwA[1]);
+                    *(uint2*)cB = make_uint2(cwB[0], cwB[1]);
+                } else {
+                    *(uint4*)cA = make_uint4(cwA[0], cwA[1], cwA[2], cwA[3]);
+                    *(uint4*)cB = make_uint4(cwB[0], cwB[1], cwB[2], cwB[3]);
+                }
+                if (G == 32 || hf == 0) {
+                    float* sA = (float*)a.scale + (bh * KD + 2 * cp) * a.lds + tok / G;
+                    float* nA = (float*)a.mn + (bh * KD + 2 * cp) * a.lds + tok / G;
+                    sA[0] = qsA; nA[0] = loA; sA[a.lds] = qsB; nA[a.lds] = loB;
+                }
+            }
+        }
+        KD_CLK(2);
+        if (a.gpart) {
+            kd_barrier();
+            KD_CLK(3);
+            const int ks_n = ntl * 4;
+            switch (wave) {
+            case 0: kd_gram<0>(buf, ks_n, lane, acc); break;
+            case 1: kd_gram<1>(buf, ks_n, lane, acc); break;
+            case 2: kd_gram<2>(buf, ks_n, lane, acc); break;
+            default: kd_gram<3>(buf, ks_n, lane, acc); break;
+            }
+        }
+        KD_CLK(4);
+    }
+    KD_CLK_OUT;
+    if (!a.gpart) return;
+    float* g = a.gpart + (bh * a.nwg + wg) * (int64_t)(KD * KD);
+    switch (wave) {
+    case 0: kd_gram_store<0>(g, lane, acc); break;
+    case 1: kd_gram_store<1>(g, lane, acc); break;
+    case 2: kd_gram_store<2>(g, lane, acc); break;
+    default: kd_gram_store<3>(g, lane, acc); break;
+    }
+}
+
 inline size_t ko_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int KO_FIXED = 848;            // words of the fixed LDS part in front of the owner's list counters
@@ -875,6 +1109,34 @@ bool gear_kone_supported(int64_t BH, int T, int group, int bits, int mode, int k
 size_t gear_kone_workspace(int64_t BH, int T, int k) {
     KoPlan p;
     return ko_plan(BH, T, k, p) ? p.total + 256 : 0;
+}
+
+// The chain's dense kernel (k_dense_kernel above) in place of k_main_kernel: fp32 arithmetic, T a multiple of 64.  gpart receives
+// nwg upper-block partial Gram matrices per head (returned through *nwg_out).  Returns 1 when the shape is not taken.
+int gear_kdense_launch(const void* x, const void* obits, const void* omean, int64_t BH, int T, int group, int bits, void* code, void* scale,
+                       void* mn, int64_t ldc, int64_t lds, int t_off, float* gpart, int nwg, const uint32_t* only_if, hipStream_t st) {
+    if (T % 64 || (group != 64 && group != 32) || (bits != 2 && bits != 4) || BH > 65535 || nwg < 1) return 1;
+    const int nslab = (T / 64 + KD_NT - 1) / KD_NT;
+    if (nwg > nslab) return 1;                                      // (every partial Gram matrix the solve adds must be written)
+    KdArgs a;
+    a.x = (const uint16_t*)x; a.obits = (const uint32_t*)obits; a.omean = (const float*)omean; a.T = T;
+    a.nwg = nwg; a.spw = (nslab + nwg - 1) / nwg;
+    if ((int64_t)a.spw * (nwg - 1) >= nslab) return 1;              // (the last workgroup of a head would hold no slab)
+    a.code = (uint32_t*)code; a.scale = scale; a.mn = mn; a.ldc = ldc; a.lds = lds; a.t_off = t_off;
+    a.gpart = gpart; a.only_if = only_if;
+    const size_t shmem = (size_t)KD_LDS;
+    const dim3 grid((unsigned)nwg, (unsigned)BH);
+#define KD_GO(B, GG)                                                                                                    \
+    do {                                                                                                                \
+        auto kfn = k_dense_kernel<B, GG>;                                                                               \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);            \
+        hipLaunchKernelGGL(kfn, grid, dim3(KD_THREADS), shmem, st, a);                                                  \
+    } while (0)
+    if (bits == 2) { if (group == 64) KD_GO(2, 64); else KD_GO(2, 32); }
+    else { if (group == 64) KD_GO(4, 64); else KD_GO(4, 32); }
+#undef KD_GO
+    GEAR_CHECK_LAUNCH("gear_kdense_launch");
+    return 0;
 }
 
 // headfail (device, [BH] words): non-zero for the heads the caller must redo with the exact chain
