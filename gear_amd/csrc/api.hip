@@ -35,6 +35,7 @@ GearOptions& gear_options() {
         v.kfused_no_tr = flag("GEAR_KFUSED_NO_TR");
         auto ival = [](const char* n) { const char* e = getenv(n); return (e && *e) ? atoi(e) : 0; };
         v.gram_fused = ival("GEAR_GRAM_FUSED");
+        v.rows_masked = ival("GEAR_ROWS_MASKED");
         v.gram_nstg = ival("GEAR_GRAM_NSTG");
         v.decomp_general = ival("GEAR_DECOMP_GENERAL");
         v.attn_gqa_group = ival("GEAR_ATTN_GQA_GROUP");
@@ -54,7 +55,7 @@ extern "C" int gear_set_option(const char* name, int value) {
     GearOptions& o = gear_options();
     const struct { const char* n; int* p; } tab[] = {
         {"attn_generic", &o.attn_generic},     {"lowrank_generic", &o.lowrank_generic}, {"rows_hist_only", &o.rows_hist_only},
-        {"rows_v1", &o.rows_v1}, {"rows_wg_only", &o.rows_wg_only},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
+        {"rows_v1", &o.rows_v1}, {"rows_masked", &o.rows_masked}, {"rows_wg_only", &o.rows_wg_only},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
         {"kfused_no_tr", &o.kfused_no_tr}, {"gram_fused", &o.gram_fused}, {"gram_nstg", &o.gram_nstg},
         {"decomp_general", &o.decomp_general}, {"attn_gqa_group", &o.attn_gqa_group}, {"attn_win_chunk", &o.attn_win_chunk}, {"attn_keep_chunk_index", &o.attn_keep_chunk_index}, {"kfused_nslab", &o.kfused_nslab}, {"kfused_one", &o.kfused_one}, {"kfused_main", &o.kfused_main}, {"attn_fold", &o.attn_fold}, {"attn_mfma", &o.attn_mfma},
     };

@@ -37,6 +37,9 @@ struct GearOptions {
     int rows_hist_only;    // row compressor: always the radix-select (exact fallback) selection
     int rows_wg_only;      // row compressor: never the wave-per-row kernel (the workgroup kernel for every row)
     int rows_v1;           // row compressor: first-generation kernel also for fp32 arithmetic (cross-check)
+    int rows_masked;       // wave-per-row compressor, dense part: outlier masks (dense16) or the substituted row (dense16s, round 6: 6 % faster
+                           // without an error matrix, 5 % slower with one -- its 2-byte zero stores): 0 = substituted when no error
+                           // matrix is written, 1 = always masks, -1 = always substituted; same bits
     int kfused_generic;    // fused K path: the element-by-element tile body instead of the packed one
     int kselect_slow;      // fused K path: always the exact slow selection (no candidate lists)
     int kfused_no_tr;      // fused K path: 16-bit LDS reads for the MFMA operands instead of ds_read_b64_tr_b16

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
                                                                     int k, float zthr, float rlen, uint32_t* __restrict__ code,
                                                                     float* __restrict__ scale, float* __restrict__ mn,
                                                                     uint16_t* __restrict__ err, uint16_t* __restrict__ oidx,
-                                                                    uint16_t* __restrict__ oval, float* __restrict__ omean) {
+                                                                    uint16_t* __restrict__ oval, float* __restrict__ omean, int masked) {
     constexpr int LEN = 1024 * C;
     constexpr int CPW = 32 / BITS;
     constexpr int WW = LEN / 2 + 256 + 2 * (LEN / 32);     // words of LDS per wave: row image | candidates [2][128] | outlier bits [2][LEN/32]
@@ -1119,9 +1119,12 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
                 slot_l += side;
                 slot_h += 1u - side;
             }
-            // the raw copy of this lane's elements is dead: the slot becomes its half-word outlier marks
-            *(uint4*)&rowimg[c * 512 + lane * 8] = make_uint4(0, 0, 0, 0);
-            *(uint4*)&rowimg[c * 512 + lane * 8 + 4] = make_uint4(0, 0, 0, 0);
+            // (the raw copy stays: the selected elements are replaced in it by fp16(mean), and the dense part reads it back;
+            // option rows_masked: the slot becomes the lane's half-word outlier marks)
+            if (masked) {
+                *(uint4*)&rowimg[c * 512 + lane * 8] = make_uint4(0, 0, 0, 0);
+                *(uint4*)&rowimg[c * 512 + lane * 8 + 4] = make_uint4(0, 0, 0, 0);
+            }
         }
         for (int i = lane; i < 2 * (LEN / 32); i += 64) omask[i] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1152,19 +1155,21 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
             const int p0 = __popcll(b0 & lt), p1 = __popcll(b0) + __popcll(b1 & lt);
             uint16_t* oi = oidx + lrow * (int64_t)(2 * k) + (side == 0 ? k : 0);
             uint16_t* ov = oval + lrow * (int64_t)(2 * k) + (side == 0 ? k : 0);
+            // the selected element's stand-in in the staged row: fp16(mean) for dense16s, the 0xFFFF mark for dense16 (option rows_masked)
+            const uint16_t subst = masked ? (uint16_t)0xFFFFu : f2h_bits(mean);
             if (s0) {
                 const uint32_t idx = c0 & 0xFFFFu;
                 oi[p0] = (uint16_t)idx;
                 ov[p0] = (uint16_t)(c0 >> 16);
                 atomicOr(&omask[side * (LEN / 32) + (idx >> 5)], 1u << (idx & 31));
-                ((uint16_t*)rowimg)[idx] = (uint16_t)0xFFFFu;
+                ((uint16_t*)rowimg)[idx] = subst;
             }
             if (s1) {
                 const uint32_t idx = c1 & 0xFFFFu;
                 oi[p1] = (uint16_t)idx;
                 ov[p1] = (uint16_t)(c1 >> 16);
                 atomicOr(&omask[side * (LEN / 32) + (idx >> 5)], 1u << (idx & 31));
-                ((uint16_t*)rowimg)[idx] = (uint16_t)0xFFFFu;
+                ((uint16_t*)rowimg)[idx] = subst;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1179,6 +1184,19 @@ __global__ __launch_bounds__(256, (C <= 4 ? 4 : (C <= 5 ? 3 : 2))) void compress
         if (lane == 0 && omean) omean[r] = mean;
     }
     // ---------------- dense part, chunk by chunk
+    if constexpr (!SLOW) {
+        if (k > 0 && !masked) {
+            // the common path: the staged row with its outliers replaced by fp16(mean) -> the mask-free dense16s
+            const uint32_t sv = f2h_bits(mean);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint4 sa = *(const uint4*)&rowimg[c * 512 + lane * 8], sb = *(const uint4*)&rowimg[c * 512 + lane * 8 + 4];
+                const uint32_t rs[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+                dense16s<BITS>(rs, flag[c], mean, sv, group, gm.group_shift, lane, code_row, scale_row, mn_row, ooff[c], err_row, loff[c]);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const uint32_t rw[8] = {ra[c].x, ra[c].y, ra[c].z, ra[c].w, rb[c].x, rb[c].y, rb[c].z, rb[c].w};
@@ -1299,7 +1317,8 @@ int gear_compress_rows_geom(const void* x, int64_t n_rows, int rows_inner, int64
         if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
         hipLaunchKernelGGL(kfn, wg, dim3(256), wlds, st, (const uint16_t*)x, gm, n_rows, group, k, zthr,                \
                            1.0f / (float)len, (uint32_t*)code, (float*)scale, (float*)mn, (uint16_t*)err, (uint16_t*)oidx, \
-                           (uint16_t*)oval, (float*)omean);                                                             \
+                           (uint16_t*)oval, (float*)omean,                                   \
+                           (gear_options().rows_masked > 0 || (gear_options().rows_masked == 0 && err != nullptr)) ? 1 : 0);                                 \
     } while (0)
 #define GOWC(B)                                                                                                         \
     do {                                                                                                                \

@@ -200,4 +200,130 @@ __device__ __forceinline__ void dense16(const uint32_t (&rw)[8], const uint32_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dense16s: dense16 for a row whose outliers have been REPLACED by fp16(row mean) in the staged copy (one 2-byte LDS store per
+// outlier, where dense16's callers store a 0xFFFF mark): no mask anywhere in the common path -- plain packed min / max
+// (three-operand forms), no clamp (every element, the substitutes included, lies inside [mn, mx]), the quotient rounded inside
+// a fused multiply-add (1.5 * 2^23 addend: rint of the exact product) with a second one for the distance to the tie, the
+// outlier slots' error cleared by 2-byte stores behind the row's 16-byte ones.  `outl` = the lane's 16 outlier flags, `sv` = the
+// substitute's bits.  Same bits as dense16: a group in which the substitute is itself the minimum or maximum (then the
+// non-outlier range is not what the substituted data shows) sends the whole WAVE through dense16 with masks rebuilt from the flags.
+template <int BITS>
+__device__ __forceinline__ void dense16s(const uint32_t (&rs)[8], uint32_t outl, float mean, uint32_t sv, int group, int group_shift,
+                                         int lane, uint32_t* __restrict__ code_row, float* __restrict__ scale_row,
+                                         float* __restrict__ mn_row, uint32_t ooff, uint16_t* __restrict__ err_row, uint32_t loff) {
+    constexpr int LEVELS = (1 << BITS) - 1;
+    constexpr int WPL = BITS / 2;
+    constexpr int CPW = 32 / BITS;
+    constexpr int HC = 16 / BITS;
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    uint32_t lo2 = rs[0], hi2 = rs[0];
+#pragma unroll
+    for (int w = 1; w < 7; w += 2) {
+        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(lo2) : "v"(lo2), "v"(rs[w]), "v"(rs[w + 1]));
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(hi2) : "v"(hi2), "v"(rs[w]), "v"(rs[w + 1]));
+    }
+    lo2 = pkmin16(lo2, rs[7]);
+    hi2 = pkmax16(hi2, rs[7]);
+    float lo = fmin_raw(h2f_bits((uint16_t)(lo2 & 0xFFFFu)), h2f_bits((uint16_t)(lo2 >> 16)));
+    float hi = fmax_raw(h2f_bits((uint16_t)(hi2 & 0xFFFFu)), h2f_bits((uint16_t)(hi2 >> 16)));
+    float gf = outl ? 1.0f : 0.0f;                        // does the group hold an outlier?
+    const int lanes_per_group = group / 16;
+    if (lanes_per_group == 4) {   // the usual group of 64: the four lanes of a DPP quad
+#define GEAR_D16_DPP(v, ctl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctl, 0xF, 0xF, true))
+        lo = fmin_raw(lo, GEAR_D16_DPP(lo, 0xB1)); hi = fmax_raw(hi, GEAR_D16_DPP(hi, 0xB1)); gf = fmax_raw(gf, GEAR_D16_DPP(gf, 0xB1));
+        lo = fmin_raw(lo, GEAR_D16_DPP(lo, 0x4E)); hi = fmax_raw(hi, GEAR_D16_DPP(hi, 0x4E)); gf = fmax_raw(gf, GEAR_D16_DPP(gf, 0x4E));
+#undef GEAR_D16_DPP
+    } else {
+        for (int mm = 1; mm < lanes_per_group; mm <<= 1) {
+            lo = fminf(lo, __shfl_xor(lo, mm, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, mm, 64));
+            gf = fmaxf(gf, __shfl_xor(gf, mm, 64));
+        }
+    }
+    const bool g = gf != 0.0f;
+    {
+        const float fs = h2f_bits((uint16_t)sv);
+        if (__any(g && (lo == fs || hi == fs))) {
+            uint32_t m[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) m[w] = (((outl >> (2 * w)) & 1u) ? 0x0000FFFFu : 0u) | (((outl >> (2 * w + 1)) & 1u) ? 0xFFFF0000u : 0u);
+            dense16<BITS>(rs, m, outl, mean, group, group_shift, lane, code_row, scale_row, mn_row, ooff, err_row, loff);
+            return;
+        }
+    }
+    lo = fmin_raw(lo, g ? mean : INFINITY);
+    hi = fmax_raw(hi, g ? mean : -INFINITY);
+    const float qscale = div_rn(hi - lo, (float)LEVELS), qmn = lo;        // make_qparams<1>
+    const float inv = (qscale != 0.0f) ? __builtin_amdgcn_rcpf(qscale) : 0.0f;
+    constexpr float TIE = (BITS == 8) ? 0.499f : 0.49999f;
+    float2v rq[8];
+    const float one = 1.0f, negmn = -qmn;
+    const float2v inv2 = {inv, inv}, magic2 = {12582912.0f, 12582912.0f};
+    float dmax = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const float2v t = {sub_mix<0>(rs[w], one, negmn), sub_mix<1>(rs[w], one, negmn)};
+        const float2v sb = __builtin_elementwise_fma(t, inv2, magic2);
+        const float2v rr = sb - magic2;
+        const float2v d = __builtin_elementwise_fma(t, inv2, -rr);
+        rq[w] = rr;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(dmax) : "v"(dmax), "v"(d.x), "v"(d.y));
+    }
+    if (dmax > TIE) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const float xa = h2f_bits((uint16_t)(rs[w] & 0xFFFFu)), xb = h2f_bits((uint16_t)(rs[w] >> 16));
+            rq[w].x = (qscale != 0.0f) ? rintf(div_rn(xa - qmn, qscale)) : 0.0f;
+            rq[w].y = (qscale != 0.0f) ? rintf(div_rn(xb - qmn, qscale)) : 0.0f;
+        }
+    }
+    uint32_t words[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; w++) {
+        uint32_t hw[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int p0 = (w * CPW + hf * HC) / 2;          // first element pair of the half word
+            float2v ab = rq[p0 + HC / 2 - 1];
+            const float2v base2 = {(float)(1 << (2 * BITS)), (float)(1 << (2 * BITS))};
+#pragma unroll
+            for (int i = HC / 2 - 2; i >= 0; i--) ab = __builtin_elementwise_fma(ab, base2, rq[p0 + i]);
+            hw[hf] = (uint32_t)fmaf(ab.y, (float)(1 << BITS), ab.x);
+        }
+        words[w] = hw[0] | (hw[1] << 16);
+    }
+    if (outl) {   // filled positions: every outlier of the group carries quant(mean)
+        const float cq = (mean - qmn) * inv;
+        float cm = rintf(cq);
+        if (fabsf(cq - cm) > TIE) cm = (qscale != 0.0f) ? rintf(div_rn(mean - qmn, qscale)) : 0.0f;
+        cm = __builtin_amdgcn_fmed3f(cm, 0.0f, (float)LEVELS);
+        const uint32_t qrep = (uint32_t)cm * (0xFFFFFFFFu / (uint32_t)LEVELS);
+#pragma unroll
+        for (int w = 0; w < WPL; w++) words[w] = bfi32(spread_flags<BITS>(outl >> (w * CPW)), qrep, words[w]);
+    }
+    uint32_t* cp = code_row + ooff / CPW;
+#pragma unroll
+    for (int w = 0; w < WPL; w++) cp[w] = words[w];
+    if ((lane & (lanes_per_group - 1)) == 0) {
+        scale_row[ooff >> group_shift] = qscale;
+        mn_row[ooff >> group_shift] = qmn;
+    }
+    if (err_row) {
+        uint32_t ew[8];
+        const float2v qs2 = {qscale, qscale}, mn2 = {qmn, qmn};
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const float2v dq = rq[w] * qs2 + mn2;            // -ffp-contract=off: v_pk_mul_f32 then v_pk_add_f32 (two roundings)
+            const uint32_t dw = f2h2_bits(dq.x, dq.y);
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ew[w]) : "v"(rs[w]), "v"(dw));
+        }
+        uint4* ep = (uint4*)(err_row + loff);
+        ep[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]);
+        ep[1] = make_uint4(ew[4], ew[5], ew[6], ew[7]);
+        // (same thread, same addresses, program order: the zeros land on top of the row's stores)
+        for (uint32_t mm = outl; mm; mm &= mm - 1u) err_row[loff + (uint32_t)__builtin_ctz(mm)] = (uint16_t)0u;
+    }
+}
+
 }  // namespace
