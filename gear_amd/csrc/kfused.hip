@@ -55,7 +55,9 @@ int gear_kone_launch(const void* x, int64_t BH, int T, int group, int bits, int 
                      int64_t lds, int t_off, void* obits, void* oidx, void* oval, int kcap, int o_off, float* G, void* ws,
                      hipStream_t st);
 int gear_kdense_launch(const void* x, const void* obits, const void* omean, int64_t BH, int T, int group, int bits, void* code, void* scale,
-                       void* mn, int64_t ldc, int64_t lds, int t_off, float* gpart, int nwg, const uint32_t* only_if, hipStream_t st);
+                       void* mn, int64_t ldc, int64_t lds, int t_off, float* gpart, void* eout, int nwg, const uint32_t* only_if, hipStream_t st);
+int gear_lr_qpass_tm_launch(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_f16, int q_tcap, int q_toff,
+                            hipStream_t st);
 
 namespace {
 
@@ -1069,7 +1071,7 @@ double inv_norm_cdf(double p) {  // Acklam's rational approximation (relative er
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KfWs {       // workspace carve-up
-    size_t obits, omean, gpart, W, todo, kone, total;
+    size_t obits, omean, gpart, W, todo, kone, err, total;
     int nslab, tiles_per_slab;
 };
 // one: the single-read kernel (kone.hip) does selection + dense part + Gram; its Gram matrix is ONE matrix per head
@@ -1094,6 +1096,8 @@ KfWs kf_workspace(int64_t BH, int T, int k, int rank, bool one = false) {
     w.W = off;     off += align256(rank > 0 ? (size_t)BH * KD * RP * 4 : 0);
     w.todo = off;  off += align256(k > 0 ? 256 + (size_t)BH * 256 * 4 : 0);   // counter (first 256 bytes) + list ids
     w.kone = off;  off += align256(one ? gear_kone_workspace(BH, T, k) : 0);
+    // the error matrix k_dense_kernel writes for the Q pass (option kfused_eout)
+    w.err = off;   off += align256(rank > 0 && gear_options().kfused_eout > 0 ? (size_t)BH * T * KD * 2 : 0);
     w.total = off + 256;
     return w;
 }
@@ -1196,6 +1200,7 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     float* Wws = rank > 0 ? (float*)(base + ws.W) : nullptr;
     const uint32_t* only_if = nullptr;
     bool upper_gram = one;                   // the Gram matrices hold the upper 32x32 blocks only (k_solve_kernel mirrors on load)
+    void* eq = nullptr;                      // the error matrix k_dense_kernel has written for the Q pass (option kfused_eout), if any
     if (one) {
         const int rc = gear_kone_launch(x, BH, T, group, bits, k, code, scale, mn, ldc, lds, t_off, obits, oidx, oval, kcap, o_off, gpart,
                                         base + ws.kone, st);
@@ -1242,11 +1247,13 @@ extern "C" int gear_compress_key_fused(const void* x, int64_t BH, int T, int gro
     // fp32 arithmetic: the slab kernel of kone.hip (k_dense_kernel: LDS-resident 256-token slabs, outliers substituted, mask-free
     // dense part, Gram in registers across the slabs) in place of k_main_kernel; variant bit 128 / option kfused_main keep k_main_kernel
     bool dense_done = false;
+    void* eout = (rank > 0 && gear_options().kfused_eout > 0 && !only_if) ? (void*)(base + ws.err) : nullptr;
     if (mode == GEAR_MODE_FP32 && fast && !(variant & (128 | 4)) && !gear_options().kfused_main && !gear_options().kfused_no_tr) {
-        const int rc = gear_kdense_launch(x, obits, omean, BH, T, group, bits, code, scale, mn, ldc, lds, t_off, gpart, ws.nslab, only_if, st);
+        const int rc = gear_kdense_launch(x, obits, omean, BH, T, group, bits, code, scale, mn, ldc, lds, t_off, gpart, eout, ws.nslab, only_if, st);
         if (rc < 0) return rc;
         dense_done = rc == 0;
     }
+    if (dense_done) eq = eout;
     upper_gram = upper_gram || dense_done;
     if (!dense_done) {
     const bool tr = (variant & 4) == 0 && !gear_options().kfused_no_tr;
@@ -1268,6 +1275,8 @@ after_main:
         const int RP = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
         ksolve_launch(gpart, ws.nslab, loop, (const float*)P0, rank, BH, Wws, P_out, 1, p_inner, p_outer_stride, upper_gram ? 1 : 0, st);
         GEAR_CHECK_LAUNCH("gear_compress_key_fused(solve)");
+        if (eq)                      // the error matrix is in the workspace: the token-major MFMA Q pass of the V chain reads it
+            return gear_lr_qpass_tm_launch(eq, Wws, BH, T, rank, Q_out, 1, q_tcap, q_toff, st);
         QpArgs qa;
         qa.x = (const uint16_t*)x; qa.obits = obits; qa.T = T;
         qa.code = (const uint32_t*)code; qa.scale = scale; qa.mn = mn; qa.ldc = ldc; qa.lds = lds; qa.t_off = t_off;

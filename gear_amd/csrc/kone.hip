@@ -833,6 +833,7 @@ struct KdArgs {
     int64_t ldc, lds;
     int t_off;
     float* gpart;            // [BH][nwg][128][128] (upper 32x32 blocks written), or null
+    uint16_t* eout;          // [BH][T][128] fp16: the error matrix written out for the Q pass (lr_qpass_tm_mfma_kernel), or null
     const uint32_t* only_if;
 };
 
@@ -1003,6 +1004,15 @@ __global__ __launch_bounds__(KD_THREADS, 2) void k_dense_kernel(KdArgs a) {
         if (a.gpart) {
             kd_barrier();
             KD_CLK(3);
+            if (a.eout && 32 * wave < 64 * ntl) {
+                // the error rows 32 wave .. + 31 of the slab leave for the Q pass: linear 16-byte LDS reads, the rotation undone
+                // on the global side -- every store instruction covers four whole 256-byte rows.  The kernel is bound by its vector
+                // instructions, the writes ride under them.
+                uint16_t* eg = a.eout + (bh * T + (int64_t)slab * KD_ROWS + 32 * wave + (lane >> 4)) * KD + 8 * (((lane & 15) - 4 * (lane >> 4)) & 15);
+                const unsigned char* el = buf + (32 * wave) * 256 + lane * 16;
+#pragma unroll
+                for (int j = 0; j < 8; j++) *(uint4*)(eg + j * 4 * KD) = *(const uint4*)(el + j * 1024);
+            }
             const int ks_n = ntl * 4;
             switch (wave) {
             case 0: kd_gram<0>(buf, ks_n, lane, acc); break;
@@ -1114,7 +1124,7 @@ size_t gear_kone_workspace(int64_t BH, int T, int k) {
 // The chain's dense kernel (k_dense_kernel above) in place of k_main_kernel: fp32 arithmetic, T a multiple of 64.  gpart receives
 // nwg upper-block partial Gram matrices per head (returned through *nwg_out).  Returns 1 when the shape is not taken.
 int gear_kdense_launch(const void* x, const void* obits, const void* omean, int64_t BH, int T, int group, int bits, void* code, void* scale,
-                       void* mn, int64_t ldc, int64_t lds, int t_off, float* gpart, int nwg, const uint32_t* only_if, hipStream_t st) {
+                       void* mn, int64_t ldc, int64_t lds, int t_off, float* gpart, void* eout, int nwg, const uint32_t* only_if, hipStream_t st) {
     if (T % 64 || (group != 64 && group != 32) || (bits != 2 && bits != 4) || BH > 65535 || nwg < 1) return 1;
     const int nslab = (T / 64 + KD_NT - 1) / KD_NT;
     if (nwg > nslab) return 1;                                      // (every partial Gram matrix the solve adds must be written)
@@ -1123,7 +1133,7 @@ int gear_kdense_launch(const void* x, const void* obits, const void* omean, int6
     a.nwg = nwg; a.spw = (nslab + nwg - 1) / nwg;
     if ((int64_t)a.spw * (nwg - 1) >= nslab) return 1;              // (the last workgroup of a head would hold no slab)
     a.code = (uint32_t*)code; a.scale = scale; a.mn = mn; a.ldc = ldc; a.lds = lds; a.t_off = t_off;
-    a.gpart = gpart; a.only_if = only_if;
+    a.gpart = gpart; a.eout = gpart ? (uint16_t*)eout : nullptr; a.only_if = only_if;
     const size_t shmem = (size_t)KD_LDS;
     const dim3 grid((unsigned)nwg, (unsigned)BH);
 #define KD_GO(B, GG)                                                                                                    \

@@ -551,6 +551,19 @@ int run_gram(const uint16_t* E, int transposed, int64_t bh, int S, int r, int lo
 
 }  // namespace
 
+// Q' = E W alone (token-major fp16 E [bh][S][128], W [bh][128][RP] from the solve): the fused K chain's Q pass when k_dense_kernel
+// has written the error matrix out (kfused.hip)
+int gear_lr_qpass_tm_launch(const void* E, const float* W, int64_t bh, int S, int r, void* Q_out, int out_f16, int q_tcap, int q_toff,
+                            hipStream_t st) {
+    const int RP = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
+    const dim3 grid((unsigned)((S + 511) / 512), (unsigned)bh);
+    if (RP == 4) hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<4>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, out_f16, q_tcap, q_toff);
+    else if (RP == 8) hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<8>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, out_f16, q_tcap, q_toff);
+    else hipLaunchKernelGGL((lr_qpass_tm_mfma_kernel<16>), grid, dim3(256), 0, st, (const uint16_t*)E, W, S, r, Q_out, out_f16, q_tcap, q_toff);
+    GEAR_CHECK_LAUNCH("gear_lr_qpass_tm_launch");
+    return 0;
+}
+
 // workspace of the Gram path: W [bh][128][RP] floats, then the slabs' partial Gram matrices [bh][nslab][128][128]
 size_t gear_lowrank_gram_workspace(int64_t bh, int S, int RP) {
     return (((size_t)bh * GD * RP * 4 + 255) & ~(size_t)255) + (size_t)bh * gram_nslab(bh, S) * GD * GD * 4 + 512;

@@ -37,9 +37,12 @@ def C():
     return compress
 
 
-@pytest.fixture(params=["chain", "one"], autouse=True)
+@pytest.fixture(params=["chain", "one", "main", "eout"], autouse=True)
 def kpath(request):
-    """Every test of this module runs twice: through the kernel chain (select -> main -> solve -> Q pass) and with the single-read
+    """Every test of this module runs four times: through the kernel chain (select -> dense -> solve -> Q pass; fp32 arithmetic:
+    k_dense_kernel, csrc/kone.hip), through the chain with the register-tile kernel of rounds 2 - 5 in its place (option
+    kfused_main: k_main_kernel), through the chain with the error matrix written by k_dense_kernel and read by the MFMA Q pass
+    (option kfused_eout) and with the single-read
     kernel of csrc/kone.hip (selection + dense part + Gram in one launch, the slabs of a head exchanging candidates inside the
     launch) wherever its plan takes the shape (fp32 arithmetic; variants 2 / 8 / 32 / 64 and the fp16-stepwise mode keep the chain).
     No exchange wait may have run into its bound, and -- ordinary data -- no head may have needed the exact fall-back chain unless
@@ -47,9 +50,13 @@ def kpath(request):
     from gear_amd import _lib as L
     lib = L.load()
     lib.gear_set_option(b"kfused_one", 1 if request.param == "one" else -1)
+    lib.gear_set_option(b"kfused_main", 1 if request.param == "main" else 0)
+    lib.gear_set_option(b"kfused_eout", 1 if request.param == "eout" else 0)
     t0 = lib.gear_kone_timeouts()
     yield request.param
     lib.gear_set_option(b"kfused_one", 0)
+    lib.gear_set_option(b"kfused_main", 0)
+    lib.gear_set_option(b"kfused_eout", 0)
     assert lib.gear_kone_timeouts() == t0, "an exchange wait of the single-read K kernel timed out"
 
 
