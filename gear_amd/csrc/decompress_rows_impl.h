@@ -68,7 +68,7 @@ struct DGeom {
 // RV: compile-time rank (4 / 8 / 16) or 0 for the generic runtime-rank path.
 // TB: launch bound bucket (256 / 512 / 1024 threads) -- the register budget for the 16 x r factor block.
 template <int BITS, int MODE, typename ST, int KIND, int RV, int TB>
-__global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __restrict__ code, const ST* __restrict__ scale,
+__global__ __launch_bounds__(TB, (TB == 256 ? 2 : 1)) void decompress_rows_kernel(const uint32_t* __restrict__ code, const ST* __restrict__ scale,
                                        const ST* __restrict__ mn, DGeom g, const uint16_t* __restrict__ P,
                                        const uint16_t* __restrict__ Q, const uint16_t* __restrict__ oidx,
                                        const uint16_t* __restrict__ oval, uint16_t* __restrict__ out) {
@@ -261,10 +261,13 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             fill_table(ri);
         }
     };
-    // (swp: exchange the store halves between lanes l and l + 32 -- every lane of the wave must be in this call)
-    auto compute_row = [&](int ri, const RowIn& cur, const bool table, const bool swp) __attribute__((always_inline)) {
+    // the dequantized row as packed fp16, outlier values restored
+    auto dense_row = [&](int ri, const uint32_t (&words)[WPL], float cs, float cm, const bool table, uint4& d0, uint4& d1) __attribute__((always_inline)) {
+        struct { uint32_t words[WPL]; float s, m; } cur;
+#pragma unroll
+        for (int w = 0; w < WPL; w++) cur.words[w] = words[w];
+        cur.s = cs; cur.m = cm;
         float f[16];
-        uint4 d0, d1;
         if constexpr (BITS == 2) {
             // Two-bit codes: a group has four dequantized values.  Compute them once per row-lane (the lane's 16 columns lie
             // in one group), keep them as two packed-fp16 registers and let v_perm_b32 pick the pair of every output word:
@@ -316,6 +319,36 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             d0 = make_uint4(sel(t0.x, d0.x), sel(t0.y, d0.y), sel(t0.z, d0.z), sel(t0.w, d0.w));
             d1 = make_uint4(sel(t1.x, d1.x), sel(t1.y, d1.y), sel(t1.z, d1.z), sel(t1.w, d1.w));
         }
+    };
+    // the lane's 32 bytes of a row -> memory (swp: the store halves exchanged between lanes l and l + 32 -- every lane of the wave
+    // must be in this call)
+    auto store_row = [&](int off, uint4 d0, uint4 d1, const bool swp) __attribute__((always_inline)) {
+        if (swp) {
+            // Full lines per store instruction: a lane's 32 bytes as two 16-byte stores cover every 128-byte line of the wave's
+            // 2 KB half per instruction, and with reads in flight the half-written lines cost a sixth of the write rate
+            // (tools/ubench/store_pattern3.hip: 3.9 -> 4.8 TB/s).  v_permlane32_swap puts both halves of the lower 32 lanes
+            // into the first instruction (lanes >= 32 carry the second halves) and those of the upper 32 lanes into the second.
+            // (the builtin, not inline asm: the instruction needs wait states after a vector write of its operands, which the
+            // compiler only inserts for instructions it knows -- with asm the first word of a block's first row came out wrong)
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(d0.x, d1.x, false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(d0.y, d1.y, false, false);
+            const u32x2 s2 = __builtin_amdgcn_permlane32_swap(d0.z, d1.z, false, false);
+            const u32x2 s3 = __builtin_amdgcn_permlane32_swap(d0.w, d1.w, false, false);
+            d0 = make_uint4(s0.x, s1.x, s2.x, s3.x);
+            d1 = make_uint4(s0.y, s1.y, s2.y, s3.y);
+            *(uint4*)(outb + off + st_a) = d0;
+            *(uint4*)(outb + off + st_b) = d1;
+        } else {
+            uint4* op = (uint4*)(outb + off);
+            op[0] = d0;
+            op[1] = d1;
+        }
+    };
+    // (swp: exchange the store halves between lanes l and l + 32 -- every lane of the wave must be in this call)
+    auto compute_row = [&](int ri, const RowIn& cur, const bool table, const bool swp) __attribute__((always_inline)) {
+        float f[16];
+        uint4 d0, d1;
+        dense_row(ri, cur.words, cur.s, cur.m, table, d0, d1);
         if (r > 0) {
             if (RV > 0) {
                 unpack8(d0, f);
@@ -350,26 +383,7 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
                 d1 = pack8(f + 8);
             }
         }
-        if (swp) {
-            // Full lines per store instruction: a lane's 32 bytes as two 16-byte stores cover every 128-byte line of the wave's
-            // 2 KB half per instruction, and with reads in flight the half-written lines cost a sixth of the write rate
-            // (tools/ubench/store_pattern3.hip: 3.9 -> 4.8 TB/s).  v_permlane32_swap puts both halves of the lower 32 lanes
-            // into the first instruction (lanes >= 32 carry the second halves) and those of the upper 32 lanes into the second.
-            // (the builtin, not inline asm: the instruction needs wait states after a vector write of its operands, which the
-            // compiler only inserts for instructions it knows -- with asm the first word of a block's first row came out wrong)
-            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(d0.x, d1.x, false, false);
-            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(d0.y, d1.y, false, false);
-            const u32x2 s2 = __builtin_amdgcn_permlane32_swap(d0.z, d1.z, false, false);
-            const u32x2 s3 = __builtin_amdgcn_permlane32_swap(d0.w, d1.w, false, false);
-            d0 = make_uint4(s0.x, s1.x, s2.x, s3.x);
-            d1 = make_uint4(s0.y, s1.y, s2.y, s3.y);
-            *(uint4*)(outb + cur.off + st_a) = d0;
-            *(uint4*)(outb + cur.off + st_b) = d1;
-        } else {
-            uint4* op = (uint4*)(outb + cur.off);
-            op[0] = d0;
-            op[1] = d1;
-        }
+        store_row(cur.off, d0, d1, swp);
     };
     // ---- a full block of 16 rows, every lane of the wave inside the row: straight-line code.  Sixteen unrolled steps, every
     // load issued by every lane, so the compiler's s_waitcnt for row i's inputs is exact -- "at most the loads of row i + 1 and
@@ -386,6 +400,91 @@ __global__ __launch_bounds__(TB) void decompress_rows_kernel(const uint32_t* __r
             constexpr bool TBL = decltype(tc)::value;
             constexpr bool R1 = decltype(rc)::value;          // one row per step (the table period is four steps)
             const int R = R1 ? 1 : g.rpar;
+            if constexpr (R1 && (RV == 4 || RV == 8)) {
+                if (r > 0) {
+                    // ---- low-rank term on the matrix cores, four rows at a time.  v_mfma_f32_4x4x4_16B_f16 computes, in every group
+                    // of four lanes, D[i][j] = C[i][j] + sum_k A_(lane i)[k] B_(lane j)[k] with D[.][j] in lane j's four registers
+                    // (tools/ubench/mfma4_layout.hip): lane 4 b + i supplies the row factor of the group's row i (ONE 8- or 16-byte load
+                    // per lane and FOUR rows instead of one per row), every lane its own column's factor block, and the accumulators
+                    // start from the four rows' dequantized values -- 2 (rank 8) matrix-core instructions per column and four rows
+                    // where the vector ALU issued 16 v_dot2_f32_f16.  Results differ from the dot-product chain's in the order of
+                    // the fp32 additions only (<= 1 ulp of the fp16 result).
+                    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                    typedef float float4_t __attribute__((ext_vector_type(4)));
+                    struct RowIn4 { uint32_t words[4][WPL]; float s[4], m[4]; uint4 fva; };
+                    auto fetch4 = [&](int gi, RowIn4& in) __attribute__((always_inline)) {
+                        const int p0 = phys(4 * gi);                     // (rot is a multiple of 4: a group stays a group)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int off = lane_off + (p0 + q) * istride;
+                            const int gix = lane_g + (p0 + q) * gstep;
+                            in.s[q] = ld_st<ST>(scaleb + gix);
+                            in.m[q] = ld_st<ST>(mnb + gix);
+#pragma unroll
+                            for (int w = 0; w < WPL; w++) in.words[q][w] = codeb[off / CPW + w];
+                        }
+                        const uint16_t* fvp = fvb + fv_lane + (p0 + (tid & 3)) * r;
+                        if (RV == 4) { const uint2 t = *(const uint2*)fvp; in.fva = make_uint4(t.x, t.y, 0, 0); }
+                        else in.fva = *(const uint4*)fvp;
+                    };
+                    // (the conversion as the compiler's own v_cvt_pk_f16_f32, not common.h's inline-asm f2h2_bits: the matrix cores'
+                    // results are not interlocked, the wait states in front of their first reader are the compiler's to insert, and it
+                    // cannot see into an asm statement -- with f2h2_bits the first row of every group read accumulators that the
+                    // later columns' instructions had not written yet)
+                    typedef float float2c __attribute__((ext_vector_type(2)));
+                    auto cvt2 = [](float a, float b) __attribute__((always_inline)) {
+                        const float2c v = {a, b};
+                        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2_t));
+                    };
+                    auto compute4 = [&](int gi, const RowIn4& in) __attribute__((always_inline)) {
+                        const int p0 = phys(4 * gi);
+                        float4_t acc[16];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            uint4 d0, d1;
+                            dense_row(4 * gi + q, in.words[q], in.s[q], in.m[q], TBL, d0, d1);
+                            float f[16];
+                            unpack8(d0, f);
+                            unpack8(d1, f + 8);
+#pragma unroll
+                            for (int j = 0; j < 16; j++) acc[j][q] = f[j];
+                        }
+                        const half4_t a_lo = __builtin_bit_cast(half4_t, make_uint2(in.fva.x, in.fva.y));
+                        const half4_t a_hi = __builtin_bit_cast(half4_t, make_uint2(in.fva.z, in.fva.w));
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            acc[j] = __builtin_amdgcn_mfma_f32_4x4x4f16(a_lo, __builtin_bit_cast(half4_t, make_uint2(gb[j][0], gb[j][1 % RV2])), acc[j], 0, 0, 0);
+                            if (RV == 8)
+                                acc[j] = __builtin_amdgcn_mfma_f32_4x4x4f16(a_hi, __builtin_bit_cast(half4_t, make_uint2(gb[j][2 % RV2], gb[j][3 % RV2])), acc[j], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint4 d0 = make_uint4(cvt2(acc[0][q], acc[1][q]), cvt2(acc[2][q], acc[3][q]), cvt2(acc[4][q], acc[5][q]), cvt2(acc[6][q], acc[7][q]));
+                            const uint4 d1 = make_uint4(cvt2(acc[8][q], acc[9][q]), cvt2(acc[10][q], acc[11][q]), cvt2(acc[12][q], acc[13][q]), cvt2(acc[14][q], acc[15][q]));
+                            store_row(lane_off + (p0 + q) * istride, d0, d1, true);
+                        }
+                    };
+                    RowIn4 gbuf[2];
+                    if (TBL) prefetch_entries_all(0);
+                    fetch4(0, gbuf[0]);
+#pragma unroll
+                    for (int gi = 0; gi < 4; gi++) {
+                        if (TBL) {
+                            if (gi) __syncthreads();            // everyone is done reading the previous fill
+                            zero_table();
+                            __syncthreads();
+#pragma unroll
+                            for (int q = 0; q < PF; q++)
+                                if (pf_rc[q] >= 0 && (int)pf_idx[q] < g.len) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+                            if (gi + 1 < 4) prefetch_entries_all(4 * (gi + 1));
+                            __syncthreads();
+                        }
+                        if (gi + 1 < 4) fetch4(gi + 1, gbuf[(gi + 1) & 1]);
+                        compute4(gi, gbuf[gi & 1]);
+                    }
+                    return;
+                }
+            }
             RowIn buf[PFD + 1];
             if (TBL) prefetch_entries_all(0);
 #pragma unroll

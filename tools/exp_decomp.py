@@ -12,6 +12,6 @@ for kind in ("v", "k"):
     comp = C.compress_value if kind == "v" else C.compress_key
     for (k, r) in ((0, 0), (40, 0), (0, 8), (40, 8)):
         p = comp(x, 2, 64, k_out=k, rank=r, loop=3, mode="fp32", P0=P0 if r else None)
-        t = timeit(lambda: C.decompress(p, transposed_out=True))
+        t = timeit(lambda: C.decompress(p, transposed_out=(kind == "k")))
         print(f"decompress {kind} k={k:2d} r={r}: {t:.3f} ms", flush=True)
         del p
