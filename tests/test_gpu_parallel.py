@@ -271,9 +271,15 @@ def test_hip_exact_v_selection_shards_are_the_unsharded_payload(H, T, world, s, 
         assert np.array_equal(got_i[:, :, :k], fo[:, :, sl]) and np.array_equal(got_v[:, :, :k], fv[:, :, sl])
         assert (got_i[:, :, k:] == 1 << 30).all() and (got_v[:, :, k:] == 0).all()      # every shard list sorted, padded at its end
     # and back: a shard's payload decompresses (padded list slots skipped) to the matching heads of the unsharded reconstruction
+    # (to one unit in the last place: rows that fill whole waves add the rank-4 / rank-8 row term on the matrix cores, shorter
+    # shard rows -- several side by side in a wave -- as a v_dot2_f32_f16 chain: same products, another order of fp32 additions)
     rec = C.decompress(full)
+
+    def ordered(t):
+        i = t.contiguous().view(torch.int16).to(torch.int32)
+        return torch.where(i < 0, -(i & 0x7FFF), i)
     for r, p in enumerate(shards):
-        assert torch.equal(C.decompress(p), rec[:, r * Hl:(r + 1) * Hl])
+        assert int((ordered(C.decompress(p)) - ordered(rec[:, r * Hl:(r + 1) * Hl])).abs().max()) <= 1
 
 
 @pytest.mark.parametrize("H,T,world,s", [(32, 128, 8, 0.02), (8, 128, 2, 0.05)])
