@@ -748,9 +748,12 @@ def main():
         b_main = 2 * n + n / 8 * (1 if k_key else 0) + n * bits / 8 + 4 * n / group
         kernels.append({"kernel": "k_select_kernel + k_select_fix_kernel (K: per-channel outlier selection over T, token-major input)",
                         "ms": ms_sel, "alg_bytes": b_sel})
-        kernels.append({"kernel": f"k_main_kernel<{bits}, 1, {group}, float, ...> (K: fused fill + quantize + pack + Gram on the matrix cores)",
+        kernels.append({"kernel": f"k_dense_kernel<{bits}, {group}> (K: fused fill + quantize + pack + Gram on the matrix cores; 128-token slabs through two LDS buffers by LDS-DMA)",
                         "ms": ms_main, "alg_bytes": b_main,
-                        "not_counted": "the partial Gram matrices (64 KB per head and slab); no error matrix is written: the Q pass rebuilds it"})
+                        "not_counted": "the partial Gram matrices (64 KB per head and workgroup); no error matrix is written: the Q pass rebuilds it"})
+        ms_kmain = timed(lambda: C.compress_key_fused(K, bits, group, k_key, rnk, loop, "fp32", P0k, variant=8 | 16 | 128))
+        kernels.append({"kernel": f"k_main_kernel<{bits}, 1, {group}, float, ...> (rounds 2 - 5: the same work on register-resident tiles with outlier masks; option kfused_main, NOT the default)",
+                        "ms": ms_kmain, "alg_bytes": b_main})
         kernels.append({"kernel": "fused K chain (select, main, per-head solve, Q pass)", "ms": ms_full, "alg_bytes": alg["k_compress"]})
         # the single-read alternative (csrc/kone.hip, option kfused_one; round 6): selection + dense part + Gram in
         # ONE launch with one read of K -- measured beside the chain in every run, not the default (profiles/r6_kone.md says why)
@@ -783,7 +786,7 @@ def main():
                 prof, tname = cand, os.path.relpath(tp, ROOT)
                 break
         if prof:
-            base = dom["kernel"].split(" ")[0].split("<")[0]       # compress_rows_wave_kernel / compress_rows_fp32_kernel / k_select_kernel / k_main_kernel
+            base = dom["kernel"].split(" ")[0].split("<")[0]       # compress_rows_wave_kernel / compress_rows_fp32_kernel / k_select_kernel / k_dense_kernel
             same = lambda kname: kname.split("<")[0] == base or (base == "k_select_kernel" and kname.split("<")[0] == "k_select_fix_kernel")
             hit = [tb for kname, tb in prof.get("kernels", {}).items() if same(kname)]
             # (both instantiations of the wave-per-row kernel -- fast and fallback pass -- share the base name and are added up)
@@ -808,7 +811,7 @@ def main():
     cname = min(("k_compress", "v_compress"), key=lambda c: chain[c]["frac"])
     # PMC traffic of the chain = the sum over its launches (same library-tied profile as above)
     chain_traffic = None
-    members = {"k_compress": ("k_select_kernel", "k_select_fix_kernel", "k_main_kernel", "k_solve_kernel", "k_qpass_kernel"),
+    members = {"k_compress": ("k_select_kernel", "k_select_fix_kernel", "k_dense_kernel", "k_solve_kernel", "k_qpass_kernel"),
                "v_compress": ("compress_rows_wave_kernel", "compress_rows_fp32_kernel", "lr_gram_wave_kernel", "k_solve_kernel",
                               "lr_qpass_tm_mfma_kernel")}
     if traffic is not None:
@@ -816,7 +819,7 @@ def main():
                if any(kname == mname or kname.startswith(mname + "<") or kname.startswith(mname) and "<" in mname for mname in members[cname])]
         if hit:
             chain_traffic = float(sum(hit))
-    launches = {"k_compress": "k_select_kernel + k_select_fix_kernel + k_main_kernel + k_solve_kernel + k_qpass_kernel",
+    launches = {"k_compress": "k_select_kernel + k_select_fix_kernel + k_dense_kernel + k_solve_kernel + k_qpass_kernel",
                 "v_compress": "compress_rows_wave_kernel (fast + fallback pass) + lr_gram_wave_kernel + k_solve_kernel + lr_qpass_tm_mfma_kernel"}
     roofline = {"bound": "hbm", "kernel": f"{cname} chain: {launches[cname]}", "achieved": chain[cname]["achieved"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chain[cname]["frac"], "traffic": chain_traffic,

@@ -34,7 +34,7 @@ dur = {n: (len(v), sum(sorted(v)[-3:]) / min(3, len(v)), min(v)) for n, v in dur
 print(f"calibration: {kf:.1f} B per FETCH_SIZE unit, {kw:.1f} B per WRITE_SIZE unit (1 GiB copy)\n")
 print("| kernel | launches | us (3 longest) | us (shortest) | read GB | written GB | total GB |\n|---|---:|---:|---:|---:|---:|---:|")
 for n in fetch:
-    if not n.startswith(("k_select", "k_main", "k_solve", "k_qpass", "k_one")):
+    if not n.startswith(("k_select", "k_main", "k_dense", "k_solve", "k_qpass", "k_one")):
         continue
     f, w = max(fetch[n]) * kf, max(write.get(n, [0.0])) * kw
     c, us, us_min = dur.get(n, (0, 0.0, 0.0))

@@ -28,7 +28,7 @@ out = {"lib_sha256": open(f"{src}/lib.sha256").read().split()[0], "config": conf
               f"1 GiB copy in the same run (read {kf:.1f}, write {kw:.1f} B / unit: KB units, FETCH_SIZE counts half the bytes)"}
 rows = []
 for n in fetch:
-    if not n.startswith(("compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "transpose_f16", "decompress_rows")):
+    if not n.startswith(("compress_rows", "k_select", "k_main", "k_dense", "k_solve", "k_qpass", "lr_", "transpose_f16", "decompress_rows")):
         continue
     f = sorted(fetch[n]["FETCH_SIZE"])[len(fetch[n]["FETCH_SIZE"]) // 2] * kf
     w = sorted(write[n]["WRITE_SIZE"])[len(write[n]["WRITE_SIZE"]) // 2] * kw
@@ -43,7 +43,7 @@ if os.path.exists(ksb):
     out["bench_step_avg_us"] = {}
     for ln in open(ksb):
         m = re.match(r"\| `([^`]+)` \| (\d+) \| ([0-9.]+) \|", ln)
-        if m and m.group(1).startswith(("compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "decompress_rows")):
+        if m and m.group(1).startswith(("compress_rows", "k_select", "k_main", "k_dense", "k_solve", "k_qpass", "lr_", "decompress_rows")):
             out["bench_step_avg_us"][m.group(1)[:60]] = float(m.group(3))
 json.dump(out, open(f"{dst}_traffic.json", "w"), indent=1)
 with open(f"{dst}_pmc_traffic.md", "w") as fmd:
@@ -59,7 +59,7 @@ if os.path.exists(f"{src}/pmc_block_FETCH_SIZE.csv"):
         fmd.write("\n## The decode-time block boundary (tools/prof_block.py: 32 layers x 32 heads x 64 tokens, K and V = 33.6 MB of fp16 in)\n\n"
                   "| kernel | read MB | written MB | total MB |\n|---|---:|---:|---:|\n")
         for n in bf:
-            if not n.startswith(("block_compress", "compress_rows", "k_select", "k_main", "k_solve", "k_qpass", "lr_", "ktile", "vtile", "outlier_chunk")):
+            if not n.startswith(("block_compress", "compress_rows", "k_select", "k_main", "k_dense", "k_solve", "k_qpass", "lr_", "ktile", "vtile", "outlier_chunk")):
                 continue
             f = sorted(bf[n]["FETCH_SIZE"])[len(bf[n]["FETCH_SIZE"]) // 2] * kf
             w = sorted(bw_[n]["WRITE_SIZE"])[len(bw_[n]["WRITE_SIZE"]) // 2] * kw if n in bw_ else 0.0

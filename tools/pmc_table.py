@@ -7,7 +7,7 @@ for r in rows:
     n = re.sub(r"\(.*", "", n)[:60]
     tab.setdefault(n, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for n, cs in tab.items():
-    if not n.startswith(("compress_rows", "lr_", "decompress", "attn", "k_select", "k_main", "k_solve", "k_qpass", "transpose_f16")):
+    if not n.startswith(("compress_rows", "lr_", "decompress", "attn", "k_select", "k_main", "k_dense", "k_solve", "k_qpass", "transpose_f16")):
         continue
     print("##", n)
     for c, v in cs.items():
