@@ -61,6 +61,13 @@ int gear_lr_qpass_tm_launch(const void* E, const float* W, int64_t bh, int S, in
 
 namespace {
 
+// phase clocks of k_select_kernel (measurement builds only: EXTRA=-DGEAR_KS_CLK; tools/exp_kselect_clk.py)
+#ifdef GEAR_KS_CLK
+__device__ unsigned long long ks_clk_buf[8 * 4096];
+#define KS_CLK_AT(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) ks_clk_buf[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KS_CLK_AT(k) do { } while (0)
+#endif
 
 constexpr int KS_CAP = 160;      // candidate slots per (channel, side) list
 constexpr int KS_STRIDE = 164;   // words between lists in LDS: 4 words of skew keep the quad-per-list reads conflict-free
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     auto ldw = [&](int i) { return *(const uint32_t*)(xbase + (lane_b + 4096u * (uint32_t)i)); };     // token s + 16 i
 
     // ---------------------------------------------------------------- phase A: sample statistics -> threshold guess
+    KS_CLK_AT(0);
     {
         float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
         constexpr int KS_A = 32;      // sampled tokens per trip: their loads fly together (8 per trip made this phase 8 dependent
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     const half2v thi2 = __builtin_bit_cast(half2v, (tw0 & 0xFFFFu) | (tw1 << 16));
     const half2v tlo2 = __builtin_bit_cast(half2v, (tw0 >> 16) | (tw1 & 0xFFFF0000u));
 
+    KS_CLK_AT(1);
     // ---------------------------------------------------------------- phase B: stream every token once
     // Row sums in fp32 (exact products on v_dot2, fp32 accumulate; the reference's own torch.mean is an fp32 reduction too).
     // Candidates: x outside [tlo, thi] <=> clamp(x) != x -- two packed min / max, one xor, one packed "min(d, 1)" per word
@@ -242,7 +251,9 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
             if (b + 2 < nb) process_batch(b + 2, bufC);
         }
     }
+    KS_CLK_AT(2);
     __syncthreads();                                   // the stash is dead: its space takes the 16 streams' partial sums
+    KS_CLK_AT(3);
     float* sum_lds = (float*)scr;                      // [16][32]
     sum_lds[s * 32 + 2 * c2] = suma;
     sum_lds[s * 32 + 2 * c2 + 1] = sumb;
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
     if (k <= 0) return;
     __syncthreads();                                   // (phase C reuses the scratch area)
 
+    KS_CLK_AT(4);
     // ---------------------------------------------------------------- phase C.1: the threshold of every list at once
     // One DPP quad per list (16 lists per wave, 64 per workgroup): lane i4 of the quad holds candidates i4, i4 + 4, ... as
     // composite keys (16-bit order key of the value, then 14 bits "earlier token first"), unique per list, and the quad finds
@@ -294,7 +306,9 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         }
         if (i4 == 0) kthr[L] = fast ? lo_b : 0u;
     }
+    KS_CLK_AT(5);
     __syncthreads();
+    KS_CLK_AT(6);
     // ---------------------------------------------------------------- phase C.2: outputs, one wave per channel
     const int nwords = (T + 31) >> 5;
     uint32_t* bmA = scr + wave * 4 * nwords;       // side 0 (large) bitmap of the current channel
@@ -384,6 +398,7 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    KS_CLK_AT(7);
 }
 
 // The lists k_select_kernel could not decide (a handful per launch on ordinary data, all of them with option kselect_slow):
@@ -1127,6 +1142,11 @@ void launch_main(const MainArgs& a, int64_t BH, bool fast, bool lr, bool tr, hip
 }
 
 }  // namespace
+#ifdef GEAR_KS_CLK
+extern "C" int gear_debug_ks_clk(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ks_clk_buf), sizeof(unsigned long long) * 8 * 4096);
+}
+#endif
 #ifdef GEAR_KF_CLK
 extern "C" int gear_debug_kf_clk(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kf_clk_buf), sizeof(unsigned long long) * 8 * 4096);
