@@ -45,6 +45,7 @@ GearOptions& gear_options() {
         v.kfused_one = ival("GEAR_KFUSED_ONE");
         v.kfused_main = ival("GEAR_KFUSED_MAIN");
         v.kfused_eout = ival("GEAR_KFUSED_EOUT");
+        v.decomp_rpb = ival("GEAR_DECOMP_RPB");
         v.attn_fold = ival("GEAR_ATTN_FOLD");
         v.attn_mfma = ival("GEAR_ATTN_MFMA");
         return v;
@@ -58,7 +59,7 @@ extern "C" int gear_set_option(const char* name, int value) {
         {"attn_generic", &o.attn_generic},     {"lowrank_generic", &o.lowrank_generic}, {"rows_hist_only", &o.rows_hist_only},
         {"rows_v1", &o.rows_v1}, {"rows_masked", &o.rows_masked}, {"rows_wg_only", &o.rows_wg_only},               {"kfused_generic", &o.kfused_generic},   {"kselect_slow", &o.kselect_slow},
         {"kfused_no_tr", &o.kfused_no_tr}, {"gram_fused", &o.gram_fused}, {"gram_nstg", &o.gram_nstg},
-        {"decomp_general", &o.decomp_general}, {"attn_gqa_group", &o.attn_gqa_group}, {"attn_win_chunk", &o.attn_win_chunk}, {"attn_keep_chunk_index", &o.attn_keep_chunk_index}, {"kfused_nslab", &o.kfused_nslab}, {"kfused_one", &o.kfused_one}, {"kfused_main", &o.kfused_main}, {"kfused_eout", &o.kfused_eout}, {"attn_fold", &o.attn_fold}, {"attn_mfma", &o.attn_mfma},
+        {"decomp_general", &o.decomp_general}, {"attn_gqa_group", &o.attn_gqa_group}, {"attn_win_chunk", &o.attn_win_chunk}, {"attn_keep_chunk_index", &o.attn_keep_chunk_index}, {"kfused_nslab", &o.kfused_nslab}, {"kfused_one", &o.kfused_one}, {"kfused_main", &o.kfused_main}, {"kfused_eout", &o.kfused_eout}, {"decomp_rpb", &o.decomp_rpb}, {"attn_fold", &o.attn_fold}, {"attn_mfma", &o.attn_mfma},
     };
     for (const auto& t : tab)
         if (name && !strcmp(name, t.n)) { *t.p = value; return 0; }

@@ -54,6 +54,8 @@ struct GearOptions {
     int attn_fold;         // decode attention (vector short-chunk kernel, fp16 baseline): the merge of a head's partial results folded into
                            // the partial launch (last-arriving workgroup merges): 1 = on; off by default (measured no faster than the
                            // reduce kernel as a second launch: csrc/attention.hip, fold_wanted)
+    int decomp_rpb;        // row decompressor, rank 4 / 8 on whole waves: rows per workgroup behind one load of the column factor block:
+                           // 0 = 128 / 64 / 32 while >= 1024 workgroups remain, else 16; 32 / 64 / 128 = that many whatever the size; -1 = 16
     int kfused_eout;       // fused K path, k_dense_kernel: 1 = the error matrix written to the workspace (+ BH T 256 bytes) and the Q pass reading it
                            // (lr_qpass_tm_mfma_kernel) instead of rebuilding it from K and the stored codes (k_qpass_kernel)
     int kfused_main;       // fused K path, fp32 arithmetic: 1 = k_main_kernel (register-resident tiles with outlier masks, rounds 2 - 5) instead of

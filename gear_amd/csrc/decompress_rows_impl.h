@@ -393,14 +393,16 @@ __global__ __launch_bounds__(TB, (TB == 256 ? 2 : 1)) void decompress_rows_kerne
     // at 2.2 - 2.5 TB/s where tools/ubench/store_pattern3.hip writes the same bytes at 4.5).
     // Short rows (rpar of them side by side, TB == 256 only): the same sixteen steps with rpar rows each; the table period in
     // steps is then a run-time number, so that flavour keeps a uniform branch around the fill.
-    const bool fast = BITS <= 4 && !g.general && wave_full && (RV > 0 || r == 0) && g.rpb == 16 * g.rpar && nrows_blk == g.rpb &&
+    const bool fast = BITS <= 4 && !g.general && wave_full && (RV > 0 || r == 0) &&
+                      (g.rpb == 16 * g.rpar || ((RV == 4 || RV == 8) && TB < 1024 && r > 0 && g.rpar == 1 && g.rpb % 8 == 0 && g.rpb > 16)) && nrows_blk == g.rpb &&
                       (g.rpar > 1 ? TB == 256 : g.trows == 4) && (!table || pf_ok);
     if (fast) {
         auto rows16 = [&](auto tc, auto rc) __attribute__((always_inline)) {
             constexpr bool TBL = decltype(tc)::value;
             constexpr bool R1 = decltype(rc)::value;          // one row per step (the table period is four steps)
             const int R = R1 ? 1 : g.rpar;
-            if constexpr (R1 && (RV == 4 || RV == 8)) {
+            // (not with 1024 threads -- rows of 16384 columns: 128 registers per lane do not hold the 64 accumulators and the factor block)
+            if constexpr (R1 && (RV == 4 || RV == 8) && TB < 1024) {
                 if (r > 0) {
                     // ---- low-rank term on the matrix cores, four rows at a time.  v_mfma_f32_4x4x4_16B_f16 computes, in every group
                     // of four lanes, D[i][j] = C[i][j] + sum_k A_(lane i)[k] B_(lane j)[k] with D[.][j] in lane j's four registers
@@ -464,23 +466,54 @@ __global__ __launch_bounds__(TB, (TB == 256 ? 2 : 1)) void decompress_rows_kerne
                             store_row(lane_off + (p0 + q) * istride, d0, d1, true);
                         }
                     };
-                    RowIn4 gbuf[2];
-                    if (TBL) prefetch_entries_all(0);
-                    fetch4(0, gbuf[0]);
+                    auto refill = [&](int gi, int ng) __attribute__((always_inline)) {
+                        if (gi) __syncthreads();            // everyone is done reading the previous fill
+                        zero_table();
+                        __syncthreads();
 #pragma unroll
-                    for (int gi = 0; gi < 4; gi++) {
-                        if (TBL) {
-                            if (gi) __syncthreads();            // everyone is done reading the previous fill
-                            zero_table();
-                            __syncthreads();
+                        for (int q = 0; q < PF; q++)
+                            if (pf_rc[q] >= 0 && (int)pf_idx[q] < g.len) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+                        prefetch_entries_all(4 * min(gi + 1, ng - 1));
+                        __syncthreads();
+                    };
+                    if (g.rpb == 16) {
+                        // sixteen rows: straight-line code over the four groups
+                        RowIn4 gbuf[2];
+                        if (TBL) prefetch_entries_all(0);
+                        fetch4(0, gbuf[0]);
 #pragma unroll
-                            for (int q = 0; q < PF; q++)
-                                if (pf_rc[q] >= 0 && (int)pf_idx[q] < g.len) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
-                            if (gi + 1 < 4) prefetch_entries_all(4 * (gi + 1));
-                            __syncthreads();
+                        for (int gi = 0; gi < 4; gi++) {
+                            if (TBL) {
+                                if (gi) __syncthreads();            // everyone is done reading the previous fill
+                                zero_table();
+                                __syncthreads();
+#pragma unroll
+                                for (int q = 0; q < PF; q++)
+                                    if (pf_rc[q] >= 0 && (int)pf_idx[q] < g.len) lval[(pf_rc[q] >> 16) * g.len + pf_idx[q]] = (uint16_t)~pf_val[q];
+                                if (gi + 1 < 4) prefetch_entries_all(4 * (gi + 1));
+                                __syncthreads();
+                            }
+                            if (gi + 1 < 4) fetch4(gi + 1, gbuf[(gi + 1) & 1]);
+                            compute4(gi, gbuf[gi & 1]);
                         }
-                        if (gi + 1 < 4) fetch4(gi + 1, gbuf[(gi + 1) & 1]);
-                        compute4(gi, gbuf[gi & 1]);
+                    } else {
+                        // 32 .. 128 rows behind ONE load of the lane's column factor block (16 instructions that touch 64 lines each: paid
+                        // per 16 rows it was 0.09 / 0.06 ms of K^T's / V's 0.37 ms at config 3): a rolled loop over pairs of groups, two
+                        // group buffers in ping-pong, the prefetch behind the last group re-reads that group (unconditional loads: the
+                        // compiler's wait counts stay exact)
+                        const int ng = g.rpb >> 2;
+                        RowIn4 gbufA, gbufB;
+                        if (TBL) prefetch_entries_all(0);
+                        fetch4(0, gbufA);
+#pragma unroll 1
+                        for (int gp = 0; gp < ng; gp += 2) {
+                            if (TBL) refill(gp, ng);
+                            fetch4(gp + 1, gbufB);
+                            compute4(gp, gbufA);
+                            if (TBL) refill(gp + 1, ng);
+                            fetch4(min(gp + 2, ng - 1), gbufA);
+                            compute4(gp + 1, gbufB);
+                        }
                     }
                     return;
                 }
@@ -659,6 +692,13 @@ int DEC_ENTRY(const void* code, const void* scale, const void* mn, int64_t n_row
         while (rb > rp && rows_inner % rb != 0) rb >>= 1;
         if (rows_inner % rb == 0) { rpar = rp; rpb = rb; }
     }
+    // rank 4 / 8 on whole waves (the matrix-core group path): up to 128 rows behind one load of the column factor block, as long as
+    // >= 1024 workgroups remain (4 per CU)
+    if ((r == 4 || r == 8) && rpar == 1 && rpb == 16 && !patch && bits <= 4 && len % 1024 == 0 && len <= 8192 && !gear_options().decomp_general)
+        for (int c = 128; c >= 32; c >>= 1) {
+            const int forced = gear_options().decomp_rpb;           // (tests: 32 / 64 / 128 rows per block whatever the size; -1: always 16)
+            if (rows_inner % c == 0 && n_rows % c == 0 && (forced > 0 ? c == forced : (forced == 0 && n_rows / c >= 1024))) { rpb = c; break; }
+        }
     int trows = rpb < 4 ? rpb : 4;            // rows per fill of the LDS outlier table (35 KB at 4096 columns)
     if (trows > rpb) trows = rpb;
     while (trows > 1 && (rpb % trows != 0 || (size_t)trows * ((len / 32 + 1) * 4 + len * 2) > 72 * 1024)) trows >>= 1;

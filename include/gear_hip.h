@@ -44,7 +44,7 @@ const char* gear_last_error(void);
 int gear_abi_version(void);
 /* Run-time options: switches that select an alternative, equally exact code path (used by the tests to reach the
  * paths ordinary inputs do not).  Names: "attn_generic", "lowrank_generic", "rows_hist_only", "rows_wg_only", "rows_v1", "rows_masked",
- * "kfused_generic", "kselect_slow", "kfused_no_tr", "gram_fused", "gram_nstg", "decomp_general", "kfused_nslab", "attn_fold" (decode attention: 1 = the merge of the partial results inside the partial launch; off by default, measured
+ * "kfused_generic", "kselect_slow", "kfused_no_tr", "gram_fused", "gram_nstg", "decomp_general", "decomp_rpb", "kfused_nslab", "attn_fold" (decode attention: 1 = the merge of the partial results inside the partial launch; off by default, measured
  * no faster), "kfused_main" (1 = k_main_kernel instead of k_dense_kernel for fp32 arithmetic), "kfused_eout" (1 = k_dense_kernel writes the error matrix, the Q pass reads it), "kfused_one" (the
  * single-read K kernel, csrc/kone.hip: 1 = wherever it applies; off by default -- measured slower than the chain), and for the decode
  * attention "attn_gqa_group" (one workgroup per KV head serves its 2 / 4 / 8 query heads), "attn_win_chunk" (fp16 window as one more
