@@ -632,7 +632,7 @@ def main():
     torch.cuda.synchronize()
     ev.clear()
     pk = pv = kr = vr = out = None
-    for _ in range(3):
+    for _ in range(5):
         pk = pv = kr = vr = out = None           # (drop the previous outputs first: the allocator then reuses their blocks)
         pk, pv, kr, vr = out = step_serial()
     torch.cuda.synchronize()
@@ -643,7 +643,7 @@ def main():
         ms = [a.elapsed_time(b) for a, b in zip(ev[prev], ev[nme])]
         if os.environ.get("GEAR_BENCH_DEBUG"):
             print(nme, [round(v, 3) for v in ms], file=sys.stderr)
-        stages[nme] = sum(ms) / len(ms)
+        stages[nme] = sorted(ms)[len(ms) // 2]      # median of the five passes (one allocator hiccup in three passes once read 9.6 ms into a mean)
         prev = nme
 
     # ---- algorithmic bytes (one K or V tensor of n elements on this rank): read 2n, write the payload
