@@ -67,6 +67,7 @@ SIGNATURES = {
     "gear_silu_mul": (_i, [_vp, _i64, _i, _vp, _vp]),
     "gear_transpose_f16": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "gear_gemv_outer": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "gear_gemv_outer_dim": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gear_gemv_outer_lrap_workspace": (_sz, [_i64, _i, _i, _i]),
     "gear_gemv_outer_lrap": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp,
                                   _sz, _vp]),

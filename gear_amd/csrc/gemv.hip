@@ -143,6 +143,72 @@ GemvPlan plan_gemv(int64_t BA, int K, int N, int bits) {
 }
 }  // namespace
 
+// ---- the reference extension's own argument layout (gemv_cuda.h:13-21, kernels gemv_cuda.cu:264-434): K innermost --------------
+// kernel [BW][N / fpi][K] int32, scaling factors / zeros [BW][N / group][K]: what cuda_bmm_fA_qB_outer hands to
+// kivi_gemv.gemv_forward_cuda_outer_dim AFTER its per-call transpose(1, 2).contiguous() (matmul.py:205, :215-216).  One wave per
+// packed word row: the lanes stride over K (contiguous: coalesced 4-byte and 2-byte loads), fpi accumulators per lane, one DPP
+// sum per output at the end.  Same arithmetic as gemv_outer_kernel (scale * a and zero * a in fp32, fp32 accumulation, one fp16
+// rounding).  For callers that keep the reference's binding line by line; the native layout (gear_gemv_outer) needs no re-layout.
+template <int BITS, typename ST>
+__global__ __launch_bounds__(256) void gemv_outer_dim_kernel(const uint16_t* __restrict__ a, const uint32_t* __restrict__ qBt,
+                                                             const ST* __restrict__ scale_t, const ST* __restrict__ zero_t, int n_rep,
+                                                             int K, int NW, int NG, int group, uint16_t* __restrict__ out16) {
+    constexpr int CPW = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const int lane = threadIdx.x & 63;
+    const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (w >= NW) return;
+    const int64_t ba = blockIdx.y, bw = ba / n_rep;
+    const int g = min((w * CPW) / group, NG - 1);
+    const uint32_t* q = qBt + (bw * NW + w) * (int64_t)K;
+    const ST* sp = scale_t + (bw * NG + g) * (int64_t)K;
+    const ST* zp = zero_t + (bw * NG + g) * (int64_t)K;
+    const uint16_t* arow = a + ba * (int64_t)K;
+    float acc[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; j++) acc[j] = 0.0f;
+    float zacc = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const uint32_t wv = q[k];
+        const float av = h2f_bits(arow[k]);
+        const float sa = ld_st<ST>(sp + k) * av;
+        zacc = fmaf(ld_st<ST>(zp + k), av, zacc);
+#pragma unroll
+        for (int j = 0; j < CPW; j++) acc[j] = fmaf(sa, (float)((wv >> (BITS * j)) & MASK), acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CPW; j++) acc[j] = wave_sum_dpp(acc[j] + zacc);
+    if (lane == 0) {
+        uint16_t* op = out16 + ba * (int64_t)(NW * CPW) + (int64_t)w * CPW;
+#pragma unroll
+        for (int j = 0; j < CPW; j++) op[j] = f2h_bits(acc[j]);
+    }
+}
+
+extern "C" int gear_gemv_outer_dim(const void* in_feats, const void* kernel, const void* scaling_factors, const void* zeros, int64_t BA,
+                                   int n_rep, int K, int N, int group, int bits, int mode, void* out, void* stream) {
+    GEAR_CHECK_ARG(bits == 2 || bits == 4, "gear_gemv_outer_dim: bits must be 2 or 4 (got %d)", bits);
+    GEAR_CHECK_ARG(mode == 0 || mode == 1, "gear_gemv_outer_dim: bad mode %d", mode);
+    GEAR_CHECK_ARG(BA > 0 && K > 0 && N > 0, "gear_gemv_outer_dim: empty problem");
+    GEAR_CHECK_ARG(n_rep >= 1 && BA % n_rep == 0, "gear_gemv_outer_dim: BA=%lld not divisible by n_rep=%d", (long long)BA, n_rep);
+    const int cpw = 32 / bits;
+    GEAR_CHECK_ARG(N % cpw == 0, "gear_gemv_outer_dim: N=%d must be a multiple of %d", N, cpw);
+    GEAR_CHECK_ARG(group > 0 && group % cpw == 0, "gear_gemv_outer_dim: group %d must be a multiple of %d", group, cpw);
+    GEAR_CHECK_ARG(BA <= 65535, "gear_gemv_outer_dim: batch*heads=%lld exceeds 65535", (long long)BA);
+    GEAR_CHECK_ARG(in_feats && kernel && scaling_factors && zeros && out, "gear_gemv_outer_dim: null pointer");
+    const int NW = N / cpw, NG = (N + group - 1) / group;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((NW + 3) / 4), (unsigned)BA);
+#define GOD(B, STT)                                                                                                         \
+    hipLaunchKernelGGL((gemv_outer_dim_kernel<B, STT>), grid, dim3(256), 0, st, (const uint16_t*)in_feats, (const uint32_t*)kernel, \
+                       (const STT*)scaling_factors, (const STT*)zeros, n_rep, K, NW, NG, group, (uint16_t*)out)
+    if (mode == 0) { if (bits == 2) GOD(2, uint16_t); else GOD(4, uint16_t); }
+    else { if (bits == 2) GOD(2, float); else GOD(4, float); }
+#undef GOD
+    GEAR_CHECK_LAUNCH("gear_gemv_outer_dim");
+    return 0;
+}
+
 extern "C" size_t gear_gemv_outer_workspace(int64_t BA, int K, int N, int bits) {
     if (bits != 2 && bits != 4) return 0;
     GemvPlan p = plan_gemv(BA, K, N, bits);

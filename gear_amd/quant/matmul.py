@@ -49,6 +49,28 @@ def cuda_bmm_fA_qB_outer(group_size: int, fA: torch.Tensor, qB: torch.Tensor, sc
     return c
 
 
+def gemv_forward_cuda_outer_dim(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors: torch.Tensor, zeros: torch.Tensor,
+                                bit: int, group_size: int, nh: int, mqa: bool) -> torch.Tensor:
+    """kivi_gemv.gemv_forward_cuda_outer_dim (csrc/pybind.cpp:5-8, gemv_cuda.h:13-21) on ITS argument layout: in_feats [BS, M = 1, K]
+    fp16, kernel [BS', N / fpi, K] int32, scaling_factors / zeros [BS', N / group, K] -- BS' = BS, or BS / nh with mqa -- i.e. what
+    matmul.py:205, :215-216 produce by transpose(1, 2).contiguous().  Returns [BS, 1, N] fp16.  For a caller that keeps the
+    reference's cuda_bmm_fA_qB_outer line by line; the operator above needs no re-layout."""
+    assert in_feats.dim() == 3 and kernel.dim() == 3 and bit in (2, 4)
+    BS, M, K = in_feats.shape
+    if M != 1:
+        raise L.GearError("gemv_forward_cuda_outer_dim supports M == 1 only (decode GEMV; the reference kernel ignores blockIdx.z)")
+    N = kernel.shape[1] * (32 // bit)
+    n_rep = nh if mqa else BS // kernel.shape[0]
+    mode = 0 if scaling_factors.dtype == torch.float16 else 1
+    in_feats, kernel, scaling_factors, zeros = in_feats.contiguous(), kernel.contiguous(), scaling_factors.contiguous(), zeros.contiguous()
+    L.require_gpu(in_feats, kernel, scaling_factors, zeros)
+    out = torch.empty((BS, 1, N), dtype=torch.float16, device=in_feats.device)
+    rc = L.load().gear_gemv_outer_dim(L.ptr(in_feats), L.ptr(kernel), L.ptr(scaling_factors), L.ptr(zeros), BS, n_rep, K, N, group_size,
+                                     bit, mode, L.ptr(out), L.stream_ptr())
+    L.check(rc, "gear_gemv_outer_dim")
+    return out
+
+
 def triton_bmm_fA_qB_outer(group_size: int, fA, qB, scales, zeros, bits: int) -> torch.Tensor:
     """matmul.py:112-175 (the Triton alternative of the same operator): same kernel here."""
     return cuda_bmm_fA_qB_outer(group_size, fA, qB, scales, zeros, bits)

@@ -101,6 +101,16 @@ int gear_gemv_outer(const void* a, const void* qB, const void* scale, const void
                     int N, int group, int bits, int mode, int64_t ldq, int64_t lds, void* out, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* The same GEMV on the reference extension's OWN argument layout -- K innermost, what cuda_bmm_fA_qB_outer produces with its
+ * per-call transpose(1, 2).contiguous() (matmul.py:205, :215-216) and hands to kivi_gemv.gemv_forward_cuda_outer_dim
+ * (gemv_cuda.h:13-21: _in_feats, _kernel, _scaling_factors, _zeros, bit, group_size, nh, mqa):
+ *   in_feats fp16 [BA, K]      kernel int32 [BW, N / fpi, K]      scaling_factors, zeros [BW, N / group, K]      out fp16 [BA, N]
+ *   n_rep = 1 (one kernel row block per query head), nh with mqa, or any divisor of the query heads (GQA).
+ * For a maintainer who keeps matmul.py line by line and swaps only the extension call; gear_gemv_outer (above) is the entry that
+ * makes the re-layout unnecessary.  Same arithmetic, no workspace. */
+int gear_gemv_outer_dim(const void* in_feats, const void* kernel, const void* scaling_factors, const void* zeros, int64_t BA,
+                        int n_rep, int K, int N, int group, int bits, int mode, void* out, void* stream);
+
 /* ---- a7: dequant GEMV + low-rank correction in two launches -------------------------------------------------------------
  * Replaces matmul_withlrap (cuda_supported_gear/modeling_llamagear.py:54-111): cuda_bmm_fA_qB_outer followed by ~8 eager matmul /
  * permute / slice-assign launches for the prefill factors (pbase[0], qbase[0]) and the per-block factors stacked on a leading

@@ -111,6 +111,37 @@ def test_f7_gemv_golden(golden, mm_, name, b):
     assert rel_fro(host(out).astype(np.float32), orc_out.astype(np.float32)) < 1e-3
 
 
+@pytest.mark.parametrize("name", ("mha", "mqa"))
+@pytest.mark.parametrize("b", BITS)
+def test_f7_gemv_golden_on_the_extension_layout(golden, mm_, name, b):
+    """gear_gemv_outer_dim = kivi_gemv.gemv_forward_cuda_outer_dim on ITS argument layout (gemv_cuda.h:13-21: kernel [BS', OC / pack,
+    IC], scaling factors / zeros [BS', OC / group, IC], K innermost): the fixture's arrays exactly as the reference extension takes
+    them, no transpose on the way in; against the fixture's output, the oracle and the native-layout entry point."""
+    f = golden("f7_gemv.npz")
+    B, nh, IC, OC, GS = [int(v) for v in f["dims"]]
+    nkv = nh if name == "mha" else 1
+    inp = dev(f[f"{name}_inp"].reshape(B * nh, 1, IC))
+    qw, sc, mn = dev(f[f"{name}_b{b}_qw"]), dev(f[f"{name}_b{b}_scale"]), dev(f[f"{name}_b{b}_mn"])
+    assert qw.shape[0] == B * nkv and qw.shape[2] == IC and sc.shape[2] == IC
+    out = mm_.gemv_forward_cuda_outer_dim(inp, qw, sc, mn, b, GS, nh, name == "mqa")
+    assert tuple(out.shape) == (B * nh, 1, OC)
+    ref = f[f"{name}_b{b}_ref"].reshape(B * nh, 1, OC)
+    assert rel_fro(host(out).astype(np.float32), ref) < 2e-3
+    native = mm_.cuda_bmm_fA_qB_outer(GS, inp.reshape(B, nh, 1, IC), qw.transpose(1, 2).contiguous().reshape(B, nkv, IC, -1),
+                                      sc.transpose(1, 2).contiguous().reshape(B, nkv, IC, -1),
+                                      mn.transpose(1, 2).contiguous().reshape(B, nkv, IC, -1), b, mqa=(name == "mqa"))
+    assert rel_fro(host(out).astype(np.float32), host(native).reshape(B * nh, 1, OC).astype(np.float32)) < 1e-3
+
+
+def test_gemv_outer_dim_rejects_bad_arguments(mm_):
+    from gear_amd import _lib as L
+    a = torch.zeros((2, 3, 64), dtype=torch.float16, device="cuda")
+    with pytest.raises(L.GearError):
+        mm_.gemv_forward_cuda_outer_dim(a, torch.zeros((2, 4, 64), dtype=torch.int32, device="cuda"),
+                                        torch.zeros((2, 1, 64), dtype=torch.float16, device="cuda"),
+                                        torch.zeros((2, 1, 64), dtype=torch.float16, device="cuda"), 2, 64, 1, False)
+
+
 # ------------------------------------------------------------------------------------------ oracle on seeded inputs
 @pytest.mark.parametrize("shape", [(1, 4, 128, 1024), (2, 3, 64, 320), (1, 32, 128, 4096)])
 @pytest.mark.parametrize("g,b", [(64, 2), (64, 4), (32, 2), (128, 4), (64, 8)])
