@@ -288,21 +288,60 @@ __global__ __launch_bounds__(256) void k_select_kernel(SelArgs a) {
             if (fast && g < n) c = cand[L * KS_STRIDE + g];
             key[j] = (fast && g < n) ? (((order_key(c >> 16, side) << 14) | (0x3FFFu - (c & 0x3FFFu))) + 1u) : 0u;
         }
-        uint32_t lo_b = 1u, hi_b = 0x40000000u;                                    // largest K with count(key >= K) >= k
-        for (int it = 0; it < 31; it++) {
-            const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+        // The k-th largest composite key = the largest K with count(key >= K) >= k.  Two stages instead of 31 bisection rounds over
+        // the 30 key bits (20 % of the kernel: profiles/r6_kselect_phase_clocks.md): 16 rounds on the 16-bit value part, then the
+        // ties at that value -- the `need` earliest tokens among them -- by walking down from the top of the tie range (one
+        // maximum per tie taken; data with distinct values at the cut take exactly one), 14 more rounds only past four ties.
+        auto count_ge = [&](uint32_t thr) __attribute__((always_inline)) {
             int c = 0;
 #pragma unroll
             for (int blk = 0; blk < KS_CAP / 32; blk++) {
                 if (blk * 8 < jm) {
 #pragma unroll
-                    for (int j = blk * 8; j < blk * 8 + 8; j++) c += (key[j] >= mid) ? 1 : 0;
+                    for (int j = blk * 8; j < blk * 8 + 8; j++) c += (key[j] >= thr) ? 1 : 0;
                 }
             }
-            c = quad_sum_i32(c);
-            const bool take = c >= k;
-            lo_b = take ? mid : lo_b;
-            hi_b = take ? hi_b : mid - 1u;
+            return quad_sum_i32(c);
+        };
+        uint32_t lo_v = 0u, hi_v = 0xFFFFu;                                        // value part: largest V with count(value >= V) >= k
+        for (int it = 0; it < 16; it++) {
+            const uint32_t mid = lo_v + ((hi_v - lo_v + 1u) >> 1);
+            const bool take = count_ge((mid << 14) + 1u) >= k;
+            lo_v = take ? mid : lo_v;
+            hi_v = take ? hi_v : mid - 1u;
+        }
+        const uint32_t base = (lo_v << 14) + 1u, top = ((lo_v + 1u) << 14) + 1u;    // composites of value lo_v: [base, top)
+        const int need = k - count_ge(top);                                         // ties still to take (>= 1 for a fast list)
+        uint32_t lo_b = base;
+        int nmax = fast ? need : 0;                                                 // the most ties any list of the wave takes
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        if (nmax > 4) {
+            // many equal values at the cut: bisection on the token part, inside the tie range
+            uint32_t hi_b = top - 1u;
+            for (int it = 0; it < 14; it++) {
+                const uint32_t mid = lo_b + ((hi_b - lo_b + 1u) >> 1);
+                const bool take = count_ge(mid) >= k;
+                lo_b = take ? mid : lo_b;
+                hi_b = take ? hi_b : mid - 1u;
+            }
+        } else {
+            uint32_t bound = top;                                                   // (exclusive)
+            for (int t = 0; t < nmax; t++) {
+                uint32_t m = 0u;
+#pragma unroll
+                for (int blk = 0; blk < KS_CAP / 32; blk++) {
+                    if (blk * 8 < jm) {
+#pragma unroll
+                        for (int j = blk * 8; j < blk * 8 + 8; j++) m = max(m, key[j] < bound ? key[j] : 0u);
+                    }
+                }
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true));
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true));
+                if (t < need) bound = m;                                            // (m >= base: `need` ties exist)
+            }
+            lo_b = bound;
         }
         if (i4 == 0) kthr[L] = fast ? lo_b : 0u;
     }
